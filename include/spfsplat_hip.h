@@ -1,0 +1,162 @@
+/*
+ * spfsplat_hip.h -- C ABI of the MI355X (gfx950) Gaussian-splat rasterizer + RoPE-2D library
+ * (libspfsplat_hip.so).
+ *
+ * Plain pointers and sizes only: no torch / pybind types.  Every pointer is a DEVICE pointer
+ * unless its comment says "host".  The library never allocates device memory, never
+ * synchronises the device (except spf_stage_times_ms, which the caller asks for) and launches
+ * everything on the stream it is given, so it can be driven from any host language.
+ *
+ * What each entry point replaces in the reference (ranrhuang/SPFSplatV2):
+ *
+ *   spf_raster_*            the external rasterizer behind
+ *                           `GaussianRasterizer(settings)(means3D=..., viewmatrix=...)`
+ *                           src/model/decoder/cuda_splatting.py:105-138 (forward) and its autograd
+ *                           backward; package diff_gauss_pose, requirements.txt:88.  One call here
+ *                           covers a whole batch of (scene, view) renders, i.e. the Python loop at
+ *                           cuda_splatting.py:96-143 and the per-view `repeat` copies at
+ *                           src/model/decoder/decoder_splatting_cuda.py:59-64.
+ *   spf_rope2d              `rope_2d(tokens, positions, base, fwd)`
+ *                           src/model/encoder/backbone/croco/curope/curope.cpp:49-65 and
+ *                           curope/kernels.cu:84-108 (in place, forward and backward).
+ *
+ * Return value of every int function: 0 = success, otherwise a negative SPF_E_* code;
+ * spf_last_error() returns a host string describing the most recent failure on this thread.
+ */
+#ifndef SPFSPLAT_HIP_H
+#define SPFSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPF_ABI_VERSION 1
+
+#define SPF_OK 0
+#define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
+#define SPF_E_LAUNCH (-2)    /* a HIP call failed; see spf_last_error() */
+#define SPF_E_CAPACITY (-3)  /* pair buffer smaller than the number of (Gaussian, tile) pairs */
+
+#define SPF_TILE 16          /* square tile edge in pixels */
+
+/* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.
+ * All scenes hold G Gaussians with K SH coefficients per colour channel (stride); the SH basis is
+ * evaluated up to min(sh_degree, 3).  K == 0 means colours are given directly (colors_precomp). */
+typedef struct SpfDims {
+    int32_t S, V, G, K, sh_degree, H, W;
+    float scale_modifier;
+} SpfDims;
+
+/* Inputs (all float32, contiguous, row-major). */
+typedef struct SpfInputs {
+    const float* means3D;    /* [S,G,3] */
+    const float* scales;     /* [S,G,3] */
+    const float* rotations;  /* [S,G,4] quaternion (r,x,y,z), used as given (not normalised) */
+    const float* opacities;  /* [S,G]   */
+    const float* shs;        /* [S,G,K,3] or NULL when colors is set */
+    const float* colors;     /* [S,G,3]  or NULL when shs is set (colors_precomp) */
+    const float* viewmatrix; /* [S,V,4,4] world->view, row-vector convention (p_view = [p,1] @ M) */
+    const float* projmatrix; /* [S,V,4,4] perspective only, row-vector convention */
+    const float* tanfov;     /* [S,V,2] (tanfovx, tanfovy) */
+    const float* bg;         /* [S,V,3] background colour */
+    const float* view_scale; /* [S,V] or NULL (= 1): per-render world scale applied to means3D and scales
+                                inside the projection kernel -- the reference's scale-invariant
+                                normalisation (cuda_splatting.py:66-74) without per-view copies */
+} SpfInputs;
+
+/* State written by the forward pass and read by the backward pass (owned by the caller, e.g. the
+ * autograd context).  T = ceil(W/16)*ceil(H/16) tiles per render, P = H*W pixels per render. */
+typedef struct SpfState {
+    float* rec;            /* [R*G,12]  screen-space record: xy, conic(3), opacity, rgb, depth, cull r^2, flags */
+    int32_t* radii;        /* [R*G]     pixel radius, 0 = culled (also an output) */
+    uint32_t* rect;        /* [R*G]     packed tile rect: xmin | ymin<<8 | xmax<<16 | ymax<<24 */
+    uint32_t* tile_count;  /* [R*T]     Gaussians per tile */
+    uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D */
+    uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */
+    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: unused */
+    uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
+    float* final_T;        /* [R*P]     transmittance left after the last contributor */
+    uint32_t* n_contrib;   /* [R*P]     1 + list position of the last contributor (0 = none) */
+} SpfState;
+
+typedef struct SpfOutputs {
+    float* image;  /* [R,3,H,W] */
+    float* depth;  /* [R,1,H,W]  sum_i z_i alpha_i T_i */
+    float* alpha;  /* [R,1,H,W]  1 - final_T */
+} SpfOutputs;
+
+/* Upstream gradients (any may be NULL = zero) and the gradients to produce (any may be NULL = skip). */
+typedef struct SpfGrads {
+    const float* dL_dimage;   /* [R,3,H,W] */
+    const float* dL_ddepth;   /* [R,1,H,W] */
+    const float* dL_dalpha;   /* [R,1,H,W] */
+    float* grec;              /* [R*G,12] scratch: per-(render,Gaussian) screen-space grads; the library zeroes it */
+    float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
+                                 nblk = spf_raster_view_partial_blocks(G) */
+    float* dL_dmeans3D;       /* [S,G,3] */
+    float* dL_dscales;        /* [S,G,3]   (NULL when enable_cov_grad is false) */
+    float* dL_drotations;     /* [S,G,4]   (NULL when enable_cov_grad is false) */
+    float* dL_dopacities;     /* [S,G]   */
+    float* dL_dshs;           /* [S,G,K,3] (NULL when enable_sh_grad is false) */
+    float* dL_dcolors;        /* [S,G,3]   */
+    float* dL_dviewmatrix;    /* [S,V,4,4] */
+    float* dL_dmeans2D;       /* [R,G,3]   NDC-scaled screen-space gradient (xy, 0) */
+} SpfGrads;
+
+int spf_abi_version(void);
+const char* spf_last_error(void);
+
+/* Number of tiles per render and size of the vpartial scratch. */
+int spf_raster_num_tiles(int32_t H, int32_t W);
+int spf_raster_view_partial_blocks(int32_t G);
+
+/* Forward, stage 1: per-Gaussian projection / 2-D covariance / colour, per-tile counts and their
+ * scan.  On return (stream order) st->counters[0] = D and st->counters[1] = longest tile list. */
+int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream);
+
+/* Forward, stage 2: bin (Gaussian, tile) pairs into per-tile lists, depth-sort every list and
+ * composite.  `capacity` = number of uint64 entries st->pairs can hold; `max_tile_hint` = host copy
+ * of counters[1] (0 = unknown: every sort size class is launched).  If D > capacity nothing is
+ * rendered, counters[2] is set to 1 and the images are left untouched. */
+int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
+                              uint64_t capacity, uint32_t max_tile_hint, void* stream);
+
+/* Backward of both stages. */
+int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
+                        const SpfGrads* g, void* stream);
+
+/* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n) for the
+ * two outer dims, stride(H) == D and stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.
+ * positions[B,N,2] int64 contiguous (y, x).  fwd = +F0 for forward, -F0 for backward. */
+int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
+               int64_t stride_b, int64_t stride_n, int32_t dtype, float base, float fwd, void* stream);
+
+/* Per-stage device timing with HIP events recorded on the launch stream around every kernel
+ * stage.  spf_stage_timing_enable(1) clears the log and starts recording (up to
+ * SPF_STAGE_LOG launches per stage are kept); spf_stage_times_ms synchronises on the recorded
+ * events and returns, per stage, the summed device time and the number of launches logged since
+ * enable -- average launch duration = total_ms[i] / count[i]. */
+enum {
+    SPF_STAGE_PROJECT = 0,   /* forward per-Gaussian kernel */
+    SPF_STAGE_SCAN = 1,
+    SPF_STAGE_BIN = 2,
+    SPF_STAGE_SORT = 3,
+    SPF_STAGE_RENDER_FWD = 4,
+    SPF_STAGE_RENDER_BWD = 5,
+    SPF_STAGE_PROJECT_BWD = 6,
+    SPF_STAGE_ROPE = 7,
+    SPF_STAGE_COUNT = 8
+};
+#define SPF_STAGE_LOG 1024
+int spf_stage_timing_enable(int32_t on);
+int spf_stage_times_ms(float* total_ms /* host, [SPF_STAGE_COUNT] */,
+                       int32_t* count /* host, [SPF_STAGE_COUNT] */);
+const char* spf_stage_kernel_name(int32_t stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPFSPLAT_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libspfsplat_hip.so (C ABI: include/spfsplat_hip.h).
+
+The HIP library is the only compute path of this package: if it is missing or does not export the
+ABI declared in the header, importing/using the package fails loudly -- there is no CPU or
+PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "_C" / "libspfsplat_hip.so"
+ABI_VERSION = 1
+
+STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
+               "project_bwd", "rope2d")
+STAGE_COUNT = len(STAGE_NAMES)
+
+
+class SpfDims(C.Structure):
+    _fields_ = [("S", C.c_int32), ("V", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
+                ("sh_degree", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("scale_modifier", C.c_float)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields]})
+
+
+SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
+                                      "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale"])
+SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "tile_count", "tile_start", "tile_fill",
+                                    "counters", "pairs", "final_T", "n_contrib"])
+SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
+SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "grec", "vpartial",
+                                    "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",
+                                    "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D"])
+
+# Every symbol include/spfsplat_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "spf_abi_version": (C.c_int, []),
+    "spf_last_error": (C.c_char_p, []),
+    "spf_raster_num_tiles": (C.c_int, [C.c_int32, C.c_int32]),
+    "spf_raster_view_partial_blocks": (C.c_int, [C.c_int32]),
+    "spf_raster_forward_project": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
+                                             C.c_void_p]),
+    "spf_raster_forward_render": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
+                                            C.POINTER(SpfOutputs), C.c_uint64, C.c_uint32, C.c_void_p]),
+    "spf_raster_backward": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
+                                      C.POINTER(SpfGrads), C.c_void_p]),
+    "spf_rope2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                             C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+    "spf_stage_timing_enable": (C.c_int, [C.c_int32]),
+    "spf_stage_times_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "spf_stage_kernel_name": (C.c_char_p, [C.c_int32]),
+}
+
+_lib = None
+
+
+class SpfError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m spfsplatv2_amd.build` "
+            "(hipcc, gfx950).  spfsplatv2_amd has no fallback path.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.spf_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {got}, expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().spf_last_error().decode(errors="replace")
+        raise SpfError(f"{what} failed (code {rc}): {msg}")
+
+
+def stage_timing_enable(on: bool) -> None:
+    check(load().spf_stage_timing_enable(1 if on else 0), "spf_stage_timing_enable")
+
+
+def stage_times() -> dict[str, tuple[float, int]]:
+    """{stage: (total device ms, launches)} since the last stage_timing_enable(True)."""
+    ms = (C.c_float * STAGE_COUNT)()
+    cnt = (C.c_int32 * STAGE_COUNT)()
+    check(load().spf_stage_times_ms(ms, cnt), "spf_stage_times_ms")
+    return {STAGE_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(STAGE_COUNT)}
+
+
+def stage_kernel_name(stage: str) -> str:
+    return load().spf_stage_kernel_name(STAGE_NAMES.index(stage)).decode()

@@ -1,0 +1,233 @@
+// extern "C" entry points of libspfsplat_hip.so (see include/spfsplat_hip.h).
+// Validation + launch sequencing only; no device allocation, no device synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "spf_common.h"
+
+namespace spf {
+hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&, int, int, hipStream_t);
+hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, hipStream_t);
+hipError_t launch_tile_scan(const SpfState&, int, hipStream_t);
+hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
+hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
+                             hipStream_t);
+hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, hipStream_t);
+hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int, float, float, hipStream_t);
+}  // namespace spf
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define SPF_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(SPF_E_LAUNCH, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- stage timing --------------------------------------------------------------------------
+struct StageLog {
+    hipEvent_t ev[SPF_STAGE_LOG][2];
+    int created = 0;
+    int used = 0;
+};
+StageLog g_log[SPF_STAGE_COUNT];
+bool g_timing = false;
+
+struct StageScope {
+    int stage;
+    hipStream_t stream;
+    int slot = -1;
+    StageScope(int st, hipStream_t s) : stage(st), stream(s) {
+        if (!g_timing) return;
+        StageLog& L = g_log[stage];
+        if (L.used >= SPF_STAGE_LOG) return;
+        if (L.used >= L.created) {
+            if (hipEventCreate(&L.ev[L.created][0]) != hipSuccess) return;
+            if (hipEventCreate(&L.ev[L.created][1]) != hipSuccess) return;
+            L.created++;
+        }
+        slot = L.used;
+        (void)hipEventRecord(L.ev[slot][0], stream);
+    }
+    ~StageScope() {
+        if (slot < 0) return;
+        (void)hipEventRecord(g_log[stage].ev[slot][1], stream);
+        g_log[stage].used = slot + 1;
+    }
+};
+
+const char* kStageKernel[SPF_STAGE_COUNT] = {
+    "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_lds_kernel",
+    "spf_render_fwd_kernel",  "spf_render_bwd_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
+
+int check_dims(const SpfDims* d) {
+    if (!d) return fail(SPF_E_INVALID, "dims is null");
+    if (d->S <= 0 || d->V <= 0 || d->G <= 0 || d->H <= 0 || d->W <= 0)
+        return fail(SPF_E_INVALID, "S, V, G, H, W must be positive (got %d %d %d %d %d)", d->S, d->V, d->G, d->H, d->W);
+    if ((d->W + SPF_TILE - 1) / SPF_TILE > 255 || (d->H + SPF_TILE - 1) / SPF_TILE > 255)
+        return fail(SPF_E_INVALID, "image larger than 4080 px per side is not supported");
+    if (d->sh_degree < 0 || d->sh_degree > 4) return fail(SPF_E_INVALID, "sh_degree %d outside 0..4", d->sh_degree);
+    if (d->K < 0) return fail(SPF_E_INVALID, "K must be >= 0");
+    return SPF_OK;
+}
+
+int check_inputs(const SpfDims* d, const SpfInputs* in) {
+    if (!in) return fail(SPF_E_INVALID, "inputs is null");
+    if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->viewmatrix || !in->projmatrix ||
+        !in->tanfov || !in->bg)
+        return fail(SPF_E_INVALID, "a required input pointer is null");
+    if ((in->shs == nullptr) == (in->colors == nullptr))
+        return fail(SPF_E_INVALID, "exactly one of shs / colors must be given");
+    if (in->shs) {
+        const int deg = d->sh_degree > 3 ? 3 : d->sh_degree;
+        if (d->K < (deg + 1) * (deg + 1))
+            return fail(SPF_E_INVALID, "K = %d is too small for sh_degree %d", d->K, d->sh_degree);
+    }
+    return SPF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spf_abi_version(void) { return SPF_ABI_VERSION; }
+const char* spf_last_error(void) { return g_err; }
+
+int spf_raster_num_tiles(int32_t H, int32_t W) {
+    return ((W + SPF_TILE - 1) / SPF_TILE) * ((H + SPF_TILE - 1) / SPF_TILE);
+}
+int spf_raster_view_partial_blocks(int32_t G) { return (G + spf::kBlock - 1) / spf::kBlock; }
+
+int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!st || !st->rec || !st->radii || !st->rect || !st->tile_count || !st->tile_start || !st->tile_fill ||
+        !st->counters)
+        return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
+    const int RT = d->S * d->V * tiles_x * tiles_y;
+    SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * (size_t)RT, stream));
+    {
+        StageScope t(SPF_STAGE_PROJECT, stream);
+        SPF_HIP(spf::launch_project_fwd(*d, *in, *st, tiles_x, tiles_y, stream));
+    }
+    {
+        StageScope t(SPF_STAGE_SCAN, stream);
+        SPF_HIP(spf::launch_tile_scan(*st, RT, stream));
+    }
+    return SPF_OK;
+}
+
+int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out, uint64_t capacity,
+                              uint32_t max_tile_hint, void* stream_) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!st || !st->rec || !st->rect || !st->tile_start || !st->tile_fill || !st->counters || !st->final_T ||
+        !st->n_contrib)
+        return fail(SPF_E_INVALID, "a state pointer needed by forward_render is null");
+    if (capacity > 0 && !st->pairs) return fail(SPF_E_INVALID, "pairs is null but capacity > 0");
+    if (!out || !out->image || !out->depth || !out->alpha) return fail(SPF_E_INVALID, "an output pointer is null");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
+    const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
+    {
+        StageScope t(SPF_STAGE_BIN, stream);
+        SPF_HIP(spf::launch_bin_pairs(*d, *st, capacity, T, tiles_x, stream));
+    }
+    {
+        StageScope t(SPF_STAGE_SORT, stream);
+        SPF_HIP(spf::launch_tile_sort(*st, RT, capacity, max_tile_hint, stream));
+    }
+    {
+        StageScope t(SPF_STAGE_RENDER_FWD, stream);
+        SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, capacity, T, tiles_x, stream));
+    }
+    return SPF_OK;
+}
+
+int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g, void* stream_) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    rc = check_inputs(d, in);
+    if (rc) return rc;
+    if (!st || !st->rec || !st->radii || !st->tile_start || !st->pairs || !st->final_T || !st->n_contrib)
+        return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
+    if (!g || !g->grec || !g->dL_dmeans3D || !g->dL_dopacities)
+        return fail(SPF_E_INVALID, "grec, dL_dmeans3D and dL_dopacities are required");
+    if (g->dL_dviewmatrix && !g->vpartial) return fail(SPF_E_INVALID, "vpartial is required with dL_dviewmatrix");
+    if ((g->dL_dscales == nullptr) != (g->dL_drotations == nullptr))
+        return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
+    const int T = tiles_x * tiles_y;
+    const size_t RG = (size_t)d->S * d->V * d->G;
+    SPF_HIP(hipMemsetAsync(g->grec, 0, sizeof(float) * spf::kRec * RG, stream));
+    {
+        StageScope t(SPF_STAGE_RENDER_BWD, stream);
+        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, stream));
+    }
+    {
+        StageScope t(SPF_STAGE_PROJECT_BWD, stream);
+        SPF_HIP(spf::launch_project_bwd(*d, *in, *st, *g, spf_raster_view_partial_blocks(d->G), stream));
+    }
+    return SPF_OK;
+}
+
+int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D, int64_t stride_b,
+               int64_t stride_n, int32_t dtype, float base, float fwd, void* stream_) {
+    if (!tokens || !positions) return fail(SPF_E_INVALID, "tokens / positions is null");
+    if (B < 0 || N < 0 || H < 0 || D <= 0) return fail(SPF_E_INVALID, "negative size");
+    if (D % 4 != 0) return fail(SPF_E_INVALID, "token dim must be multiple of 4");
+    if (D > 256) return fail(SPF_E_INVALID, "token dim > 256 is not supported");
+    if (dtype < 0 || dtype > 2) return fail(SPF_E_INVALID, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    if ((size_t)B * N * H == 0) return SPF_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    StageScope t(SPF_STAGE_ROPE, stream);
+    SPF_HIP(spf::launch_rope2d(tokens, positions, B, N, H, D, stride_b, stride_n, dtype, base, fwd, stream));
+    return SPF_OK;
+}
+
+int spf_stage_timing_enable(int32_t on) {
+    g_timing = on != 0;
+    if (g_timing)
+        for (int s = 0; s < SPF_STAGE_COUNT; ++s) g_log[s].used = 0;
+    return SPF_OK;
+}
+
+int spf_stage_times_ms(float* total_ms, int32_t* count) {
+    if (!total_ms || !count) return fail(SPF_E_INVALID, "null output");
+    for (int s = 0; s < SPF_STAGE_COUNT; ++s) {
+        total_ms[s] = 0.f;
+        count[s] = g_log[s].used;
+        for (int i = 0; i < g_log[s].used; ++i) {
+            SPF_HIP(hipEventSynchronize(g_log[s].ev[i][1]));
+            float ms = 0.f;
+            SPF_HIP(hipEventElapsedTime(&ms, g_log[s].ev[i][0], g_log[s].ev[i][1]));
+            total_ms[s] += ms;
+        }
+    }
+    return SPF_OK;
+}
+
+const char* spf_stage_kernel_name(int32_t stage) {
+    return (stage >= 0 && stage < SPF_STAGE_COUNT) ? kStageKernel[stage] : "";
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+// Tile binning for gfx950: scan of per-tile counts, scatter-with-keys into per-tile bins
+// (an MSD counting pass on the tile id) and a per-tile depth sort done entirely in LDS.
+//
+// The classic formulation (duplicate-with-keys, then one global radix sort of 64-bit
+// tile|depth keys: SURVEY.md section 8a R2-R5) moves every pair through HBM once per radix pass.
+// Here the tile digit is resolved by a counting pass (atomics on R*T counters, which live in L2)
+// and the remaining depth order is resolved inside the 160 KiB LDS of one CU, so a pair crosses
+// HBM twice (bin write, sorted write) however long the key is.
+//
+// Result contract (Appendix B #10): every tile's list is ordered by (depth bits, Gaussian index)
+// ascending.  Keys are unique, so the result does not depend on the (non-deterministic) order in
+// which the atomics fill a bin.
+#include "spf_common.h"
+
+namespace spf {
+
+// ---- scan of tile counts: single block, n = R*T is small (<= a few 10^5) --------------------
+constexpr int kScanThreads = 1024;
+
+__global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
+                                                                     uint32_t* __restrict__ start,
+                                                                     uint32_t* __restrict__ fill,
+                                                                     uint32_t* __restrict__ counters, int n) {
+    __shared__ uint32_t s_wsum[kScanThreads / kWave];
+    __shared__ uint32_t s_wmax[kScanThreads / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + kScanThreads - 1) / kScanThreads;
+    const int b = tid * chunk, e = min(n, b + chunk);
+    uint32_t sum = 0, mx = 0;
+    for (int i = b; i < e; ++i) {
+        const uint32_t c = count[i];
+        sum += c;
+        mx = max(mx, c);
+    }
+    // inclusive scan of per-thread sums inside the wave
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
+        if (lane >= o) inc += y;
+    }
+    mx = wave_max_u32(mx);
+    if (lane == kWave - 1) s_wsum[wave] = inc;
+    if (lane == 0) s_wmax[wave] = mx;
+    __syncthreads();
+    uint32_t woff = 0, total = 0, gmax = 0;
+    for (int w = 0; w < kScanThreads / kWave; ++w) {
+        const uint32_t x = s_wsum[w];
+        if (w < wave) woff += x;
+        total += x;
+        gmax = max(gmax, s_wmax[w]);
+    }
+    uint32_t run = woff + inc - sum;  // exclusive prefix of this thread's chunk
+    for (int i = b; i < e; ++i) {
+        start[i] = run;
+        fill[i] = 0;
+        run += count[i];
+    }
+    if (tid == 0) {
+        start[n] = total;
+        counters[0] = total;
+        counters[1] = gmax;
+        counters[2] = 0;
+        counters[3] = 0;
+    }
+}
+
+// ---- scatter-with-keys: thread per (render, Gaussian) -----------------------------------------
+__global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __restrict__ rec,
+                                                               const uint32_t* __restrict__ rect,
+                                                               const uint32_t* __restrict__ tile_start,
+                                                               uint32_t* __restrict__ tile_fill,
+                                                               uint32_t* __restrict__ counters,
+                                                               uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                               int G, int T, int tiles_x, size_t RG) {
+    const size_t rg = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (counters[0] > capacity) {
+        if (rg == 0) counters[2] = 1;
+        return;
+    }
+    if (rg >= RG) return;
+    const uint32_t rc = rect[rg];
+    const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
+    if (x1 <= x0 || y1 <= y0) return;
+    const int r = (int)(rg / (size_t)G);
+    const uint32_t g = (uint32_t)(rg - (size_t)r * G);
+    const uint32_t depth_bits = __float_as_uint(rec[rg * kRec + 6]);
+    const uint64_t key = ((uint64_t)depth_bits << 32) | g;
+    const size_t tb = (size_t)r * T;
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            const size_t t = tb + ty * tiles_x + tx;
+            const uint32_t pos = tile_start[t] + atomicAdd(&tile_fill[t], 1u);
+            pairs[pos] = key;
+        }
+}
+
+// ---- per-tile sort in LDS ---------------------------------------------------------------------
+// Bitonic network in its "all comparators ascending" form (first step of every merge compares
+// i with i ^ (k-1), the rest with i ^ j): it needs no padding, because a missing partner above n
+// behaves as +infinity and an ascending comparator never moves +infinity.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void spf_sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_start,
+                                                                     const uint32_t* __restrict__ counters,
+                                                                     uint64_t* __restrict__ pairs,
+                                                                     uint64_t capacity, uint32_t lo, uint32_t hi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
+    if (counters[0] > capacity) return;
+    const uint32_t b = tile_start[blockIdx.x];
+    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    if (n <= lo || n > hi) return;
+    uint64_t* __restrict__ p = pairs + b;
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) s[i] = p[i];
+    __syncthreads();
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    const uint32_t half = m >> 1;
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
+            for (uint32_t i = threadIdx.x; i < half; i += THREADS) {
+                // i-th comparator of this step: insert a 0 bit at position log2(j)
+                const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const uint32_t c = a ^ mask;
+                if (c < n) {
+                    const uint64_t x = s[a], y = s[c];
+                    if (x > y) { s[a] = y; s[c] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) p[i] = s[i];
+}
+
+// Lists longer than the LDS classes: same network straight on global memory, one 1024-thread
+// block per tile (L2-resident; slow but exact -- a correctness fallback for degenerate scenes
+// where one tile holds > 16384 Gaussians).
+__global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint32_t* __restrict__ tile_start,
+                                                                     const uint32_t* __restrict__ counters,
+                                                                     uint64_t* pairs, uint64_t capacity,
+                                                                     uint32_t lo) {
+    if (counters[0] > capacity) return;
+    const uint32_t b = tile_start[blockIdx.x];
+    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    if (n <= lo) return;
+    volatile uint64_t* p = pairs + b;
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    const uint32_t half = m >> 1;
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
+            for (uint32_t i = threadIdx.x; i < half; i += 1024) {
+                const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const uint32_t c = a ^ mask;
+                if (c < n) {
+                    const uint64_t x = p[a], y = p[c];
+                    if (x > y) { p[a] = y; p[c] = x; }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+hipError_t launch_tile_scan(const SpfState& st, int RT, hipStream_t stream) {
+    spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.counters, RT);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
+                            hipStream_t stream) {
+    const size_t RG = (size_t)d.S * d.V * d.G;
+    const unsigned grid = (unsigned)((RG + kBlock - 1) / kBlock);
+    spf_bin_pairs_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.rect, st.tile_start, st.tile_fill, st.counters,
+                                                      st.pairs, capacity, d.G, T, tiles_x, RG);
+    return hipGetLastError();
+}
+
+// Size classes: (1, 512], (512, 2048], (2048, 8192], (8192, 16384], > 16384 (global fallback).
+hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
+                            hipStream_t stream) {
+    const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
+    if (mx > 1)
+        spf_sort_tiles_lds_kernel<256><<<RT, 256, 512 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1, 512);
+    if (mx > 512)
+        spf_sort_tiles_lds_kernel<256><<<RT, 256, 2048 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 512, 2048);
+    if (mx > 2048)
+        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
+    if (mx > 8192) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_lds_kernel<1024>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 8192, 16384);
+    }
+    if (mx > 16384)
+        spf_sort_tiles_global_kernel<<<RT, 1024, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 16384);
+    return hipGetLastError();
+}
+
+}  // namespace spf

@@ -1,0 +1,565 @@
+// Per-Gaussian projection ("preprocess") forward and backward for gfx950.
+//
+// One thread owns one Gaussian of one scene and walks that scene's V views, so the Gaussian's
+// parameters (mean, scale, quaternion, SH block) are read from HBM once per scene instead of once
+// per (scene, view) -- the reference materialises v copies of every Gaussian tensor before calling
+// its rasterizer (/root/reference/src/model/decoder/decoder_splatting_cuda.py:59-64).
+//
+// Semantics: SURVEY.md Appendix B #1-#9 (restated in oracle/splat_ref.py::project).
+#include "spf_common.h"
+
+namespace spf {
+
+struct Sym3 {  // symmetric 3x3
+    float xx, xy, xz, yy, yz, zz;
+};
+
+__device__ __forceinline__ void quat_rot(const float4 q, float R[9]) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R diag(s^2) R^T
+__device__ __forceinline__ Sym3 cov3d(const float R[9], float sx, float sy, float sz) {
+    const float a = sx * sx, b = sy * sy, c = sz * sz;
+    Sym3 S;
+    S.xx = R[0] * R[0] * a + R[1] * R[1] * b + R[2] * R[2] * c;
+    S.xy = R[0] * R[3] * a + R[1] * R[4] * b + R[2] * R[5] * c;
+    S.xz = R[0] * R[6] * a + R[1] * R[7] * b + R[2] * R[8] * c;
+    S.yy = R[3] * R[3] * a + R[4] * R[4] * b + R[5] * R[5] * c;
+    S.yz = R[3] * R[6] * a + R[4] * R[7] * b + R[5] * R[8] * c;
+    S.zz = R[6] * R[6] * a + R[7] * R[7] * b + R[8] * R[8] * c;
+    return S;
+}
+
+__device__ __forceinline__ Sym3 scaled(const Sym3& S, float k) {
+    return Sym3{S.xx * k, S.xy * k, S.xz * k, S.yy * k, S.yz * k, S.zz * k};
+}
+
+// Everything the forward and the backward need about one (view, Gaussian) projection.
+struct Proj {
+    float tx, ty, tz;          // view-space position
+    float homx, homy, pw;      // clip x, y and 1/(w+eps)
+    float px, py;              // pixel centre
+    float tcx, tcy;            // frustum-clamped t.x, t.y used in J
+    bool inx, iny;             // clamp inactive
+    float m0[3], m1[3];        // rows of M = J * Wcv
+    float J00, J02, J11, J12;
+    float a, b, c, det;        // 2-D covariance (with low-pass) and determinant
+};
+
+__device__ __forceinline__ void project_point(const float p[3], const float* __restrict__ Vm,
+                                              const float* __restrict__ Pm, float tanx, float tany,
+                                              int H, int W, const Sym3& S, Proj& o) {
+    o.tx = p[0] * Vm[0] + p[1] * Vm[4] + p[2] * Vm[8] + Vm[12];
+    o.ty = p[0] * Vm[1] + p[1] * Vm[5] + p[2] * Vm[9] + Vm[13];
+    o.tz = p[0] * Vm[2] + p[1] * Vm[6] + p[2] * Vm[10] + Vm[14];
+    o.homx = o.tx * Pm[0] + o.ty * Pm[4] + o.tz * Pm[8] + Pm[12];
+    o.homy = o.tx * Pm[1] + o.ty * Pm[5] + o.tz * Pm[9] + Pm[13];
+    const float homw = o.tx * Pm[3] + o.ty * Pm[7] + o.tz * Pm[11] + Pm[15];
+    o.pw = 1.0f / (homw + 1e-7f);
+    o.px = ((o.homx * o.pw + 1.0f) * W - 1.0f) * 0.5f;
+    o.py = ((o.homy * o.pw + 1.0f) * H - 1.0f) * 0.5f;
+
+    const float fx = W / (2.0f * tanx), fy = H / (2.0f * tany);
+    const float limx = kFovClamp * tanx, limy = kFovClamp * tany;
+    const float txz = o.tx / o.tz, tyz = o.ty / o.tz;
+    o.inx = fabsf(txz) <= limx;
+    o.iny = fabsf(tyz) <= limy;
+    o.tcx = o.inx ? o.tx : fminf(limx, fmaxf(-limx, txz)) * o.tz;
+    o.tcy = o.iny ? o.ty : fminf(limy, fmaxf(-limy, tyz)) * o.tz;
+    const float itz = 1.0f / o.tz;
+    o.J00 = fx * itz;
+    o.J11 = fy * itz;
+    o.J02 = -fx * o.tcx * itz * itz;
+    o.J12 = -fy * o.tcy * itz * itz;
+    // Wcv[i][j] = Vm[4j + i]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        o.m0[j] = o.J00 * Vm[4 * j + 0] + o.J02 * Vm[4 * j + 2];
+        o.m1[j] = o.J11 * Vm[4 * j + 1] + o.J12 * Vm[4 * j + 2];
+    }
+    // Sigma * m^T
+    const float s0x = S.xx * o.m0[0] + S.xy * o.m0[1] + S.xz * o.m0[2];
+    const float s0y = S.xy * o.m0[0] + S.yy * o.m0[1] + S.yz * o.m0[2];
+    const float s0z = S.xz * o.m0[0] + S.yz * o.m0[1] + S.zz * o.m0[2];
+    const float s1x = S.xx * o.m1[0] + S.xy * o.m1[1] + S.xz * o.m1[2];
+    const float s1y = S.xy * o.m1[0] + S.yy * o.m1[1] + S.yz * o.m1[2];
+    const float s1z = S.xz * o.m1[0] + S.yz * o.m1[1] + S.zz * o.m1[2];
+    o.a = o.m0[0] * s0x + o.m0[1] * s0y + o.m0[2] * s0z + kLowPass;
+    o.b = o.m0[0] * s1x + o.m0[1] * s1y + o.m0[2] * s1z;
+    o.c = o.m1[0] * s1x + o.m1[1] * s1y + o.m1[2] * s1z + kLowPass;
+    o.det = o.a * o.c - o.b * o.b;
+}
+
+// SH basis (deg <= 3) for unit direction (x,y,z); optional derivatives.
+template <int DEG, bool WITH_GRAD>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float* __restrict__ b,
+                                         float* __restrict__ dbx, float* __restrict__ dby,
+                                         float* __restrict__ dbz) {
+    b[0] = SH_C0;
+    if (WITH_GRAD) { dbx[0] = dby[0] = dbz[0] = 0.f; }
+    if (DEG > 0) {
+        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+        if (WITH_GRAD) {
+            dbx[1] = 0.f; dby[1] = -SH_C1; dbz[1] = 0.f;
+            dbx[2] = 0.f; dby[2] = 0.f; dbz[2] = SH_C1;
+            dbx[3] = -SH_C1; dby[3] = 0.f; dbz[3] = 0.f;
+        }
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
+        b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
+        if (WITH_GRAD) {
+            dbx[4] = SH_C2[0] * y; dby[4] = SH_C2[0] * x; dbz[4] = 0.f;
+            dbx[5] = 0.f; dby[5] = SH_C2[1] * z; dbz[5] = SH_C2[1] * y;
+            dbx[6] = SH_C2[2] * -2.f * x; dby[6] = SH_C2[2] * -2.f * y; dbz[6] = SH_C2[2] * 4.f * z;
+            dbx[7] = SH_C2[3] * z; dby[7] = 0.f; dbz[7] = SH_C2[3] * x;
+            dbx[8] = SH_C2[4] * 2.f * x; dby[8] = SH_C2[4] * -2.f * y; dbz[8] = 0.f;
+        }
+        if (DEG > 2) {
+            b[9] = SH_C3[0] * y * (3.f * xx - yy);
+            b[10] = SH_C3[1] * xy * z;
+            b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+            b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+            b[14] = SH_C3[5] * z * (xx - yy);
+            b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            if (WITH_GRAD) {
+                dbx[9] = SH_C3[0] * 6.f * xy; dby[9] = SH_C3[0] * (3.f * xx - 3.f * yy); dbz[9] = 0.f;
+                dbx[10] = SH_C3[1] * yz; dby[10] = SH_C3[1] * xz; dbz[10] = SH_C3[1] * xy;
+                dbx[11] = SH_C3[2] * -2.f * xy; dby[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy);
+                dbz[11] = SH_C3[2] * 8.f * yz;
+                dbx[12] = SH_C3[3] * -6.f * xz; dby[12] = SH_C3[3] * -6.f * yz;
+                dbz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                dbx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); dby[13] = SH_C3[4] * -2.f * xy;
+                dbz[13] = SH_C3[4] * 8.f * xz;
+                dbx[14] = SH_C3[5] * 2.f * xz; dby[14] = SH_C3[5] * -2.f * yz; dbz[14] = SH_C3[5] * (xx - yy);
+                dbx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); dby[15] = SH_C3[6] * -6.f * xy; dbz[15] = 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward.  grid = (ceil(G/256), S), block = 256.  DEG = -1: colours given (colors_precomp).
+// ------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+                                                                  int tiles_x, int tiles_y) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    if (g >= d.G) return;
+    const size_t sg = (size_t)s * d.G + g;
+    const float p0[3] = {in.means3D[3 * sg], in.means3D[3 * sg + 1], in.means3D[3 * sg + 2]};
+    const float sx = in.scales[3 * sg] * d.scale_modifier, sy = in.scales[3 * sg + 1] * d.scale_modifier,
+                sz = in.scales[3 * sg + 2] * d.scale_modifier;
+    const float4 q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+    const float opac = in.opacities[sg];
+    float R[9];
+    quat_rot(q, R);
+    const Sym3 Sg0 = cov3d(R, sx, sy, sz);
+    constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+    const int T = tiles_x * tiles_y;
+
+    for (int v = 0; v < d.V; ++v) {
+        const int r = s * d.V + v;
+        const float* __restrict__ Vm = in.viewmatrix + 16 * r;
+        const float* __restrict__ Pm = in.projmatrix + 16 * r;
+        const float tanx = in.tanfov[2 * r], tany = in.tanfov[2 * r + 1];
+        const size_t rg = (size_t)r * d.G + g;
+        float4* __restrict__ rec = reinterpret_cast<float4*>(st.rec + rg * kRec);
+        const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
+        const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
+        const Sym3 Sg = scaled(Sg0, sc * sc);
+
+        Proj pr;
+        project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
+        bool ok = pr.tz > kNearCull && pr.det != 0.0f;
+        float radius = 0.f;
+        int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+        float cA = 0.f, cB = 0.f, cC = 0.f;
+        if (ok) {
+            const float idet = 1.0f / pr.det;
+            cA = pr.c * idet; cB = -pr.b * idet; cC = pr.a * idet;
+            const float mid = 0.5f * (pr.a + pr.c);
+            const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - pr.det));
+            radius = ceilf(3.0f * sqrtf(lam));
+            ok = isfinite(pr.px) && isfinite(pr.py) && isfinite(radius);
+            if (ok) {
+                const float fgx = (float)tiles_x, fgy = (float)tiles_y;
+                x0 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px - radius) * (1.0f / kTile))));
+                y0 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py - radius) * (1.0f / kTile))));
+                x1 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px + radius + (kTile - 1)) * (1.0f / kTile))));
+                y1 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py + radius + (kTile - 1)) * (1.0f / kTile))));
+                ok = (x1 - x0) * (y1 - y0) > 0;
+            }
+        }
+        if (!ok) {
+            st.radii[rg] = 0;
+            st.rect[rg] = 0;
+            rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rec[1] = make_float4(0.f, 0.f, 0.f, -1.f);
+            rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        // colour
+        float col[3];
+        int clampmask = 0;
+        if (DEG < 0) {
+            col[0] = in.colors[3 * sg]; col[1] = in.colors[3 * sg + 1]; col[2] = in.colors[3 * sg + 2];
+        } else {
+            // campos c_j = -sum_i t_i R[j][i]
+            float dir[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
+            const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            float basis[NB];
+            sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
+                                                 nullptr, nullptr);
+            const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+            col[0] = col[1] = col[2] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                col[0] += basis[k] * sh[3 * k];
+                col[1] += basis[k] * sh[3 * k + 1];
+                col[2] += basis[k] * sh[3 * k + 2];
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                col[ch] += 0.5f;
+                if (col[ch] < 0.f) { col[ch] = 0.f; clampmask |= 1 << ch; }
+            }
+        }
+        // Conservative per-sub-tile cull radius: a pixel at squared distance d2 from the centre has
+        // q = A dx^2 + 2B dx dy + C dy^2 >= mu_min * d2, and the pixel loop drops the Gaussian when
+        // opacity * exp(-q/2) < 1/255, i.e. when q > 2 ln(255 * opacity).
+        float cull_r2;
+        const float thr = 2.0f * __logf(255.0f * opac);
+        const float mu = 0.5f * (cA + cC) - sqrtf(0.25f * (cA - cC) * (cA - cC) + cB * cB);
+        if (!(255.0f * opac > 1.0f)) cull_r2 = -1.0f;                       // never reaches 1/255
+        else if (mu > 0.f) cull_r2 = (thr * 1.001f + 1e-3f) / mu * 1.001f;  // slack for rounding
+        else cull_r2 = 3.0e38f;
+        if (!(cull_r2 == cull_r2)) cull_r2 = 3.0e38f;
+
+        st.radii[rg] = (int)radius;
+        st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+        rec[0] = make_float4(pr.px, pr.py, cA, cB);
+        rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
+        rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
+        uint32_t* __restrict__ cnt = st.tile_count + (size_t)r * T;
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward.  Same decomposition; per-view viewmatrix partials are reduced per block into
+// vpartial[r][block][12] (no float atomics -> deterministic), summed by spf_view_reduce_kernel.
+// ------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+                                                                  SpfGrads gr, int nblk) {
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
+    const bool live = g < d.G;
+    const size_t sg = (size_t)s * d.G + (live ? g : 0);
+    float p0[3] = {0.f, 0.f, 0.f};
+    float sx = 1.f, sy = 1.f, sz = 1.f, opac = 0.f;
+    float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (live) {
+        p0[0] = in.means3D[3 * sg]; p0[1] = in.means3D[3 * sg + 1]; p0[2] = in.means3D[3 * sg + 2];
+        sx = in.scales[3 * sg] * d.scale_modifier; sy = in.scales[3 * sg + 1] * d.scale_modifier;
+        sz = in.scales[3 * sg + 2] * d.scale_modifier;
+        q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+        opac = in.opacities[sg];
+    }
+    (void)opac;
+    float R[9];
+    quat_rot(q, R);
+    const Sym3 Sg0 = cov3d(R, sx, sy, sz);
+    constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+
+    float dp0[3] = {0.f, 0.f, 0.f};          // dL/dmean3D
+    float dS0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dL/dSigma as full-matrix partials, symmetrised:
+                                             // xx, xy(+yx), xz(+zx), yy, yz(+zy), zz
+    float dopac = 0.f;
+    float dcol[3] = {0.f, 0.f, 0.f};        // colours given directly
+    float dsh[NB][3];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
+
+    __shared__ float s_part[4][12];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    for (int v = 0; v < d.V; ++v) {
+        const int r = s * d.V + v;
+        const float* __restrict__ Vm = in.viewmatrix + 16 * r;
+        const float* __restrict__ Pm = in.projmatrix + 16 * r;
+        const float tanx = in.tanfov[2 * r], tany = in.tanfov[2 * r + 1];
+        const size_t rg = (size_t)r * d.G + (live ? g : 0);
+        float dV[12];  // dL/dVm[4i+j] for i<3 (index 3i+j) and dL/dVm[12+j] (index 9+j)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) dV[k] = 0.f;
+
+        const bool vis = live && st.radii[rg] > 0;
+        if (vis) {
+            const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
+            const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
+            const Sym3 Sg = scaled(Sg0, sc * sc);
+            float dp[3] = {0.f, 0.f, 0.f};
+            float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float4* __restrict__ gp = reinterpret_cast<const float4*>(gr.grec + rg * kRec);
+            const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
+            const float gx = g0.x, gy = g0.y, gA = g0.z, gB = g0.w, gC = g1.x;
+            const float gdepth = g2.y;
+            float gcol[3] = {g1.z, g1.w, g2.x};
+            dopac += g1.y;
+            if (gr.dL_dmeans2D) {
+                float* m2 = gr.dL_dmeans2D + rg * 3;
+                m2[0] = gx * 0.5f * d.W; m2[1] = gy * 0.5f * d.H; m2[2] = 0.f;
+            }
+            Proj pr;
+            project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
+            float dt[3] = {0.f, 0.f, gdepth};  // dL/dt (view space)
+
+            // ---- pixel centre -> t (through the projection matrix) ----
+            {
+                const float ax = 0.5f * d.W * gx, ay = 0.5f * d.H * gy;
+                const float dhx = ax * pr.pw, dhy = ay * pr.pw;
+                const float dhw = -pr.pw * pr.pw * (ax * pr.homx + ay * pr.homy);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dt[i] += Pm[4 * i] * dhx + Pm[4 * i + 1] * dhy + Pm[4 * i + 3] * dhw;
+            }
+            // ---- conic -> cov2D ----
+            const float idet = 1.0f / pr.det, id2 = idet * idet;
+            const float a = pr.a, b = pr.b, c = pr.c;
+            const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
+            const float db = (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC) * id2;
+            const float dc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
+            // ---- cov2D = M Sigma M^T ----
+            const float* m0 = pr.m0; const float* m1 = pr.m1;
+            dS[0] += da * m0[0] * m0[0] + db * m0[0] * m1[0] + dc * m1[0] * m1[0];
+            dS[3] += da * m0[1] * m0[1] + db * m0[1] * m1[1] + dc * m1[1] * m1[1];
+            dS[5] += da * m0[2] * m0[2] + db * m0[2] * m1[2] + dc * m1[2] * m1[2];
+            dS[1] += 2.f * da * m0[0] * m0[1] + db * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * dc * m1[0] * m1[1];
+            dS[2] += 2.f * da * m0[0] * m0[2] + db * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * dc * m1[0] * m1[2];
+            dS[4] += 2.f * da * m0[1] * m0[2] + db * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * dc * m1[1] * m1[2];
+            float Sm0[3], Sm1[3];
+            Sm0[0] = Sg.xx * m0[0] + Sg.xy * m0[1] + Sg.xz * m0[2];
+            Sm0[1] = Sg.xy * m0[0] + Sg.yy * m0[1] + Sg.yz * m0[2];
+            Sm0[2] = Sg.xz * m0[0] + Sg.yz * m0[1] + Sg.zz * m0[2];
+            Sm1[0] = Sg.xx * m1[0] + Sg.xy * m1[1] + Sg.xz * m1[2];
+            Sm1[1] = Sg.xy * m1[0] + Sg.yy * m1[1] + Sg.yz * m1[2];
+            Sm1[2] = Sg.xz * m1[0] + Sg.yz * m1[1] + Sg.zz * m1[2];
+            float dm0[3], dm1[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dm0[j] = 2.f * da * Sm0[j] + db * Sm1[j];
+                dm1[j] = 2.f * dc * Sm1[j] + db * Sm0[j];
+            }
+            // M = J Wcv, Wcv[i][j] = Vm[4j+i]:  m0[j] = J00 Vm[4j] + J02 Vm[4j+2], m1[j] = J11 Vm[4j+1] + J12 Vm[4j+2]
+            float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dJ00 += dm0[j] * Vm[4 * j];
+                dJ02 += dm0[j] * Vm[4 * j + 2];
+                dJ11 += dm1[j] * Vm[4 * j + 1];
+                dJ12 += dm1[j] * Vm[4 * j + 2];
+                dV[3 * j + 0] += dm0[j] * pr.J00;
+                dV[3 * j + 1] += dm1[j] * pr.J11;
+                dV[3 * j + 2] += dm0[j] * pr.J02 + dm1[j] * pr.J12;
+            }
+            {
+                const float fx = d.W / (2.0f * tanx), fy = d.H / (2.0f * tany);
+                const float itz = 1.0f / pr.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+                if (pr.inx) dt[0] += -fx * itz2 * dJ02;
+                if (pr.iny) dt[1] += -fy * itz2 * dJ12;
+                dt[2] += -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.f * fx * pr.tcx * itz3 * dJ02 +
+                         2.f * fy * pr.tcy * itz3 * dJ12;
+            }
+            // ---- colour ----
+            if (DEG < 0) {
+                dcol[0] += gcol[0]; dcol[1] += gcol[1]; dcol[2] += gcol[2];
+            } else {
+                const int clampmask = __float_as_int(reinterpret_cast<const float4*>(st.rec + rg * kRec)[2].w);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    if (clampmask & (1 << ch)) gcol[ch] = 0.f;
+                float vdir[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    vdir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
+                const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
+                const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
+                float basis[NB], dbx[NB], dby[NB], dbz[NB];
+                sh_basis<(DEG < 0 ? 0 : DEG), true>(x, y, z, basis, dbx, dby, dbz);
+                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                float dd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    dsh[k][0] += basis[k] * gcol[0];
+                    dsh[k][1] += basis[k] * gcol[1];
+                    dsh[k][2] += basis[k] * gcol[2];
+                    if (DEG > 0) {
+                        const float w = sh[3 * k] * gcol[0] + sh[3 * k + 1] * gcol[1] + sh[3 * k + 2] * gcol[2];
+                        dd[0] += dbx[k] * w; dd[1] += dby[k] * w; dd[2] += dbz[k] * w;
+                    }
+                }
+                if (DEG > 0) {
+                    const float dot = dd[0] * x + dd[1] * y + dd[2] * z;
+                    float dv[3] = {(dd[0] - x * dot) * inv, (dd[1] - y * dot) * inv, (dd[2] - z * dot) * inv};
+                    // v = p - c, c_j = -sum_i tvec_i Vm[4j+i]  ->  v_j = p_j + sum_i tvec_i Vm[4j+i]
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        dp[j] += dv[j];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            dV[9 + i] += dv[j] * Vm[4 * j + i];    // d/dtvec_i
+                            dV[3 * j + i] += dv[j] * Vm[12 + i];   // d/dVm[4j+i]
+                        }
+                    }
+                }
+            }
+            // ---- t = p R + tvec ----
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dp[i] += Vm[4 * i] * dt[0] + Vm[4 * i + 1] * dt[1] + Vm[4 * i + 2] * dt[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) dV[3 * i + j] += p[i] * dt[j];
+                dV[9 + i] += dt[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dp0[i] += sc * dp[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
+        }
+        // ---- block reduction of the 12 viewmatrix partials for this view ----
+        if (gr.dL_dviewmatrix) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const float tot = wave_sum(dV[k]);
+                if (lane == 0) s_part[wave][k] = tot;
+            }
+            __syncthreads();
+            if (threadIdx.x < 12)
+                gr.vpartial[((size_t)r * nblk + blockIdx.x) * 12 + threadIdx.x] =
+                    s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            __syncthreads();
+        }
+    }
+    if (!live) return;
+
+    gr.dL_dmeans3D[3 * sg] = dp0[0]; gr.dL_dmeans3D[3 * sg + 1] = dp0[1]; gr.dL_dmeans3D[3 * sg + 2] = dp0[2];
+    gr.dL_dopacities[sg] = dopac;
+    if (DEG < 0) {
+        if (gr.dL_dcolors) {
+            gr.dL_dcolors[3 * sg] = dcol[0]; gr.dL_dcolors[3 * sg + 1] = dcol[1]; gr.dL_dcolors[3 * sg + 2] = dcol[2];
+        }
+    } else if (gr.dL_dshs) {
+        float* __restrict__ o = gr.dL_dshs + sg * (size_t)d.K * 3;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { o[3 * k] = dsh[k][0]; o[3 * k + 1] = dsh[k][1]; o[3 * k + 2] = dsh[k][2]; }
+        for (int k = NB; k < d.K; ++k) { o[3 * k] = 0.f; o[3 * k + 1] = 0.f; o[3 * k + 2] = 0.f; }
+    }
+    if (gr.dL_dscales && gr.dL_drotations) {
+        // Sigma = Rm diag(s^2) Rm^T.  G = symmetric gradient matrix with G_ij = dL/dSigma_ij (full partials).
+        // dS holds xx, (xy+yx), (xz+zx), yy, (yz+zy), zz  ->  Gs = (G + G^T) has entries:
+        const float* dS = dS0;
+        const float Gs[9] = {2.f * dS[0], dS[1], dS[2], dS[1], 2.f * dS[3], dS[4], dS[2], dS[4], 2.f * dS[5]};
+        // Sigma = N N^T with N = Rm diag(s):  dL/dN = Gs N
+        const float sv[3] = {sx, sy, sz};
+        float dN[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                dN[3 * i + k] = (Gs[3 * i] * R[k] + Gs[3 * i + 1] * R[3 + k] + Gs[3 * i + 2] * R[6 + k]) * sv[k];
+        // N[i][k] = R[i][k] s_k
+        float ds[3], dR[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ds[k] = (dN[k] * R[k] + dN[3 + k] * R[3 + k] + dN[6 + k] * R[6 + k]) * d.scale_modifier;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN[3 * i + k] * sv[k];
+        }
+        gr.dL_dscales[3 * sg] = ds[0]; gr.dL_dscales[3 * sg + 1] = ds[1]; gr.dL_dscales[3 * sg + 2] = ds[2];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        float4 dq;
+        dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] -
+                      2.f * x * dR[8]);
+        dq.z = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] -
+                      2.f * y * dR[8]);
+        dq.w = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] +
+                      y * dR[7]);
+        *reinterpret_cast<float4*>(gr.dL_drotations + 4 * sg) = dq;
+    }
+}
+
+// Sum vpartial[r][0..nblk) -> dL_dviewmatrix[r] (4x4, last column zero).  grid = R, block = 64.
+__global__ void spf_view_reduce_kernel(const float* __restrict__ vpartial, float* __restrict__ dview, int nblk) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int b = lane; b < nblk; b += kWave) {
+        const float* pp = vpartial + ((size_t)r * nblk + b) * 12;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += pp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane < 16) {
+        const int i = lane >> 2, j = lane & 3;
+        float v = 0.f;
+        if (j < 3) {
+            const int k = (i < 3) ? 3 * i + j : 9 + j;
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk)
+                if (kk == k) v = acc[kk];
+        }
+        dview[16 * r + lane] = v;
+    }
+}
+
+// ---- host-side launchers (called from api.hip) ---------------------------------------------
+hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, int tiles_x, int tiles_y,
+                              hipStream_t stream) {
+    dim3 grid((d.G + kBlock - 1) / kBlock, d.S), block(kBlock);
+    const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    switch (deg) {
+        case -1: spf_project_fwd_kernel<-1><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+        case 0: spf_project_fwd_kernel<0><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+        case 1: spf_project_fwd_kernel<1><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+        case 2: spf_project_fwd_kernel<2><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+        default: spf_project_fwd_kernel<3><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
+                              int nblk, hipStream_t stream) {
+    dim3 grid(nblk, d.S), block(kBlock);
+    const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    switch (deg) {
+        case -1: spf_project_bwd_kernel<-1><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
+        case 0: spf_project_bwd_kernel<0><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
+        case 1: spf_project_bwd_kernel<1><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
+        case 2: spf_project_bwd_kernel<2><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
+        default: spf_project_bwd_kernel<3><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (g.dL_dviewmatrix) {
+        spf_view_reduce_kernel<<<d.S * d.V, kWave, 0, stream>>>(g.vpartial, g.dL_dviewmatrix, nblk);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace spf

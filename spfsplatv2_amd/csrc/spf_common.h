@@ -1,0 +1,86 @@
+// Shared device helpers for the gfx950 Gaussian-splat rasterizer.
+// Wave = 64 lanes everywhere in this library (CDNA4); no other target is supported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spfsplat_hip.h"
+
+namespace spf {
+
+constexpr int kWave = 64;
+constexpr int kRec = 12;        // floats per screen-space record / gradient record
+constexpr int kTile = SPF_TILE; // 16
+constexpr int kBlock = 256;     // one 16x16 tile = 4 waves, one 8x8 sub-tile per wave
+
+// Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
+// 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).
+// Gradient record: 0 dx, 1 dy (pixel space), 2 dA, 3 dB, 4 dC, 5 dopacity, 6..8 drgb, 9 ddepth.
+
+constexpr float kNearCull = 0.2f;
+constexpr float kLowPass = 0.3f;
+constexpr float kAlphaMax = 0.99f;
+constexpr float kAlphaMin = 1.0f / 255.0f;
+constexpr float kTMin = 1e-4f;
+constexpr float kFovClamp = 1.3f;
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,
+                                       0.31539156525252005f, -1.0925484305920792f,
+                                       0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
+                                       -0.4570457994644658f, 0.3731763325901154f,
+                                       -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// ---- DPP wave-64 reductions (result valid in lane 63) --------------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Sum over the 64 lanes; lane 63 holds the total (other lanes hold partial sums).
+__device__ __forceinline__ float wave_sum_to63(float x) {
+    float t = x;
+    t += dpp_f<0x111>(x);             // row_shr:1
+    t += dpp_f<0x112>(x);             // row_shr:2
+    t += dpp_f<0x113>(x);             // row_shr:3
+    t += dpp_f<0x114, 0xf, 0xe>(t);   // row_shr:4, banks 1-3
+    t += dpp_f<0x118, 0xf, 0xc>(t);   // row_shr:8, banks 2-3
+    t += dpp_f<0x142, 0xa>(t);        // row_bcast:15 into rows 1,3
+    t += dpp_f<0x143, 0xc>(t);        // row_bcast:31 into rows 2,3
+    return t;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+    float t = wave_sum_to63(x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t y = (uint32_t)__shfl_xor((int)x, o, 64);
+        x = x > y ? x : y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint64_t readfirstlane64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8, so give each XCD one
+// contiguous range of work ids (contiguous renders -> their records stay in that XCD's L2).
+// Speed only; correctness never depends on it.  grid must be a multiple of 8.
+__device__ __forceinline__ int xcd_remap(int block, int grid) {
+    const int per = grid >> 3;
+    return (block & 7) * per + (block >> 3);
+}
+
+}  // namespace spf

@@ -1,0 +1,253 @@
+"""Decoder glue: the reference's ``src/model/decoder`` package re-stated on top of the batched HIP
+rasterizer.  Same names, argument meaning and error behaviour as the reference so that callers
+(`ModelWrapper.training_step` etc.) can switch by changing one import:
+
+=============================  =====================================================================
+here                           reference
+=============================  =====================================================================
+``Gaussians``                  src/model/types.py:7-14
+``DecoderOutput``, ``Decoder`` src/model/decoder/decoder.py:18-45
+``get_projection_matrix``      src/model/decoder/cuda_splatting.py:15-42
+``get_fov``                    src/geometry/projection.py:269-283
+``render_cuda``                src/model/decoder/cuda_splatting.py:45-144
+``render_cuda_orthographic``   src/model/decoder/cuda_splatting.py:146-255
+``DecoderSplattingCUDACfg``    src/model/decoder/decoder_splatting_cuda.py:15-21
+``DecoderSplattingCUDA``       src/model/decoder/decoder_splatting_cuda.py:23-78
+``DECODERS``, ``get_decoder``  src/model/decoder/__init__.py:4-12
+=============================  =====================================================================
+
+What changes underneath (results are the same):
+* no Python loop over views and no ``.item()`` host syncs (cuda_splatting.py:96-143,108-109): one
+  batched launch chain, tan(fov/2) stays on the device;
+* no ``repeat`` of every Gaussian tensor per view (decoder_splatting_cuda.py:59-64): the V views of a
+  scene share its Gaussian buffers, and the scale-invariant normalisation (cuda_splatting.py:66-74)
+  is applied per view inside the projection kernel (``view_scale``);
+* the SH block is handed over in the layout the kernel reads, ``[.., K, 3]`` (cuda_splatting.py:79).
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from math import isqrt
+from typing import Generic, Literal, Optional, TypeVar
+
+import torch
+from torch import Tensor, nn
+
+from .rasterizer import rasterize_batch
+
+DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
+
+
+@dataclass
+class Gaussians:
+    means: Tensor        # [b, g, 3]
+    covariances: Tensor  # [b, g, 3, 3]   (carried, never read by the rasterizer: cuda_splatting.py:136)
+    rotations: Tensor    # [b, g, 4]
+    scales: Tensor       # [b, g, 3]
+    harmonics: Tensor    # [b, g, 3, d_sh]
+    opacities: Tensor    # [b, g]
+
+
+@dataclass
+class DecoderOutput:
+    color: Tensor            # [b, v, 3, h, w]
+    depth: Optional[Tensor]  # [b, v, h, w]
+
+
+def get_projection_matrix(near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tensor) -> Tensor:
+    """Perspective matrix [B,4,4]: x, y -> (-1, 1), z -> (0, 1), w = z_view (column-vector form)."""
+    tan_x = (0.5 * fov_x).tan()
+    tan_y = (0.5 * fov_y).tan()
+    top, right = tan_y * near, tan_x * near
+    bottom, left = -top, -right
+    (b,) = near.shape
+    out = torch.zeros((b, 4, 4), dtype=torch.float32, device=near.device)
+    out[:, 0, 0] = 2 * near / (right - left)
+    out[:, 1, 1] = 2 * near / (top - bottom)
+    out[:, 0, 2] = (right + left) / (right - left)
+    out[:, 1, 2] = (top + bottom) / (top - bottom)
+    out[:, 3, 2] = 1
+    out[:, 2, 2] = far / (far - near)
+    out[:, 2, 3] = -(far * near) / (far - near)
+    return out
+
+
+def get_fov(intrinsics: Tensor) -> Tensor:
+    """Field of view [B,2] (x, y) in radians from normalised intrinsics [B,3,3]: angle between the
+    unit rays through the midpoints of opposite image edges."""
+    inv = intrinsics.inverse()
+
+    def ray(u: float, v: float) -> Tensor:
+        p = torch.tensor([u, v, 1.0], dtype=torch.float32, device=intrinsics.device)
+        d = (inv * p[None, None, :]).sum(dim=-1)
+        return d / d.norm(dim=-1, keepdim=True)
+
+    fov_x = (ray(0.0, 0.5) * ray(1.0, 0.5)).sum(dim=-1).acos()
+    fov_y = (ray(0.5, 0.0) * ray(0.5, 1.0)).sum(dim=-1).acos()
+    return torch.stack((fov_x, fov_y), dim=-1)
+
+
+def _camera_tensors(extrinsics: Tensor, near: Tensor, far: Tensor, fov_x: Tensor, fov_y: Tensor):
+    """Row-vector view / projection matrices (the transposes built at cuda_splatting.py:88-90)."""
+    proj = get_projection_matrix(near, far, fov_x, fov_y).transpose(-1, -2)
+    view = extrinsics.inverse().transpose(-1, -2)
+    return view, proj
+
+
+def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple[int, int],
+                 background_color: Tensor, gaussian_means: Tensor, gaussian_sh_coefficients: Tensor,
+                 gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
+                 scale_invariant: bool = True, use_sh: bool = True, enable_cov_grad: bool = False,
+                 enable_sh_grad: bool = False, max_pairs: Optional[int] = None):
+    """Batched form of ``render_cuda``: b scenes x v views sharing each scene's Gaussians.
+
+    extrinsics [b,v,4,4] (camera-to-world), intrinsics [b,v,3,3] (normalised), near/far [b,v],
+    background_color [3] or [b,v,3], gaussian_* [b,g,...] with SH as [b,g,3,d_sh].
+    Returns color [b,v,3,h,w], depth [b,v,1,h,w] (in the rasterizer's normalised units: the caller
+    multiplies by near, decoder_splatting_cuda.py:72-76) and alpha [b,v,1,h,w].
+    """
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    b, v = extrinsics.shape[:2]
+    h, w = image_shape
+    view_scale = None
+    if scale_invariant:
+        scale = 1 / near                                             # [b,v]
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[..., None]
+        view_scale = scale
+        far = far * scale
+        near = near * scale
+    n = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()   # [b,g,d_sh,3]
+    fov = get_fov(intrinsics.reshape(b * v, 3, 3))
+    fov_x, fov_y = fov.unbind(dim=-1)
+    tanfov = torch.stack(((0.5 * fov_x).tan(), (0.5 * fov_y).tan()), dim=-1).reshape(b, v, 2)
+    view, proj = _camera_tensors(extrinsics.reshape(b * v, 4, 4), near.reshape(-1), far.reshape(-1), fov_x, fov_y)
+    color, depth, alpha, _radii = rasterize_batch(
+        gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
+        shs if use_sh else None, None if use_sh else shs[:, :, 0, :],
+        view.reshape(b, v, 4, 4), proj.reshape(b, v, 4, 4), tanfov, background_color,
+        h, w, degree, 1.0, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs, view_scale=view_scale)
+    return color, depth, alpha
+
+
+def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple[int, int],
+                background_color: Tensor, gaussian_means: Tensor, gaussian_covariances: Tensor,
+                gaussian_sh_coefficients: Tensor, gaussian_opacities: Tensor, gaussian_rotations: Tensor,
+                gaussian_scales: Tensor, scale_invariant: bool = True, use_sh: bool = True,
+                enable_cov_grad: bool = False, enable_sh_grad: bool = False):
+    """Same signature and result as the reference's ``render_cuda`` (flat batch: item i renders its own
+    Gaussian set ``gaussian_*[i]`` from camera i).  Returns (images [B,3,h,w], depths [B,1,h,w])."""
+    del gaussian_covariances  # dead in the reference too (cuda_splatting.py:136)
+    color, depth, _ = render_views(
+        extrinsics[:, None], intrinsics[:, None], near[:, None], far[:, None], image_shape,
+        background_color[:, None], gaussian_means, gaussian_sh_coefficients, gaussian_opacities,
+        gaussian_rotations, gaussian_scales, scale_invariant, use_sh, enable_cov_grad, enable_sh_grad)
+    return color[:, 0], depth[:, 0]
+
+
+def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor,
+                             image_shape: tuple[int, int], background_color: Tensor, gaussian_means: Tensor,
+                             gaussian_covariances: Tensor, gaussian_sh_coefficients: Tensor,
+                             gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
+                             fov_degrees: float = 0.1, use_sh: bool = True, dump: dict | None = None,
+                             enable_cov_grad: bool = False, enable_sh_grad: bool = False) -> Tensor:
+    """Fake orthographic render (tiny FOV, camera moved back); returns images [B,3,h,w]."""
+    del gaussian_covariances
+    b = extrinsics.shape[0]
+    h, w = image_shape
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
+    n = gaussian_sh_coefficients.shape[-1]
+    degree = isqrt(n) - 1
+    shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()
+
+    fov_x = torch.tensor(fov_degrees, device=extrinsics.device).deg2rad()
+    tan_fov_x = (0.5 * fov_x).tan()
+    distance_to_near = (0.5 * width) / tan_fov_x
+    tan_fov_y = 0.5 * height / distance_to_near
+    fov_y = (2 * tan_fov_y).atan()
+    near = near + distance_to_near
+    far = far + distance_to_near
+    # (the reference writes a single 4x4 here, cuda_splatting.py:183-185, which only works for batch 1)
+    move_back = torch.eye(4, dtype=torch.float32, device=extrinsics.device).repeat(b, 1, 1)
+    move_back[:, 2, 3] = -distance_to_near
+    extrinsics = extrinsics @ move_back
+    if dump is not None:
+        dump["extrinsics"] = extrinsics
+        dump["fov_x"] = fov_x
+        dump["fov_y"] = fov_y
+        dump["near"] = near
+        dump["far"] = far
+    view, proj = _camera_tensors(extrinsics, near, far, fov_x.expand(b), fov_y)
+    tanfov = torch.stack((tan_fov_x.expand(b), tan_fov_y.expand(b)), dim=-1).reshape(b, 1, 2)
+    color, _, _, _ = rasterize_batch(
+        gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
+        shs if use_sh else None, None if use_sh else shs[:, :, 0, :],
+        view[:, None], proj[:, None], tanfov, background_color[:, None],
+        h, w, degree, 1.0, enable_cov_grad, enable_sh_grad)
+    return color[:, 0]
+
+
+T = TypeVar("T")
+
+
+class Decoder(nn.Module, ABC, Generic[T]):
+    cfg: T
+
+    def __init__(self, cfg: T) -> None:
+        super().__init__()
+        self.cfg = cfg
+
+    @abstractmethod
+    def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape: tuple[int, int], depth_mode: DepthRenderingMode | None = None) -> DecoderOutput:
+        pass
+
+
+@dataclass
+class DecoderSplattingCUDACfg:
+    name: Literal["splatting_cuda"]
+    background_color: list[float]
+    make_scale_invariant: bool
+    enable_cov_grad: bool
+    enable_sh_grad: bool
+
+
+class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
+    """Drop-in for the reference decoder (kept under the reference's registry name
+    ``"splatting_cuda"``); the work runs on the MI355X HIP rasterizer."""
+
+    background_color: Tensor
+
+    def __init__(self, cfg: DecoderSplattingCUDACfg) -> None:
+        super().__init__(cfg)
+        self.make_scale_invariant = cfg.make_scale_invariant
+        self.enable_cov_grad = cfg.enable_cov_grad
+        self.enable_sh_grad = cfg.enable_sh_grad
+        self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
+                             persistent=False)
+
+    def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                image_shape: tuple[int, int], depth_mode: DepthRenderingMode | None = None) -> DecoderOutput:
+        # depth_mode is accepted and ignored, as in the reference (decoder_splatting_cuda.py:49)
+        color, depth, _ = render_views(
+            extrinsics, intrinsics, near, far, image_shape, self.background_color,
+            gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
+            scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
+            enable_sh_grad=self.enable_sh_grad)
+        depth = depth[:, :, 0]
+        if self.make_scale_invariant:
+            depth = depth * near[:, :, None, None]
+        return DecoderOutput(color, depth)
+
+
+DecoderSplattingHIP = DecoderSplattingCUDA
+
+DECODERS = {"splatting_cuda": DecoderSplattingCUDA}
+DecoderCfg = DecoderSplattingCUDACfg
+
+
+def get_decoder(decoder_cfg: DecoderCfg) -> Decoder:
+    return DECODERS[decoder_cfg.name](decoder_cfg)

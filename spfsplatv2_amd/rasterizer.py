@@ -1,0 +1,287 @@
+"""Host side of the MI355X Gaussian-splat rasterizer.
+
+Two surfaces over the same HIP library (C ABI in include/spfsplat_hip.h):
+
+* ``GaussianRasterizationSettings`` / ``GaussianRasterizer`` -- the exact call surface the reference
+  uses (/root/reference/src/model/decoder/cuda_splatting.py:105-138): one (scene, view) per call,
+  keyword arguments, 6-tuple result ``(image, depth, norm, alpha, radii, extra)``.
+* ``rasterize_batch`` -- S scenes x V views in ONE launch chain sharing each scene's Gaussian
+  buffers (what the Python loop at cuda_splatting.py:96-143 plus the ``repeat`` copies at
+  decoder_splatting_cuda.py:59-64 amount to).  This is what fills 256 CUs at 256x256.
+
+PyTorch is plumbing here (device memory, current stream, autograd bookkeeping); all arithmetic is
+in the HIP kernels.  There is no CPU path: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "last_forward_stats"]
+
+_REC = 12
+_stats: dict = {}
+
+
+def last_forward_stats() -> dict:
+    """{'num_pairs': D, 'max_tile_list': n} of the most recent forward call in this process."""
+    return dict(_stats)
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: Tensor, name: str, shape: tuple) -> Tensor:
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the rasterizer only runs on a HIP device "
+                           "(there is no CPU fallback)")
+    if tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _RasterizeBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
+                view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        S, G, _ = means3D.shape
+        V = viewmatrix.shape[1]
+        R = S * V
+        dev = means3D.device
+        K = 0 if shs is None else shs.shape[2]
+        dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier))
+        T = lib.spf_raster_num_tiles(H, W)
+        P = H * W
+        i32 = dict(dtype=torch.int32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        rec = torch.empty((R * G, _REC), **f32)
+        radii = torch.empty((R * G,), **i32)
+        rect = torch.empty((R * G,), **i32)
+        tiles = torch.empty((3 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | counters
+        tile_count = tiles[:R * T]
+        tile_start = tiles[R * T:2 * R * T + 1]
+        tile_fill = tiles[2 * R * T + 1:3 * R * T + 1]
+        counters = tiles[3 * R * T + 1:]
+        final_T = torch.empty((R * P,), **f32)
+        n_contrib = torch.empty((R * P,), **i32)
+        image = torch.empty((S, V, 3, H, W), **f32)
+        depth = torch.empty((S, V, 1, H, W), **f32)
+        alpha = torch.empty((S, V, 1, H, W), **f32)
+
+        inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
+                             _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
+                             _ptr(view_scale))
+        st = _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tile_count), _ptr(tile_start),
+                           _ptr(tile_fill), _ptr(counters), None, _ptr(final_T), _ptr(n_contrib))
+        stream = _stream_ptr(dev)
+        _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
+                   "spf_raster_forward_project")
+        if max_pairs is None:
+            # exact mode: one 16-byte read-back per BATCH (the reference syncs twice per view,
+            # cuda_splatting.py:108-109, plus once inside its rasterizer)
+            host = counters.cpu()
+            D, max_tile = int(host[0]), int(host[1])
+            capacity = D
+            _stats.update(num_pairs=D, max_tile_list=max_tile)
+        else:
+            capacity, max_tile = int(max_pairs), 0
+        pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
+        st.pairs = _ptr(pairs)
+        out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
+        _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
+                                                 capacity, max_tile, stream),
+                   "spf_raster_forward_render")
+        ctx.dims = (S, V, G, K, sh_degree, H, W, float(scale_modifier))
+        ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), max_pairs is not None)
+        ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
+        ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
+                              tanfov, bg, view_scale, rec, radii, rect, tiles, pairs, final_T, n_contrib)
+        radii_out = radii.view(S, V, G)
+        ctx.mark_non_differentiable(radii_out)
+        return image, depth, alpha, radii_out
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_alpha, _g_radii):
+        lib = _lib.load()
+        (means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, rec,
+         radii, rect, tiles, pairs, final_T, n_contrib) = ctx.saved_tensors
+        S, V, G, K, sh_degree, H, W, scale_modifier = ctx.dims
+        enable_cov_grad, enable_sh_grad, capacity_mode = ctx.flags
+        R = S * V
+        dev = means3D.device
+        T = lib.spf_raster_num_tiles(H, W)
+        if capacity_mode and int(tiles[3 * R * T + 1 + 2]) != 0:
+            raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
+                                f"({pairs.numel()} < {int(tiles[3 * R * T + 1])}); outputs were not rendered")
+        dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def up(g):
+            return None if g is None else g.contiguous().float()
+
+        g_image, g_depth, g_alpha = up(g_image), up(g_depth), up(g_alpha)
+        need = ctx.needs_input_grad
+        nblk = lib.spf_raster_view_partial_blocks(G)
+        grec = torch.empty((R * G, _REC), **f32)
+        d_means = torch.empty_like(means3D)
+        d_opac = torch.empty_like(opacities)
+        cov = enable_cov_grad and (need[1] or need[2])
+        d_scales = torch.empty_like(scales) if cov else None
+        d_rot = torch.empty_like(rotations) if cov else None
+        d_shs = torch.empty_like(shs) if (shs is not None and enable_sh_grad and need[4]) else None
+        d_col = torch.empty_like(colors) if (colors is not None and need[5]) else None
+        d_view = torch.empty_like(viewmatrix) if need[6] else None
+        vpartial = torch.empty((R, nblk, 12), **f32) if need[6] else None
+        want_m2d = ctx.means2D_shape is not None and need[17]
+        d_m2d = torch.zeros((R, G, 3), **f32) if want_m2d else None
+
+        inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
+                             _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
+                             _ptr(view_scale))
+        st = _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:R * T]),
+                           _ptr(tiles[R * T:2 * R * T + 1]), _ptr(tiles[2 * R * T + 1:3 * R * T + 1]),
+                           _ptr(tiles[3 * R * T + 1:]), _ptr(pairs), _ptr(final_T), _ptr(n_contrib))
+        gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(grec), _ptr(vpartial),
+                           _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
+                           _ptr(d_view), _ptr(d_m2d))
+        _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr),
+                                           _stream_ptr(dev)), "spf_raster_backward")
+        if d_m2d is not None:
+            d_m2d = d_m2d.view(ctx.means2D_shape)
+        return (d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, None, None, None, None,
+                None, None, None, None, None, None, d_m2d, None)
+
+
+def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
+                    shs: Optional[Tensor], colors_precomp: Optional[Tensor],
+                    viewmatrix: Tensor, projmatrix: Tensor, tanfov: Tensor, bg: Tensor,
+                    image_height: int, image_width: int, sh_degree: int, scale_modifier: float = 1.0,
+                    enable_cov_grad: bool = True, enable_sh_grad: bool = True,
+                    means2D: Optional[Tensor] = None, max_pairs: Optional[int] = None,
+                    view_scale: Optional[Tensor] = None):
+    """Render S scenes x V views.
+
+    means3D [S,G,3], scales [S,G,3], rotations [S,G,4] (r,x,y,z; used as given), opacities [S,G] or
+    [S,G,1], shs [S,G,K,3] XOR colors_precomp [S,G,3], viewmatrix / projmatrix [S,V,4,4] (row-vector
+    convention, i.e. the transposes the reference builds at cuda_splatting.py:89-90), tanfov [S,V,2],
+    bg [S,V,3] or [3].  Returns image [S,V,3,H,W], depth [S,V,1,H,W], alpha [S,V,1,H,W],
+    radii [S,V,G] int32.
+
+    ``view_scale`` ([S,V], optional): per-render world scale; render (s,v) sees ``means3D[s] * k`` and
+    ``scales[s] * k`` with ``k = view_scale[s,v]`` (the reference's scale-invariant normalisation,
+    cuda_splatting.py:66-74, fused into the projection kernel instead of materialised per view).
+
+    ``means2D`` ([S,V,G,3], optional) is only a gradient holder: if it requires grad it receives the
+    NDC-scaled screen-space gradient of every Gaussian centre (cuda_splatting.py:98-102,130).
+
+    ``max_pairs``: None = exact mode (one tiny device->host read per call to size the pair buffer);
+    an integer = sync-free mode with a fixed pair-buffer capacity (overflow raises in backward).
+    """
+    if (shs is None) == (colors_precomp is None):
+        raise RuntimeError("provide exactly one of shs / colors_precomp")
+    if means3D.dim() != 3 or means3D.shape[-1] != 3:
+        raise RuntimeError(f"means3D must be [S,G,3], got {tuple(means3D.shape)}")
+    S, G, _ = means3D.shape
+    if viewmatrix.dim() != 4:
+        raise RuntimeError(f"viewmatrix must be [S,V,4,4], got {tuple(viewmatrix.shape)}")
+    V = viewmatrix.shape[1]
+    means3D = _f32c(means3D, "means3D", (S, G, 3))
+    scales = _f32c(scales, "scales", (S, G, 3))
+    rotations = _f32c(rotations, "rotations", (S, G, 4))
+    opacities = _f32c(opacities.reshape(S, G), "opacities", (S, G))
+    if shs is not None:
+        if shs.dim() != 4 or shs.shape[-1] != 3:
+            raise RuntimeError(f"shs must be [S,G,K,3], got {tuple(shs.shape)}")
+        K = shs.shape[2]
+        if K < (min(sh_degree, 3) + 1) ** 2:
+            raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
+        shs = _f32c(shs, "shs", (S, G, K, 3))
+    else:
+        colors_precomp = _f32c(colors_precomp, "colors_precomp", (S, G, 3))
+    viewmatrix = _f32c(viewmatrix, "viewmatrix", (S, V, 4, 4))
+    projmatrix = _f32c(projmatrix, "projmatrix", (S, V, 4, 4))
+    tanfov = _f32c(tanfov, "tanfov", (S, V, 2))
+    if bg.dim() == 1:
+        bg = bg.expand(S, V, 3)
+    bg = _f32c(bg, "bg", (S, V, 3))
+    if not (0 <= sh_degree <= 4):
+        raise RuntimeError(f"sh_degree {sh_degree} outside 0..4")
+    if view_scale is not None:
+        view_scale = _f32c(view_scale.detach(), "view_scale", (S, V))
+    if means2D is not None and means2D.numel() != S * V * G * 3:
+        raise RuntimeError(f"means2D must hold S*V*G*3 elements, got {tuple(means2D.shape)}")
+    return _RasterizeBatch.apply(means3D, scales, rotations, opacities, shs, colors_precomp, viewmatrix,
+                                 projmatrix, tanfov, bg, view_scale, int(image_height), int(image_width),
+                                 int(sh_degree), float(scale_modifier), enable_cov_grad, enable_sh_grad, means2D,
+                                 max_pairs)
+
+
+# ---------------------------------------------------------------------------------------------
+# Drop-in surface of the reference's rasterizer package (diff_gauss_pose)
+# ---------------------------------------------------------------------------------------------
+class GaussianRasterizationSettings(NamedTuple):
+    """Field-for-field the settings tuple built at cuda_splatting.py:105-120."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    projmatrix: Tensor
+    sh_degree: int
+    prefiltered: bool = False
+    debug: bool = False
+    enable_cov_grad: bool = True
+    enable_sh_grad: bool = True
+
+
+class GaussianRasterizer(torch.nn.Module):
+    """``GaussianRasterizer(settings)(means3D=..., means2D=..., shs=..., colors_precomp=..., opacities=...,
+    scales=..., rotations=..., viewmatrix=...) -> (image[3,H,W], depth[1,H,W], norm, alpha[1,H,W], radii[G], extra)``
+    (call site: cuda_splatting.py:124-138).  ``norm`` and ``extra`` are not produced (None): the reference
+    never reads them (cuda_splatting.py:141-144)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D=None, opacities=None, shs=None, colors_precomp=None, scales=None,
+                rotations=None, cov3Ds_precomp=None, viewmatrix=None, extra_attrs=None):
+        s = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if cov3Ds_precomp is not None:
+            raise NotImplementedError("cov3Ds_precomp is not supported (the reference never passes it, "
+                                      "cuda_splatting.py:136)")
+        if scales is None or rotations is None:
+            raise Exception("Please provide scales and rotations")
+        if viewmatrix is None:
+            raise Exception("viewmatrix is a forward argument of this rasterizer (cuda_splatting.py:137)")
+        if extra_attrs is not None:
+            raise NotImplementedError("extra_attrs is not supported")
+        dev = means3D.device
+        tanfov = torch.tensor([[[float(s.tanfovx), float(s.tanfovy)]]], dtype=torch.float32, device=dev)
+        image, depth, alpha, radii = rasterize_batch(
+            means3D[None], scales[None], rotations[None], opacities.reshape(1, -1),
+            None if shs is None else shs[None], None if colors_precomp is None else colors_precomp[None],
+            viewmatrix[None, None], s.projmatrix[None, None], tanfov, s.bg.reshape(1, 1, 3),
+            s.image_height, s.image_width, s.sh_degree, s.scale_modifier,
+            s.enable_cov_grad, s.enable_sh_grad, means2D=means2D)
+        return image[0, 0], depth[0, 0], None, alpha[0, 0], radii[0, 0], None

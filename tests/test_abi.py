@@ -1,0 +1,71 @@
+"""C-ABI surface: the library loads without a GPU and exports exactly what include/spfsplat_hip.h declares."""
+import ctypes as C
+import re
+
+from tests.conftest import ROOT
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "spfsplat_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(hip_lib):
+    from spfsplatv2_amd import _lib
+    declared = _declared_symbols()
+    assert declared, "no symbols parsed from the header"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.spf_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    from spfsplatv2_amd import _lib
+    assert C.sizeof(_lib.SpfDims) == 32
+    assert C.sizeof(_lib.SpfInputs) == 11 * 8
+    assert C.sizeof(_lib.SpfState) == 10 * 8
+    assert C.sizeof(_lib.SpfOutputs) == 3 * 8
+    assert C.sizeof(_lib.SpfGrads) == 13 * 8
+
+
+def test_host_helpers_no_gpu(hip_lib):
+    assert hip_lib.spf_raster_num_tiles(256, 256) == 256
+    assert hip_lib.spf_raster_num_tiles(100, 33) == 7 * 3
+    assert hip_lib.spf_raster_view_partial_blocks(65536) == 256
+    assert hip_lib.spf_raster_view_partial_blocks(257) == 2
+    assert hip_lib.spf_stage_kernel_name(5) == b"spf_render_bwd_kernel"
+
+
+def test_argument_validation_without_compute(hip_lib):
+    """Bad arguments are rejected before anything touches a device."""
+    from spfsplatv2_amd import _lib
+    d = _lib.SpfDims(1, 1, 0, 1, 0, 64, 64, 1.0)            # G = 0
+    rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
+    assert rc == -1 and b"positive" in hip_lib.spf_last_error()
+    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 64, 1.0)
+    rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
+    assert rc == -1 and b"null" in hip_lib.spf_last_error()
+    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 5000, 1.0)
+    rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
+    assert rc == -1 and b"4080" in hip_lib.spf_last_error()
+    rc = hip_lib.spf_rope2d(None, None, 1, 1, 1, 64, 64, 64, 0, 100.0, 1.0, None)
+    assert rc == -1
+    rc = hip_lib.spf_rope2d(C.c_void_p(16), C.c_void_p(16), 1, 1, 1, 6, 6, 6, 0, 100.0, 1.0, None)
+    assert rc == -1 and b"multiple of 4" in hip_lib.spf_last_error()
+
+
+def test_product_refuses_cpu_tensors(hip_lib):
+    """No silent fallback: CPU tensors raise."""
+    import pytest
+    import torch
+
+    import spfsplatv2_amd as spf
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        spf.rope_2d(torch.zeros(1, 4, 2, 16), torch.zeros(1, 4, 2, dtype=torch.int64), 100.0, 1.0)
+    G = 4
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        spf.rasterize_batch(torch.zeros(1, G, 3), torch.ones(1, G, 3), torch.ones(1, G, 4), torch.ones(1, G),
+                            torch.zeros(1, G, 1, 3), None, torch.eye(4)[None, None], torch.eye(4)[None, None],
+                            torch.ones(1, 1, 2), torch.zeros(3), 16, 16, 0)
