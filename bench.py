@@ -1,0 +1,200 @@
+"""Headline benchmark: forward+backward Mpixels/s of the splat decoder path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): scenes of 65,536 pixel-aligned Gaussians, SH degree 0, rendered at
+256x256.  One STEP = one pass of the hot path over one batch that is already resident in HBM:
+`--scenes` scenes x `--views` target views per GPU (default 8 x 4 = 32 renders -- BASELINE configs[3]'s per-GPU
+share), i.e. decoder forward (projection, tile binning, depth sort, compositing) + MSE loss + full backward to
+every Gaussian parameter and to the camera poses.  Renders are independent, so N GPUs shard scene-first with no
+data-path collective (weak scaling: every rank gets its own 8 x 4 batch).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel's algorithmic HBM bytes / its HIP-event duration over the timed region
+  cpu_baseline  the CPU oracle (oracle/splat_ref.py, kind "port") timed on the host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0           # measured float4 copy ceiling
+
+
+def stage_bytes(stage: str, S: int, V: int, G: int, K: int, P: int, D_total: int) -> float:
+    """Algorithmic (compulsory) HBM bytes of ONE launch of a stage: SURVEY.md 8(d) per-unit figures x units."""
+    R = S * V
+    if stage == "project_fwd":
+        return S * G * (44 + 12 * K) + R * G * 48.0          # scene parameters once, one record per render
+    if stage == "bin_pairs":
+        return R * G * 8.0 + 12.0 * D_total
+    if stage == "tile_sort":
+        return 24.0 * D_total
+    if stage == "render_fwd":
+        return 40.0 * D_total + 28.0 * R * P
+    if stage == "render_bwd":
+        return 40.0 * D_total + 32.0 * R * P + 40.0 * R * G
+    if stage == "project_bwd":
+        return S * G * (44 + 12 * K) * 2.0 + 88.0 * R * G
+    return 0.0
+
+
+def total_bytes(S, V, G, K, P, D_total) -> float:
+    """Whole fwd+bwd path per step: A = G(308+36K) + 124 D + 60 P per render."""
+    return S * V * (G * (308 + 36 * K) + 60.0 * P) + 124.0 * D_total
+
+
+def cpu_baseline(args, batch_cpu) -> dict:
+    """CPU oracle, fwd+bwd, same workload, bounded sample (first scene, `--cpu-views` views)."""
+    from tests import util
+    from spfsplatv2_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    v = min(args.cpu_views, batch_cpu.extrinsics.shape[1])
+    sub = syn.Batch(**{k: (t[:1, :v] if k in ("extrinsics", "intrinsics", "near", "far", "target") else
+                           (t[:1] if isinstance(t, torch.Tensor) else t)) for k, t in batch_cpu.__dict__.items()})
+    t0 = time.perf_counter()
+    util.run_oracle(sub, torch.float32, want_fragile=False)
+    dt = time.perf_counter() - t0
+    h, w = sub.image_shape
+    return {"value": round(v * h * w / dt / 1e6, 4), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"1 scene x {v} views of the same C2 workload ({sub.means.shape[1]} Gaussians, {h}x{w}), "
+                      f"oracle/splat_ref.py fwd+bwd in float32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scenes", type=int, default=8, help="scenes per GPU per step")
+    ap.add_argument("--views", type=int, default=4, help="target views per scene")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--s-mult", type=float, default=1.0)
+    ap.add_argument("--cpu-views", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-free", action="store_true", help="fixed pair-buffer capacity, no per-step read-back")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import _lib, synthetic as syn
+
+    S, V = args.scenes, args.views
+    batch_cpu = syn.make_batch(args.config, S, V, seed=1000 + rank, s_mult=args.s_mult)
+    b = batch_cpu.to(dev)
+    h, w = b.image_shape
+    G, K = b.means.shape[1], b.harmonics.shape[-1]
+    names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
+    leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in names}
+    bg = torch.zeros(3, device=dev)
+    max_pairs = None
+
+    def step():
+        for t in leaves.values():
+            t.grad = None
+        color, depth, _alpha = spf.render_views(
+            leaves["extrinsics"], b.intrinsics, b.near, b.far, (h, w), bg, leaves["means"], leaves["harmonics"],
+            leaves["opacities"], leaves["rotations"], leaves["scales"], scale_invariant=True,
+            enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
+        loss = ((color - b.target) ** 2).mean()
+        loss.backward()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    step()
+    D_total = spf.last_forward_stats()["num_pairs"]
+    if args.sync_free:
+        max_pairs = int(D_total * 1.25) + 1024
+    for _ in range(args.warmup):
+        step()
+    _lib.stage_timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = _lib.stage_times()
+    _lib.stage_timing_enable(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        P = h * w
+        renders = world * S * V
+        value = renders * P * args.steps / dt / 1e6
+        raster = {k: v for k, v in stages.items() if k != "rope2d" and v[1] > 0}
+        dom = max(raster, key=lambda k: raster[k][0])
+        dom_ms = raster[dom][0] / raster[dom][1]
+        dom_bytes = stage_bytes(dom, S, V, G, K, P, D_total)
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        prof = ROOT / "profiles" / "pmc_summary.json"
+        if prof.exists():
+            try:
+                traffic = json.loads(prof.read_text()).get(_lib.stage_kernel_name(dom), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        A = total_bytes(S, V, G, K, P, D_total)
+        out = {
+            "metric": "Mpixels/s fwd+bwd, 256x256 @ ~65k Gaussians" if args.config == "C2" else
+                      f"Mpixels/s fwd+bwd ({args.config})",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, SH degree "
+                                   f"{int(K ** 0.5) - 1}, {h}x{w}, {S} scenes x {V} views per GPU per step, "
+                                   "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
+                       "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
+                       "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
+                       "s_mult": args.s_mult, "pair_buffer": "capacity" if args.sync_free else "exact",
+                       "sharding": "scene-first, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": _lib.stage_kernel_name(dom), "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "launch_ms": round(dom_ms, 5),
+                         "algorithmic_bytes_per_launch": dom_bytes,
+                         "path_achieved_GBs": round(A / (dt / args.steps) / 1e9, 2),
+                         "path_frac_of_copy_ceiling": round(A / (dt / args.steps) / 1e9 / HBM_COPY_GBS, 5)},
+            "stage_ms_per_step": {k: round(v[0] / max(v[1], 1) * (v[1] / args.steps), 5) for k, v in raster.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, batch_cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

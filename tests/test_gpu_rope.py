@@ -1,0 +1,77 @@
+"""HIP RoPE-2D (through the C ABI) vs the reference-generated goldens and the C oracle."""
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5   # BASELINE.md parity gate for curope (the reference's two own paths differ by 4e-6)
+
+
+@pytest.fixture(scope="module")
+def goldens(golden_dir):
+    return torch.load(golden_dir / "rope_goldens.pt")
+
+
+def test_goldens_fp32(hip_lib, goldens):
+    import spfsplatv2_amd as spf
+    for name, c in goldens["cases"].items():
+        buf = c["tokens_BHND"].transpose(1, 2).contiguous().cuda()           # (B,N,H,D)-major buffer
+        tok = buf.transpose(1, 2)                                             # the module sees [B,H,N,D]
+        out = spf.cuRoPE2D(freq=c["base"], F0=c["F0"])(tok, c["positions"].cuda())
+        assert out is tok                                                     # in place, same object (curope2d.py:40)
+        assert float((out.cpu() - c["out_fallback_BHND"]).abs().max()) <= TOL, name
+        assert float((buf.cpu() - c["out_cpp_BNHD"]).abs().max()) <= TOL, name
+
+
+def test_strided_qkv_view_and_neighbours_untouched(hip_lib):
+    import spfsplatv2_amd as spf
+    gen = torch.Generator().manual_seed(1)
+    B, N, H, D = 3, 258, 12, 64
+    qkv = torch.randn(B, N, 3, H, D, generator=gen)
+    pos = torch.randint(0, 18, (B, N, 2), generator=gen)
+    want_q = util.rope_oracle(qkv[:, :, 0], pos, 100.0, 1.0)
+    dev = qkv.cuda().transpose(1, 3)                # (B,H,3,N,D) view, exactly croco/blocks.py:97-98
+    q = dev[:, :, 0]                                # [B,H,N,D] non-contiguous
+    spf.cuRoPE2D()(q, pos.cuda())
+    back = dev.transpose(1, 3).cpu()
+    assert float((back[:, :, 0] - want_q).abs().max()) <= TOL
+    assert torch.equal(back[:, :, 1], qkv[:, :, 1]) and torch.equal(back[:, :, 2], qkv[:, :, 2])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 2e-2)])
+def test_half_types(hip_lib, dtype, tol):
+    import spfsplatv2_amd as spf
+    gen = torch.Generator().manual_seed(2)
+    buf = torch.randn(2, 64, 16, 64, generator=gen)
+    pos = torch.randint(0, 18, (2, 64, 2), generator=gen)
+    want = util.rope_oracle(buf.to(dtype).float(), pos, 100.0, 1.0)
+    t = buf.to(dtype).cuda()
+    spf.rope_2d(t, pos.cuda(), 100.0, 1.0)
+    assert float((t.float().cpu() - want).abs().max()) <= tol
+
+
+def test_autograd_backward_is_inverse_rotation(hip_lib):
+    import spfsplatv2_amd as spf
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 20, 4, 32, generator=gen).cuda().requires_grad_(True)     # (B,N,H,D)
+    pos = torch.randint(0, 12, (2, 20, 2), generator=gen)
+    w = torch.randn(2, 20, 4, 32, generator=gen)
+    y = spf.cuRoPE2D_func.apply(x.clone(), pos.cuda(), 100.0, 1.0)
+    (y * w.cuda()).sum().backward()
+    want = util.rope_oracle(w, pos, 100.0, -1.0)         # d/dx sum(w * R x) = R^T w = rotation by -angle
+    assert float((x.grad.cpu() - want).abs().max()) <= TOL
+
+
+def test_error_behaviour(hip_lib):
+    import spfsplatv2_amd as spf
+    t = torch.zeros(2, 4, 3, 16, device="cuda")
+    p = torch.zeros(2, 4, 2, dtype=torch.int64, device="cuda")
+    with pytest.raises(RuntimeError, match="4 dimensions"):
+        spf.rope_2d(t[0], p, 100.0, 1.0)
+    with pytest.raises(RuntimeError, match="seq_length differs"):
+        spf.rope_2d(t, p[:, :3], 100.0, 1.0)
+    with pytest.raises(RuntimeError, match="not contiguous"):
+        spf.rope_2d(t.transpose(1, 2), p.transpose(0, 1).contiguous().transpose(0, 1), 100.0, 1.0)
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        spf.rope_2d(torch.zeros(2, 4, 3, 6, device="cuda"), p, 100.0, 1.0)

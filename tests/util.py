@@ -73,7 +73,7 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
         wd, wa = loss_weights(batch)
         loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype))
         loss.backward()
-        res["loss"] = float(loss)
+        res["loss"] = float(loss.detach())
         res["grads"] = {n: leaves[n].grad.detach() for n in GRAD_NAMES}
     return res
 
@@ -97,7 +97,7 @@ def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invarian
         wd, wa = loss_weights(batch)
         loss = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device))
         loss.backward()
-        res["loss"] = float(loss)
+        res["loss"] = float(loss.detach())
         res["grads"] = {n: leaves[n].grad.detach().cpu() for n in GRAD_NAMES}
     return res
 
