@@ -71,7 +71,9 @@ def test_error_behaviour(hip_lib):
         spf.rope_2d(t[0], p, 100.0, 1.0)
     with pytest.raises(RuntimeError, match="seq_length differs"):
         spf.rope_2d(t, p[:, :3], 100.0, 1.0)
-    with pytest.raises(RuntimeError, match="not contiguous"):
-        spf.rope_2d(t.transpose(1, 2), p.transpose(0, 1).contiguous().transpose(0, 1), 100.0, 1.0)
+    with pytest.raises(RuntimeError, match="tokens are not contiguous"):
+        spf.rope_2d(torch.zeros(2, 4, 3, 32, device="cuda")[..., :16], p, 100.0, 1.0)       # stride(2) != D
+    with pytest.raises(RuntimeError, match="positions are not contiguous"):
+        spf.rope_2d(t, torch.zeros(2, 4, 4, dtype=torch.int64, device="cuda")[..., :2], 100.0, 1.0)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         spf.rope_2d(torch.zeros(2, 4, 3, 6, device="cuda"), p, 100.0, 1.0)
