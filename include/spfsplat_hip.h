@@ -16,6 +16,10 @@
  *                           covers a whole batch of (scene, view) renders, i.e. the Python loop at
  *                           cuda_splatting.py:96-143 and the per-view `repeat` copies at
  *                           src/model/decoder/decoder_splatting_cuda.py:59-64.
+ *   spf_camera_*            the camera preparation inside render_cuda: scale-invariant rescale
+ *                           (cuda_splatting.py:66-74), get_fov (src/geometry/projection.py:269-283),
+ *                           get_projection_matrix (cuda_splatting.py:15-42), extrinsics.inverse() and the
+ *                           transposes (cuda_splatting.py:84-91), and its autograd backward to the poses.
  *   spf_rope2d              `rope_2d(tokens, positions, base, fwd)`
  *                           src/model/encoder/backbone/croco/curope/curope.cpp:49-65 and
  *                           curope/kernels.cu:84-108 (in place, forward and backward).
@@ -106,12 +110,31 @@ typedef struct SpfGrads {
     float* dL_dmeans2D;       /* [R,G,3]   NDC-scaled screen-space gradient (xy, 0) */
 } SpfGrads;
 
+/* Camera set-up for R = S*V renders (all float32, contiguous). */
+typedef struct SpfCamera {
+    const float* extrinsics;  /* [R,4,4] camera-to-world (OpenCV), as the decoder receives it */
+    const float* intrinsics;  /* [R,3,3] normalised */
+    const float* near;        /* [R] */
+    const float* far;         /* [R] */
+    float* viewmatrix;        /* [R,4,4] out: inverse(extrinsics')^T (row-vector convention) */
+    float* projmatrix;        /* [R,4,4] out: perspective^T */
+    float* tanfov;            /* [R,2]   out */
+    float* view_scale;        /* [R]     out (may be NULL): 1/near when scale_invariant else 1 */
+    int32_t R;
+    int32_t scale_invariant;  /* cuda_splatting.py:66-74: translation, means, scales x 1/near; near -> 1 */
+} SpfCamera;
+
 int spf_abi_version(void);
 const char* spf_last_error(void);
 
 /* Number of tiles per render and size of the vpartial scratch. */
 int spf_raster_num_tiles(int32_t H, int32_t W);
 int spf_raster_view_partial_blocks(int32_t G);
+
+/* Camera tensors from poses / intrinsics, and the gradient of the poses from dL/dviewmatrix
+ * (dL_dviewmatrix [R,4,4] in, dL_dextrinsics [R,4,4] out; cam->viewmatrix must hold the forward result). */
+int spf_camera_forward(const SpfCamera* cam, void* stream);
+int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float* dL_dextrinsics, void* stream);
 
 /* Forward, stage 1: per-Gaussian projection / 2-D covariance / colour, per-tile counts and their
  * scan.  On return (stream order) st->counters[0] = D and st->counters[1] = longest tile list. */

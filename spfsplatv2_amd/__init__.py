@@ -2,15 +2,16 @@
 decoder / curope call surfaces.  All compute lives in libspfsplat_hip.so (C ABI: include/spfsplat_hip.h).
 """
 from . import _lib
-from .decoder import (DECODERS, Decoder, DecoderOutput, DecoderSplattingCUDA, DecoderSplattingCUDACfg,
+from .decoder import (DECODERS, camera_tensors, Decoder, DecoderOutput, DecoderSplattingCUDA, DecoderSplattingCUDACfg,
                       DecoderSplattingHIP, Gaussians, get_decoder, get_fov, get_projection_matrix, render_cuda,
                       render_cuda_orthographic, render_views)
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, last_forward_stats, rasterize_batch
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, camera_forward, last_forward_stats,
+                         rasterize_batch, render_batch)
 from .rope import RoPE2D, cuRoPE2D, cuRoPE2D_func, rope_2d
 
 __all__ = [
     "DECODERS", "Decoder", "DecoderOutput", "DecoderSplattingCUDA", "DecoderSplattingCUDACfg",
     "DecoderSplattingHIP", "Gaussians", "get_decoder", "get_fov", "get_projection_matrix", "render_cuda",
     "render_cuda_orthographic", "render_views", "GaussianRasterizationSettings", "GaussianRasterizer",
-    "last_forward_stats", "rasterize_batch", "RoPE2D", "cuRoPE2D", "cuRoPE2D_func", "rope_2d",
+    "last_forward_stats", "rasterize_batch", "render_batch", "camera_forward", "camera_tensors", "RoPE2D", "cuRoPE2D", "cuRoPE2D_func", "rope_2d",
 ]

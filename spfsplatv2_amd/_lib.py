@@ -36,12 +36,21 @@ SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "grec
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",
                                     "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D"])
 
+
+
+class SpfCamera(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in ("extrinsics", "intrinsics", "near", "far", "viewmatrix", "projmatrix",
+                                          "tanfov", "view_scale")] + [("R", C.c_int32), ("scale_invariant", C.c_int32)]
+
+
 # Every symbol include/spfsplat_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "spf_abi_version": (C.c_int, []),
     "spf_last_error": (C.c_char_p, []),
     "spf_raster_num_tiles": (C.c_int, [C.c_int32, C.c_int32]),
     "spf_raster_view_partial_blocks": (C.c_int, [C.c_int32]),
+    "spf_camera_forward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p]),
+    "spf_camera_backward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_void_p, C.c_void_p]),
     "spf_raster_forward_project": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
                                              C.c_void_p]),
     "spf_raster_forward_render": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),

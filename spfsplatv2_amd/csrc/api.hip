@@ -15,6 +15,8 @@ hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
                              hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, hipStream_t);
+hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
+hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
 hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int, float, float, hipStream_t);
 }  // namespace spf
 
@@ -109,6 +111,30 @@ int spf_raster_num_tiles(int32_t H, int32_t W) {
     return ((W + SPF_TILE - 1) / SPF_TILE) * ((H + SPF_TILE - 1) / SPF_TILE);
 }
 int spf_raster_view_partial_blocks(int32_t G) { return (G + spf::kBlock - 1) / spf::kBlock; }
+
+static int check_camera(const SpfCamera* c, bool fwd) {
+    if (!c) return fail(SPF_E_INVALID, "camera is null");
+    if (c->R <= 0) return fail(SPF_E_INVALID, "camera R must be positive");
+    if (!c->near || !c->viewmatrix) return fail(SPF_E_INVALID, "a camera pointer is null");
+    if (fwd && (!c->extrinsics || !c->intrinsics || !c->far || !c->projmatrix || !c->tanfov))
+        return fail(SPF_E_INVALID, "a camera pointer is null");
+    return SPF_OK;
+}
+
+int spf_camera_forward(const SpfCamera* cam, void* stream_) {
+    int rc = check_camera(cam, true);
+    if (rc) return rc;
+    SPF_HIP(spf::launch_camera_fwd(*cam, static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float* dL_dextrinsics, void* stream_) {
+    int rc = check_camera(cam, false);
+    if (rc) return rc;
+    if (!dL_dviewmatrix || !dL_dextrinsics) return fail(SPF_E_INVALID, "gradient pointer is null");
+    SPF_HIP(spf::launch_camera_bwd(*cam, dL_dviewmatrix, dL_dextrinsics, static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
 
 int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
     int rc = check_dims(d);

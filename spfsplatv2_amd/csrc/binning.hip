@@ -65,34 +65,62 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
     }
 }
 
-// ---- scatter-with-keys: thread per (render, Gaussian) -----------------------------------------
+// ---- scatter-with-keys: block = 256 consecutive Gaussians of one render -----------------------------
+// Three phases per block, all tile bookkeeping in LDS: (1) count the block's pairs per tile, (2) reserve one
+// contiguous range per touched tile with ONE global atomic, (3) hand out slots inside the range with LDS
+// atomics and write the keys.  lds = 0 (more than kMaxLdsTiles tiles): one global atomic per pair.
 __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __restrict__ rec,
                                                                const uint32_t* __restrict__ rect,
                                                                const uint32_t* __restrict__ tile_start,
                                                                uint32_t* __restrict__ tile_fill,
                                                                uint32_t* __restrict__ counters,
                                                                uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                               int G, int T, int tiles_x, size_t RG) {
-    const size_t rg = (size_t)blockIdx.x * kBlock + threadIdx.x;
+                                                               int G, int T, int tiles_x, int lds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases
+    uint32_t* s_cnt = s_bin;
+    uint32_t* s_base = s_bin + T;
+    const int r = blockIdx.y;
+    const int g = blockIdx.x * kBlock + threadIdx.x;
     if (counters[0] > capacity) {
-        if (rg == 0) counters[2] = 1;
+        if (r == 0 && g == 0) counters[2] = 1;
         return;
     }
-    if (rg >= RG) return;
-    const uint32_t rc = rect[rg];
+    const bool live = g < G;
+    const size_t rg = (size_t)r * G + (live ? g : 0);
+    const uint32_t rc = live ? rect[rg] : 0u;
     const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
-    if (x1 <= x0 || y1 <= y0) return;
-    const int r = (int)(rg / (size_t)G);
-    const uint32_t g = (uint32_t)(rg - (size_t)r * G);
-    const uint32_t depth_bits = __float_as_uint(rec[rg * kRec + 6]);
-    const uint64_t key = ((uint64_t)depth_bits << 32) | g;
+    const bool any = x1 > x0 && y1 > y0;
+    const uint64_t key = any ? (((uint64_t)__float_as_uint(rec[rg * kRec + 6]) << 32) | (uint32_t)g) : 0ull;
     const size_t tb = (size_t)r * T;
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            const size_t t = tb + ty * tiles_x + tx;
-            const uint32_t pos = tile_start[t] + atomicAdd(&tile_fill[t], 1u);
-            pairs[pos] = key;
+    if (!lds) {
+        if (any)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const size_t t = tb + ty * tiles_x + tx;
+                    pairs[tile_start[t] + atomicAdd(&tile_fill[t], 1u)] = key;
+                }
+        return;
+    }
+    for (int t = threadIdx.x; t < T; t += kBlock) s_cnt[t] = 0;
+    __syncthreads();
+    if (any)
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += kBlock) {
+        const uint32_t c = s_cnt[t];
+        if (c) {
+            s_base[t] = tile_start[tb + t] + atomicAdd(&tile_fill[tb + t], c);
+            s_cnt[t] = 0;
         }
+    }
+    __syncthreads();
+    if (any)
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const int t = ty * tiles_x + tx;
+                pairs[s_base[t] + atomicAdd(&s_cnt[t], 1u)] = key;
+            }
 }
 
 // ---- per-tile sort in LDS ---------------------------------------------------------------------
@@ -174,10 +202,10 @@ hipError_t launch_tile_scan(const SpfState& st, int RT, hipStream_t stream) {
 
 hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
                             hipStream_t stream) {
-    const size_t RG = (size_t)d.S * d.V * d.G;
-    const unsigned grid = (unsigned)((RG + kBlock - 1) / kBlock);
-    spf_bin_pairs_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.rect, st.tile_start, st.tile_fill, st.counters,
-                                                      st.pairs, capacity, d.G, T, tiles_x, RG);
+    dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
+    const int lds = T <= kMaxLdsTiles ? 1 : 0;
+    spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
+        st.rec, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, d.G, T, tiles_x, lds);
     return hipGetLastError();
 }
 

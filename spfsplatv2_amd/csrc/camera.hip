@@ -1,0 +1,153 @@
+// Camera set-up for a batch of renders, forward and backward, as two tiny kernels (one lane per render).
+//
+// Replaces the per-step chain of small PyTorch ops in the reference's render_cuda
+// (/root/reference/src/model/decoder/cuda_splatting.py:66-74,84-91): scale-invariant rescale of the
+// camera translation, get_fov (src/geometry/projection.py:269-283), tan(fov/2), get_projection_matrix
+// (cuda_splatting.py:15-42), extrinsics.inverse() and the two transposes.  On MI355X those ~100 launches of
+// a few microseconds each cost more host time than the whole rasterizer costs device time.
+#include "spf_common.h"
+
+namespace spf {
+
+__device__ __forceinline__ float det3(float a, float b, float c, float d, float e, float f, float g, float h,
+                                      float i) {
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+
+// General 4x4 inverse by cofactors (row-major).  Returns false if singular.
+__device__ __forceinline__ bool inv4(const float* m, float* o) {
+    float c[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            float s[9];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i != r && j != col) s[k++] = m[4 * i + j];
+            const float minor = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+            c[4 * r + col] = ((r + col) & 1) ? -minor : minor;
+        }
+    const float det = m[0] * c[0] + m[1] * c[1] + m[2] * c[2] + m[3] * c[3];
+    const float id = 1.0f / det;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int col = 0; col < 4; ++col) o[4 * r + col] = c[4 * col + r] * id;  // adjugate = cofactor^T
+    return det != 0.0f;
+}
+
+__device__ __forceinline__ void inv3(const float* m, float* o) {
+    const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const float id = 1.0f / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__device__ __forceinline__ void unit_ray(const float* Kinv, float u, float v, float* d) {
+    d[0] = Kinv[0] * u + Kinv[1] * v + Kinv[2];
+    d[1] = Kinv[3] * u + Kinv[4] * v + Kinv[5];
+    d[2] = Kinv[6] * u + Kinv[7] * v + Kinv[8];
+    const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    d[0] /= n; d[1] /= n; d[2] /= n;
+}
+
+__global__ void spf_camera_fwd_kernel(SpfCamera c) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.R) return;
+    float nr = c.near[r], fr = c.far[r];
+    const float scale = c.scale_invariant ? 1.0f / nr : 1.0f;
+    float A[16], B[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) A[i] = c.extrinsics[16 * r + i];
+    if (c.scale_invariant) {
+        A[3] *= scale; A[7] *= scale; A[11] *= scale;
+        nr = nr * scale;
+        fr = fr * scale;
+    }
+    inv4(A, B);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.viewmatrix[16 * r + 4 * i + j] = B[4 * j + i];
+    // field of view from the normalised intrinsics
+    float K[9], Ki[9], l[3], rr[3], t[3], b[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) K[i] = c.intrinsics[9 * r + i];
+    inv3(K, Ki);
+    unit_ray(Ki, 0.f, 0.5f, l); unit_ray(Ki, 1.f, 0.5f, rr);
+    unit_ray(Ki, 0.5f, 0.f, t); unit_ray(Ki, 0.5f, 1.f, b);
+    const float fov_x = acosf(l[0] * rr[0] + l[1] * rr[1] + l[2] * rr[2]);
+    const float fov_y = acosf(t[0] * b[0] + t[1] * b[1] + t[2] * b[2]);
+    const float tan_x = tanf(0.5f * fov_x), tan_y = tanf(0.5f * fov_y);
+    c.tanfov[2 * r] = tan_x;
+    c.tanfov[2 * r + 1] = tan_y;
+    if (c.view_scale) c.view_scale[r] = scale;
+    // perspective matrix (column-vector form P), stored transposed
+    const float top = tan_y * nr, bottom = -top, right = tan_x * nr, left = -right;
+    float P[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) P[i] = 0.f;
+    P[0] = 2.f * nr / (right - left);
+    P[5] = 2.f * nr / (top - bottom);
+    P[2] = (right + left) / (right - left);
+    P[6] = (top + bottom) / (top - bottom);
+    P[14] = 1.f;
+    P[10] = fr / (fr - nr);
+    P[11] = -(fr * nr) / (fr - nr);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c.projmatrix[16 * r + 4 * i + j] = P[4 * j + i];
+}
+
+// dL/dA = -B^T (dL/dB) B^T with B = A^-1 = viewmatrix^T and dL/dB = (dL/dviewmatrix)^T; then undo the
+// translation rescale.
+__global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_dview,
+                                      float* __restrict__ dL_dext) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= c.R) return;
+    const float scale = c.scale_invariant ? 1.0f / c.near[r] : 1.0f;
+    float Bt[16], Gb[16], T1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Bt[i] = c.viewmatrix[16 * r + i];            // B^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Gb[4 * i + j] = dL_dview[16 * r + 4 * j + i];  // dL/dB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += Bt[4 * i + k] * Gb[4 * k + j];
+            T1[4 * i + j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += T1[4 * i + k] * Bt[4 * k + j];
+            if (j == 3 && i < 3) s *= scale;
+            dL_dext[16 * r + 4 * i + j] = -s;
+        }
+}
+
+hipError_t launch_camera_fwd(const SpfCamera& c, hipStream_t stream) {
+    spf_camera_fwd_kernel<<<(c.R + 63) / 64, 64, 0, stream>>>(c);
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_bwd(const SpfCamera& c, const float* dL_dview, float* dL_dext, hipStream_t stream) {
+    spf_camera_bwd_kernel<<<(c.R + 63) / 64, 64, 0, stream>>>(c, dL_dview, dL_dext);
+    return hipGetLastError();
+}
+
+}  // namespace spf

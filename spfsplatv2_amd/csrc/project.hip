@@ -149,11 +149,16 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* __res
 // ------------------------------------------------------------------------------------------
 template <int DEG>
 __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
-                                                                  int tiles_x, int tiles_y) {
+                                                                  int tiles_x, int tiles_y, int lds_hist) {
+    // Per-tile counts are first accumulated in an LDS histogram of the block's render (T counters) and
+    // flushed with one global atomic per touched tile: neighbouring Gaussians of a pixel-aligned scene land
+    // in the same few tiles, so this removes most of the L2 atomic traffic.  lds_hist = 0 (T too large for
+    // LDS): straight global atomics.
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
-    if (g >= d.G) return;
-    const size_t sg = (size_t)s * d.G + g;
+    const bool live = g < d.G;
+    const size_t sg = (size_t)s * d.G + (live ? g : 0);
     const float p0[3] = {in.means3D[3 * sg], in.means3D[3 * sg + 1], in.means3D[3 * sg + 2]};
     const float sx = in.scales[3 * sg] * d.scale_modifier, sy = in.scales[3 * sg + 1] * d.scale_modifier,
                 sz = in.scales[3 * sg + 2] * d.scale_modifier;
@@ -164,13 +169,17 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
     const Sym3 Sg0 = cov3d(R, sx, sy, sz);
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
     const int T = tiles_x * tiles_y;
+    if (lds_hist) {
+        for (int t = threadIdx.x; t < T; t += kBlock) s_hist[t] = 0;
+        __syncthreads();
+    }
 
     for (int v = 0; v < d.V; ++v) {
         const int r = s * d.V + v;
         const float* __restrict__ Vm = in.viewmatrix + 16 * r;
         const float* __restrict__ Pm = in.projmatrix + 16 * r;
         const float tanx = in.tanfov[2 * r], tany = in.tanfov[2 * r + 1];
-        const size_t rg = (size_t)r * d.G + g;
+        const size_t rg = (size_t)r * d.G + (live ? g : 0);
         float4* __restrict__ rec = reinterpret_cast<float4*>(st.rec + rg * kRec);
         const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
         const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
 
         Proj pr;
         project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
-        bool ok = pr.tz > kNearCull && pr.det != 0.0f;
+        bool ok = live && pr.tz > kNearCull && pr.det != 0.0f;
         float radius = 0.f;
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         float cA = 0.f, cB = 0.f, cC = 0.f;
@@ -198,62 +207,75 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
                 ok = (x1 - x0) * (y1 - y0) > 0;
             }
         }
-        if (!ok) {
+        if (live && !ok) {
             st.radii[rg] = 0;
             st.rect[rg] = 0;
             rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             rec[1] = make_float4(0.f, 0.f, 0.f, -1.f);
             rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
         }
-        // colour
-        float col[3];
-        int clampmask = 0;
-        if (DEG < 0) {
-            col[0] = in.colors[3 * sg]; col[1] = in.colors[3 * sg + 1]; col[2] = in.colors[3 * sg + 2];
-        } else {
-            // campos c_j = -sum_i t_i R[j][i]
-            float dir[3];
+        if (ok) {
+            // colour
+            float col[3];
+            int clampmask = 0;
+            if (DEG < 0) {
+                col[0] = in.colors[3 * sg]; col[1] = in.colors[3 * sg + 1]; col[2] = in.colors[3 * sg + 2];
+            } else {
+                // campos c_j = -sum_i t_i R[j][i]
+                float dir[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
-            const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-            float basis[NB];
-            sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
-                                                 nullptr, nullptr);
-            const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
-            col[0] = col[1] = col[2] = 0.f;
+                for (int j = 0; j < 3; ++j)
+                    dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
+                const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                float basis[NB];
+                sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
+                                                     nullptr, nullptr);
+                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                col[0] = col[1] = col[2] = 0.f;
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                col[0] += basis[k] * sh[3 * k];
-                col[1] += basis[k] * sh[3 * k + 1];
-                col[2] += basis[k] * sh[3 * k + 2];
+                for (int k = 0; k < NB; ++k) {
+                    col[0] += basis[k] * sh[3 * k];
+                    col[1] += basis[k] * sh[3 * k + 1];
+                    col[2] += basis[k] * sh[3 * k + 2];
+                }
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    col[ch] += 0.5f;
+                    if (col[ch] < 0.f) { col[ch] = 0.f; clampmask |= 1 << ch; }
+                }
             }
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                col[ch] += 0.5f;
-                if (col[ch] < 0.f) { col[ch] = 0.f; clampmask |= 1 << ch; }
-            }
-        }
-        // Conservative per-sub-tile cull radius: a pixel at squared distance d2 from the centre has
-        // q = A dx^2 + 2B dx dy + C dy^2 >= mu_min * d2, and the pixel loop drops the Gaussian when
-        // opacity * exp(-q/2) < 1/255, i.e. when q > 2 ln(255 * opacity).
-        float cull_r2;
-        const float thr = 2.0f * __logf(255.0f * opac);
-        const float mu = 0.5f * (cA + cC) - sqrtf(0.25f * (cA - cC) * (cA - cC) + cB * cB);
-        if (!(255.0f * opac > 1.0f)) cull_r2 = -1.0f;                       // never reaches 1/255
-        else if (mu > 0.f) cull_r2 = (thr * 1.001f + 1e-3f) / mu * 1.001f;  // slack for rounding
-        else cull_r2 = 3.0e38f;
-        if (!(cull_r2 == cull_r2)) cull_r2 = 3.0e38f;
+            // Conservative per-sub-tile cull radius: a pixel at squared distance d2 from the centre has
+            // q = A dx^2 + 2B dx dy + C dy^2 >= mu_min * d2, and the pixel loop drops the Gaussian when
+            // opacity * exp(-q/2) < 1/255, i.e. when q > 2 ln(255 * opacity).
+            float cull_r2;
+            const float thr = 2.0f * __logf(255.0f * opac);
+            const float mu = 0.5f * (cA + cC) - sqrtf(0.25f * (cA - cC) * (cA - cC) + cB * cB);
+            if (!(255.0f * opac > 1.0f)) cull_r2 = -1.0f;                       // never reaches 1/255
+            else if (mu > 0.f) cull_r2 = (thr * 1.001f + 1e-3f) / mu * 1.001f;  // slack for rounding
+            else cull_r2 = 3.0e38f;
+            if (!(cull_r2 == cull_r2)) cull_r2 = 3.0e38f;
 
-        st.radii[rg] = (int)radius;
-        st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
-        rec[0] = make_float4(pr.px, pr.py, cA, cB);
-        rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
-        rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
-        uint32_t* __restrict__ cnt = st.tile_count + (size_t)r * T;
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+            st.radii[rg] = (int)radius;
+            st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+            rec[0] = make_float4(pr.px, pr.py, cA, cB);
+            rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
+            rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
+            uint32_t* __restrict__ cnt = lds_hist ? s_hist : st.tile_count + (size_t)r * T;
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+        }
+        if (lds_hist) {
+            __syncthreads();
+            uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
+            for (int t = threadIdx.x; t < T; t += kBlock) {
+                const uint32_t c = s_hist[t];
+                if (c) {
+                    atomicAdd(&gcnt[t], c);
+                    s_hist[t] = 0;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -532,12 +554,15 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
                               hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S), block(kBlock);
     const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    const int T = tiles_x * tiles_y;
+    const int lds = T <= kMaxLdsTiles ? 1 : 0;
+    const size_t sm = lds ? sizeof(uint32_t) * T : 0;
     switch (deg) {
-        case -1: spf_project_fwd_kernel<-1><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
-        case 0: spf_project_fwd_kernel<0><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
-        case 1: spf_project_fwd_kernel<1><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
-        case 2: spf_project_fwd_kernel<2><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
-        default: spf_project_fwd_kernel<3><<<grid, block, 0, stream>>>(d, in, st, tiles_x, tiles_y); break;
+        case -1: spf_project_fwd_kernel<-1><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
+        case 0: spf_project_fwd_kernel<0><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
+        case 1: spf_project_fwd_kernel<1><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
+        case 2: spf_project_fwd_kernel<2><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
+        default: spf_project_fwd_kernel<3><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
     }
     return hipGetLastError();
 }

@@ -13,6 +13,7 @@ constexpr int kWave = 64;
 constexpr int kRec = 12;        // floats per screen-space record / gradient record
 constexpr int kTile = SPF_TILE; // 16
 constexpr int kBlock = 256;     // one 16x16 tile = 4 waves, one 8x8 sub-tile per wave
+constexpr int kMaxLdsTiles = 4096;  // per-render tile histograms up to this many tiles live in LDS (1024x1024 px)
 
 // Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
 // 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).

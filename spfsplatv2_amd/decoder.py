@@ -34,7 +34,7 @@ from typing import Generic, Literal, Optional, TypeVar
 import torch
 from torch import Tensor, nn
 
-from .rasterizer import rasterize_batch
+from .rasterizer import rasterize_batch, render_batch
 
 DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
 
@@ -108,29 +108,33 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     multiplies by near, decoder_splatting_cuda.py:72-76) and alpha [b,v,1,h,w].
     """
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
-    b, v = extrinsics.shape[:2]
     h, w = image_shape
-    view_scale = None
-    if scale_invariant:
-        scale = 1 / near                                             # [b,v]
-        extrinsics = extrinsics.clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[..., None]
-        view_scale = scale
-        far = far * scale
-        near = near * scale
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()   # [b,g,d_sh,3]
-    fov = get_fov(intrinsics.reshape(b * v, 3, 3))
-    fov_x, fov_y = fov.unbind(dim=-1)
-    tanfov = torch.stack(((0.5 * fov_x).tan(), (0.5 * fov_y).tan()), dim=-1).reshape(b, v, 2)
-    view, proj = _camera_tensors(extrinsics.reshape(b * v, 4, 4), near.reshape(-1), far.reshape(-1), fov_x, fov_y)
-    color, depth, alpha, _radii = rasterize_batch(
-        gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
-        shs if use_sh else None, None if use_sh else shs[:, :, 0, :],
-        view.reshape(b, v, 4, 4), proj.reshape(b, v, 4, 4), tanfov, background_color,
-        h, w, degree, 1.0, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs, view_scale=view_scale)
+    color, depth, alpha, _radii = render_batch(
+        extrinsics, intrinsics, near, far, gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
+        shs if use_sh else None, None if use_sh else shs[:, :, 0, :], background_color, h, w, degree,
+        scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs)
     return color, depth, alpha
+
+
+def camera_tensors(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
+    """The camera preamble of ``render_cuda`` (cuda_splatting.py:66-74,84-91) as plain torch ops, for callers
+    that drive ``rasterize_batch`` / ``GaussianRasterizer`` themselves: flat batch [B,...] in, row-vector
+    view / projection matrices [B,4,4], tanfov [B,2] and the per-render world scale [B] out.  (The decoder itself
+    uses the fused HIP camera kernel through ``render_batch``.)"""
+    scale = torch.ones_like(near)
+    if scale_invariant:
+        scale = 1 / near
+        extrinsics = extrinsics.clone()
+        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[..., None]
+        far = far * scale
+        near = near * scale
+    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
+    tanfov = torch.stack(((0.5 * fov_x).tan(), (0.5 * fov_y).tan()), dim=-1)
+    view, proj = _camera_tensors(extrinsics, near, far, fov_x, fov_y)
+    return view, proj, tanfov, scale
 
 
 def render_cuda(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, image_shape: tuple[int, int],

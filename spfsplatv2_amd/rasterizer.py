@@ -22,7 +22,8 @@ from torch import Tensor
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "last_forward_stats"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward",
+           "last_forward_stats"]
 
 _REC = 12
 _stats: dict = {}
@@ -54,119 +55,237 @@ def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
+                  view_scale, H, W, sh_degree, scale_modifier, max_pairs):
+    """Launch the forward chain.  Returns (outputs, saved state tensors)."""
+    lib = _lib.load()
+    S, G, _ = means3D.shape
+    V = viewmatrix.shape[1]
+    R = S * V
+    dev = means3D.device
+    K = 0 if shs is None else shs.shape[2]
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier))
+    T = lib.spf_raster_num_tiles(H, W)
+    P = H * W
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    rec = torch.empty((R * G, _REC), **f32)
+    radii = torch.empty((R * G,), **i32)
+    rect = torch.empty((R * G,), **i32)
+    tiles = torch.empty((3 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | counters
+    counters = tiles[3 * R * T + 1:]
+    final_T = torch.empty((R * P,), **f32)
+    n_contrib = torch.empty((R * P,), **i32)
+    image = torch.empty((S, V, 3, H, W), **f32)
+    depth = torch.empty((S, V, 1, H, W), **f32)
+    alpha = torch.empty((S, V, 1, H, W), **f32)
+
+    inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
+                         _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
+                         _ptr(view_scale))
+    st = _state_struct(rec, radii, rect, tiles, None, final_T, n_contrib, R * T)
+    stream = _stream_ptr(dev)
+    _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
+               "spf_raster_forward_project")
+    if max_pairs is None:
+        # exact mode: one 16-byte read-back per BATCH (the reference syncs twice per view,
+        # cuda_splatting.py:108-109, plus once inside its rasterizer)
+        host = counters.cpu()
+        D, max_tile = int(host[0]), int(host[1])
+        capacity = D
+        _stats.update(num_pairs=D, max_tile_list=max_tile)
+    else:
+        capacity, max_tile = int(max_pairs), 0
+    pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
+    st.pairs = _ptr(pairs)
+    out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
+    _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
+                                             capacity, max_tile, stream),
+               "spf_raster_forward_render")
+    return (image, depth, alpha, radii.view(S, V, G)), (rec, radii, rect, tiles, pairs, final_T, n_contrib)
+
+
+def _state_struct(rec, radii, rect, tiles, pairs, final_T, n_contrib, RT):
+    return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:RT]), _ptr(tiles[RT:2 * RT + 1]),
+                         _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:]), _ptr(pairs),
+                         _ptr(final_T), _ptr(n_contrib))
+
+
+def _backward_impl(inputs, state, geom, grads_out, want):
+    """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
+    lib = _lib.load()
+    means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
+    rec, radii, rect, tiles, pairs, final_T, n_contrib = state
+    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode = geom
+    R = S * V
+    dev = means3D.device
+    T = lib.spf_raster_num_tiles(H, W)
+    if capacity_mode and int(tiles[3 * R * T + 1 + 2]) != 0:
+        raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
+                            f"({pairs.numel()} < {int(tiles[3 * R * T + 1])}); outputs were not rendered")
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
+    nblk = lib.spf_raster_view_partial_blocks(G)
+    grec = torch.empty((R * G, _REC), **f32)
+    d_means = torch.empty_like(means3D)
+    d_opac = torch.empty_like(opacities)
+    d_scales = torch.empty_like(scales) if want["scales_rot"] else None
+    d_rot = torch.empty_like(rotations) if want["scales_rot"] else None
+    d_shs = torch.empty_like(shs) if (shs is not None and want["shs"]) else None
+    d_col = torch.empty_like(colors) if (colors is not None and want["colors"]) else None
+    d_view = torch.empty_like(viewmatrix) if want["view"] else None
+    vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
+    d_m2d = torch.zeros((R, G, 3), **f32) if want["means2D"] else None
+    inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
+                         _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
+                         _ptr(view_scale))
+    st = _state_struct(rec, radii, rect, tiles, pairs, final_T, n_contrib, R * T)
+    gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(grec), _ptr(vpartial),
+                       _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
+                       _ptr(d_view), _ptr(d_m2d))
+    _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr),
+                                       _stream_ptr(dev)), "spf_raster_backward")
+    return d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d
+
+
 class _RasterizeBatch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                 view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs):
-        lib = _lib.load()
         ctx.set_materialize_grads(False)
+        outs, state = _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
+                                    tanfov, bg, view_scale, H, W, sh_degree, scale_modifier, max_pairs)
         S, G, _ = means3D.shape
-        V = viewmatrix.shape[1]
-        R = S * V
-        dev = means3D.device
-        K = 0 if shs is None else shs.shape[2]
-        dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier))
-        T = lib.spf_raster_num_tiles(H, W)
-        P = H * W
-        i32 = dict(dtype=torch.int32, device=dev)
-        f32 = dict(dtype=torch.float32, device=dev)
-
-        rec = torch.empty((R * G, _REC), **f32)
-        radii = torch.empty((R * G,), **i32)
-        rect = torch.empty((R * G,), **i32)
-        tiles = torch.empty((3 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | counters
-        tile_count = tiles[:R * T]
-        tile_start = tiles[R * T:2 * R * T + 1]
-        tile_fill = tiles[2 * R * T + 1:3 * R * T + 1]
-        counters = tiles[3 * R * T + 1:]
-        final_T = torch.empty((R * P,), **f32)
-        n_contrib = torch.empty((R * P,), **i32)
-        image = torch.empty((S, V, 3, H, W), **f32)
-        depth = torch.empty((S, V, 1, H, W), **f32)
-        alpha = torch.empty((S, V, 1, H, W), **f32)
-
-        inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
-                             _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                             _ptr(view_scale))
-        st = _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tile_count), _ptr(tile_start),
-                           _ptr(tile_fill), _ptr(counters), None, _ptr(final_T), _ptr(n_contrib))
-        stream = _stream_ptr(dev)
-        _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
-                   "spf_raster_forward_project")
-        if max_pairs is None:
-            # exact mode: one 16-byte read-back per BATCH (the reference syncs twice per view,
-            # cuda_splatting.py:108-109, plus once inside its rasterizer)
-            host = counters.cpu()
-            D, max_tile = int(host[0]), int(host[1])
-            capacity = D
-            _stats.update(num_pairs=D, max_tile_list=max_tile)
-        else:
-            capacity, max_tile = int(max_pairs), 0
-        pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
-        st.pairs = _ptr(pairs)
-        out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
-        _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
-                                                 capacity, max_tile, stream),
-                   "spf_raster_forward_render")
-        ctx.dims = (S, V, G, K, sh_degree, H, W, float(scale_modifier))
-        ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), max_pairs is not None)
+        ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
+                    float(scale_modifier), max_pairs is not None)
+        ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
-                              tanfov, bg, view_scale, rec, radii, rect, tiles, pairs, final_T, n_contrib)
-        radii_out = radii.view(S, V, G)
-        ctx.mark_non_differentiable(radii_out)
-        return image, depth, alpha, radii_out
+                              tanfov, bg, view_scale, *state)
+        ctx.mark_non_differentiable(outs[3])
+        return outs
 
     @staticmethod
     def backward(ctx, g_image, g_depth, g_alpha, _g_radii):
-        lib = _lib.load()
-        (means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, rec,
-         radii, rect, tiles, pairs, final_T, n_contrib) = ctx.saved_tensors
-        S, V, G, K, sh_degree, H, W, scale_modifier = ctx.dims
-        enable_cov_grad, enable_sh_grad, capacity_mode = ctx.flags
-        R = S * V
-        dev = means3D.device
-        T = lib.spf_raster_num_tiles(H, W)
-        if capacity_mode and int(tiles[3 * R * T + 1 + 2]) != 0:
-            raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
-                                f"({pairs.numel()} < {int(tiles[3 * R * T + 1])}); outputs were not rendered")
-        dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)
-        f32 = dict(dtype=torch.float32, device=dev)
-
-        def up(g):
-            return None if g is None else g.contiguous().float()
-
-        g_image, g_depth, g_alpha = up(g_image), up(g_depth), up(g_alpha)
+        saved = ctx.saved_tensors
         need = ctx.needs_input_grad
-        nblk = lib.spf_raster_view_partial_blocks(G)
-        grec = torch.empty((R * G, _REC), **f32)
-        d_means = torch.empty_like(means3D)
-        d_opac = torch.empty_like(opacities)
-        cov = enable_cov_grad and (need[1] or need[2])
-        d_scales = torch.empty_like(scales) if cov else None
-        d_rot = torch.empty_like(rotations) if cov else None
-        d_shs = torch.empty_like(shs) if (shs is not None and enable_sh_grad and need[4]) else None
-        d_col = torch.empty_like(colors) if (colors is not None and need[5]) else None
-        d_view = torch.empty_like(viewmatrix) if need[6] else None
-        vpartial = torch.empty((R, nblk, 12), **f32) if need[6] else None
-        want_m2d = ctx.means2D_shape is not None and need[17]
-        d_m2d = torch.zeros((R, G, 3), **f32) if want_m2d else None
-
-        inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
-                             _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                             _ptr(view_scale))
-        st = _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:R * T]),
-                           _ptr(tiles[R * T:2 * R * T + 1]), _ptr(tiles[2 * R * T + 1:3 * R * T + 1]),
-                           _ptr(tiles[3 * R * T + 1:]), _ptr(pairs), _ptr(final_T), _ptr(n_contrib))
-        gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(grec), _ptr(vpartial),
-                           _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
-                           _ptr(d_view), _ptr(d_m2d))
-        _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr),
-                                           _stream_ptr(dev)), "spf_raster_backward")
+        enable_cov_grad, enable_sh_grad = ctx.flags
+        want = dict(scales_rot=enable_cov_grad and (need[1] or need[2]), shs=enable_sh_grad and need[4],
+                    colors=need[5], view=need[6], means2D=ctx.means2D_shape is not None and need[17])
+        d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d = _backward_impl(
+            saved[:11], saved[11:], ctx.geom, (g_image, g_depth, g_alpha), want)
         if d_m2d is not None:
             d_m2d = d_m2d.view(ctx.means2D_shape)
         return (d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, None, None, None, None,
                 None, None, None, None, None, None, d_m2d, None)
+
+
+class _DecoderRender(torch.autograd.Function):
+    """Camera set-up + rasterizer as ONE autograd node (poses in, images out): the whole of
+    render_cuda (cuda_splatting.py:45-144) for b scenes x v views without any intermediate torch op."""
+
+    @staticmethod
+    def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
+                H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs):
+        ctx.set_materialize_grads(False)
+        lib = _lib.load()
+        S, V = extrinsics.shape[:2]
+        dev = means3D.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        view = torch.empty((S, V, 4, 4), **f32)
+        proj = torch.empty((S, V, 4, 4), **f32)
+        tanfov = torch.empty((S, V, 2), **f32)
+        vscale = torch.empty((S, V), **f32) if scale_invariant else None
+        cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
+                             _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
+        _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
+        outs, state = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg,
+                                    vscale, H, W, sh_degree, 1.0, max_pairs)
+        G = means3D.shape[1]
+        ctx.geom = (S, V, G, 0 if shs is None else shs.shape[2], sh_degree, H, W, 1.0, max_pairs is not None)
+        ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
+        ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
+                              *state, near)
+        ctx.mark_non_differentiable(outs[3])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_image, g_depth, g_alpha, _g_radii):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        enable_cov_grad, enable_sh_grad, scale_invariant = ctx.flags
+        want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
+                    colors=need[9], view=need[0], means2D=False)
+        d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, _ = _backward_impl(
+            saved[:11], saved[11:18], ctx.geom, (g_image, g_depth, g_alpha), want)
+        d_ext = None
+        if need[0]:
+            view, near = saved[6], saved[18]
+            d_ext = torch.empty_like(view)
+            cam = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(view), None, None, None,
+                                 view.shape[0] * view.shape[1], 1 if scale_invariant else 0)
+            _lib.check(lib.spf_camera_backward(C.byref(cam), _ptr(d_view), _ptr(d_ext), _stream_ptr(view.device)),
+                       "spf_camera_backward")
+        return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
+                None, None, None, None, None, None, None)
+
+
+def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
+    """HIP camera set-up kernel on its own (no autograd): [S,V,...] poses -> (viewmatrix [S,V,4,4],
+    projmatrix [S,V,4,4], tanfov [S,V,2], view_scale [S,V]) exactly as ``render_batch`` feeds the rasterizer."""
+    lib = _lib.load()
+    S, V = extrinsics.shape[:2]
+    extrinsics = _f32c(extrinsics.detach(), "extrinsics", (S, V, 4, 4))
+    intrinsics = _f32c(intrinsics, "intrinsics", (S, V, 3, 3))
+    near = _f32c(near, "near", (S, V))
+    far = _f32c(far, "far", (S, V))
+    f32 = dict(dtype=torch.float32, device=extrinsics.device)
+    view, proj = torch.empty((S, V, 4, 4), **f32), torch.empty((S, V, 4, 4), **f32)
+    tanfov, vscale = torch.empty((S, V, 2), **f32), torch.empty((S, V), **f32)
+    cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
+                         _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
+    _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(extrinsics.device)), "spf_camera_forward")
+    return view, proj, tanfov, vscale
+
+
+def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+                 means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
+                 shs: Optional[Tensor], colors_precomp: Optional[Tensor], bg: Tensor,
+                 image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
+                 enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs: Optional[int] = None):
+    """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
+
+    extrinsics [S,V,4,4] camera-to-world, intrinsics [S,V,3,3] normalised, near/far [S,V]; Gaussians as in
+    ``rasterize_batch``.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units), alpha [S,V,1,H,W],
+    radii [S,V,G]."""
+    if (shs is None) == (colors_precomp is None):
+        raise RuntimeError("provide exactly one of shs / colors_precomp")
+    S, G, _ = means3D.shape
+    V = extrinsics.shape[1]
+    extrinsics = _f32c(extrinsics, "extrinsics", (S, V, 4, 4))
+    intrinsics = _f32c(intrinsics, "intrinsics", (S, V, 3, 3))
+    near = _f32c(near, "near", (S, V))
+    far = _f32c(far, "far", (S, V))
+    means3D = _f32c(means3D, "means3D", (S, G, 3))
+    scales = _f32c(scales, "scales", (S, G, 3))
+    rotations = _f32c(rotations, "rotations", (S, G, 4))
+    opacities = _f32c(opacities.reshape(S, G), "opacities", (S, G))
+    if shs is not None:
+        K = shs.shape[2]
+        if K < (min(sh_degree, 3) + 1) ** 2:
+            raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
+        shs = _f32c(shs, "shs", (S, G, K, 3))
+    else:
+        colors_precomp = _f32c(colors_precomp, "colors_precomp", (S, G, 3))
+    if bg.dim() == 1:
+        bg = bg.expand(S, V, 3)
+    bg = _f32c(bg, "bg", (S, V, 3))
+    return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
+                                colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
+                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs)
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,

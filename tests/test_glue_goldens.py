@@ -110,49 +110,68 @@ def _expand_batched_call(c: dict) -> list[dict]:
     return out
 
 
+def _expected_camera(g):
+    """(view [N,4,4], proj [N,4,4], tanfov [N,2], scale [N]) the reference used, from the recorded calls."""
+    i = g["inputs"]
+    view = torch.stack([c["kwargs"]["viewmatrix"] for c in g["calls"]])
+    proj = torch.stack([c["settings"]["projmatrix"] for c in g["calls"]])
+    tanfov = torch.tensor([[c["settings"]["tanfovx"], c["settings"]["tanfovy"]] for c in g["calls"]])
+    scale = (1 / i["near"]).reshape(-1) if i["make_scale_invariant"] else torch.ones(i["near"].numel())
+    return view, proj, tanfov, scale
+
+
 @pytest.mark.parametrize("tag", ["decoder_k4_si", "decoder_k25_nosi"])
-def test_product_decoder_matches_reference_callsite(golden_dir, tag, monkeypatch):
+def test_product_torch_camera_path_matches_reference_callsite(golden_dir, tag):
+    """spfsplatv2_amd.camera_tensors (the torch preamble offered to direct users of rasterize_batch)."""
     from spfsplatv2_amd import decoder as dec
     g = torch.load(golden_dir / f"callsite_{tag}.pt")
     i = g["inputs"]
-    rec = _Recorder()
-    monkeypatch.setattr(dec, "rasterize_batch", rec)
-    cfg = dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=i["background_color"],
-                                      make_scale_invariant=i["make_scale_invariant"], enable_cov_grad=True,
-                                      enable_sh_grad=True)
-    d = dec.get_decoder(cfg)
-    gs = dec.Gaussians(i["means"], i["covariances"], i["rotations"], i["scales"], i["harmonics"], i["opacities"])
-    out = d.forward(gs, i["extrinsics"], i["intrinsics"], i["near"], i["far"], i["image_shape"])
-    assert len(rec.calls) == 1                                 # one batched launch chain, not b*v calls
-    got = _expand_batched_call(rec.calls[0])
-    assert len(got) == len(g["calls"])
-    for a, w in zip(got, g["calls"]):
-        _check_call(a, w)
-    assert tuple(out.color.shape) == g["decoder_color_shape"]
-    # post-processing of depth (x near when scale-invariant): the recorder returns depth 2 everywhere, the
-    # reference's fake returned 2 + call#
     b, v = i["extrinsics"].shape[:2]
-    fake = 2.0 + torch.arange(1, b * v + 1, dtype=torch.float32).reshape(b, v, 1, 1)
-    ratio = g["decoder_depth"] / fake
-    _close(out.depth / 2.0, ratio.expand_as(out.depth))
+    view, proj, tanfov, scale = dec.camera_tensors(i["extrinsics"].reshape(b * v, 4, 4),
+                                                   i["intrinsics"].reshape(b * v, 3, 3), i["near"].reshape(-1),
+                                                   i["far"].reshape(-1), i["make_scale_invariant"])
+    ev, ep, et, es = _expected_camera(g)
+    _close(view, ev); _close(proj, ep); _close(tanfov, et); _close(scale, es)
+    # the Gaussians the reference passed are the scene's Gaussians times that scale
+    for n, c in enumerate(g["calls"]):
+        _close(i["means"][n // v] * scale[n], c["kwargs"]["means3D"])
+        _close(i["scales"][n // v] * scale[n], c["kwargs"]["scales"])
+        _close(i["harmonics"][n // v].transpose(-1, -2), c["kwargs"]["shs"])
 
 
-def test_product_render_cuda_and_orthographic_callsite(golden_dir, monkeypatch):
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["decoder_k4_si", "decoder_k25_nosi"])
+def test_hip_camera_kernel_matches_reference_callsite(hip_lib, golden_dir, tag):
+    """The fused HIP camera kernel (what DecoderSplattingCUDA.forward runs) against the recorded call site."""
+    import spfsplatv2_amd as spf
+    g = torch.load(golden_dir / f"callsite_{tag}.pt")
+    i = g["inputs"]
+    view, proj, tanfov, scale = spf.camera_forward(i["extrinsics"].cuda(), i["intrinsics"].cuda(), i["near"].cuda(),
+                                                   i["far"].cuda(), i["make_scale_invariant"])
+    ev, ep, et, es = _expected_camera(g)
+    _close(view.cpu().reshape(-1, 4, 4), ev, 2e-6); _close(proj.cpu().reshape(-1, 4, 4), ep, 2e-6)
+    _close(tanfov.cpu().reshape(-1, 2), et, 2e-6); _close(scale.cpu().reshape(-1), es, 2e-6)
+
+
+def test_product_orthographic_callsite(golden_dir, monkeypatch):
     from spfsplatv2_amd import decoder as dec
     g = torch.load(golden_dir / "callsite_render_cuda.pt")
     i = g["inputs"]
     rec = _Recorder()
     monkeypatch.setattr(dec, "rasterize_batch", rec)
-    img, dep = dec.render_cuda(i["extrinsics"], i["intrinsics"], i["near"], i["far"], i["image_shape"], i["bg"],
-                               i["means"], i["covariances"], i["harmonics"], i["opacities"], i["rotations"],
-                               i["scales"], scale_invariant=True, use_sh=False)
-    assert img.shape == (3, 3, *i["image_shape"]) and dep.shape == (3, 1, *i["image_shape"])
-    for a, w in zip(_expand_batched_call(rec.calls[0]), g["calls_precomp"]):
-        _check_call(a, w)
-    rec.calls.clear()
     out = dec.render_cuda_orthographic(i["extrinsics"], i["ortho_width"], i["ortho_height"], i["near"], i["far"],
                                        i["ortho_image_shape"], torch.zeros(3, 3), i["means"], i["covariances"],
                                        i["harmonics"], i["opacities"], i["rotations"], i["scales"])
     assert out.shape == (3, 3, *i["ortho_image_shape"])
     for a, w in zip(_expand_batched_call(rec.calls[0]), g["calls_ortho"]):
         _check_call(a, w)
+
+
+def test_product_decoder_registry_and_types():
+    from spfsplatv2_amd import decoder as dec
+    cfg = dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
+                                      make_scale_invariant=True, enable_cov_grad=True, enable_sh_grad=True)
+    d = dec.get_decoder(cfg)
+    assert isinstance(d, dec.DecoderSplattingCUDA) and isinstance(d, dec.Decoder)
+    assert list(dec.DECODERS) == ["splatting_cuda"] and len(list(d.parameters())) == 0
+    assert "background_color" not in d.state_dict()          # non-persistent buffer, like the reference
