@@ -82,6 +82,10 @@ typedef struct SpfState {
     uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */
     uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: unused */
     uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
+    uint32_t* pair_off;    /* [R*G]     index of the Gaussian's first (Gaussian, tile) pair in Gaussian-major order:
+                                        its pair with the k-th tile of its rect (row-major) has index pair_off + k */
+    uint32_t* blk_total;   /* [R*nblk]  pairs per block of 256 Gaussians, nblk = spf_raster_view_partial_blocks(G) */
+    uint32_t* blk_base;    /* [R*nblk]  exclusive scan of blk_total */
     float* final_T;        /* [R*P]     transmittance left after the last contributor */
     uint32_t* n_contrib;   /* [R*P]     1 + list position of the last contributor (0 = none) */
 } SpfState;
@@ -97,7 +101,9 @@ typedef struct SpfGrads {
     const float* dL_dimage;   /* [R,3,H,W] */
     const float* dL_ddepth;   /* [R,1,H,W] */
     const float* dL_dalpha;   /* [R,1,H,W] */
-    float* grec;              /* [R*G,12] scratch: per-(render,Gaussian) screen-space grads; the library zeroes it */
+    float* gpair;             /* [capacity,12] scratch: screen-space gradient of every (Gaussian, tile) pair, written
+                                 once per pair by its tile (no global atomics), indexed by pair_off + k; the
+                                 library zeroes it */
     float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
                                  nblk = spf_raster_view_partial_blocks(G) */
     float* dL_dmeans3D;       /* [S,G,3] */
@@ -147,9 +153,9 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
                               uint64_t capacity, uint32_t max_tile_hint, void* stream);
 
-/* Backward of both stages. */
+/* Backward of both stages.  `capacity` = number of 12-float records g->gpair can hold (>= D). */
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
-                        const SpfGrads* g, void* stream);
+                        const SpfGrads* g, uint64_t capacity, void* stream);
 
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n) for the
  * two outer dims, stride(H) == D and stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.

@@ -30,9 +30,10 @@ def _ptr_struct(name, fields):
 SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
                                       "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "tile_count", "tile_start", "tile_fill",
-                                    "counters", "pairs", "final_T", "n_contrib"])
+                                    "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
+                                    "n_contrib"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
-SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "grec", "vpartial",
+SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",
                                     "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D"])
 
@@ -56,7 +57,7 @@ SYMBOLS = {
     "spf_raster_forward_render": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
                                             C.POINTER(SpfOutputs), C.c_uint64, C.c_uint32, C.c_void_p]),
     "spf_raster_backward": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
-                                      C.POINTER(SpfGrads), C.c_void_p]),
+                                      C.POINTER(SpfGrads), C.c_uint64, C.c_void_p]),
     "spf_rope2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
     "spf_stage_timing_enable": (C.c_int, [C.c_int32]),

@@ -9,7 +9,7 @@
 namespace spf {
 hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&, int, int, hipStream_t);
 hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, hipStream_t);
-hipError_t launch_tile_scan(const SpfState&, int, hipStream_t);
+hipError_t launch_tile_scan(const SpfState&, int, int, hipStream_t);
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, hipStream_t);
 hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
@@ -142,7 +142,7 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     rc = check_inputs(d, in);
     if (rc) return rc;
     if (!st || !st->rec || !st->radii || !st->rect || !st->tile_count || !st->tile_start || !st->tile_fill ||
-        !st->counters)
+        !st->counters || !st->blk_total || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
@@ -154,7 +154,7 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     }
     {
         StageScope t(SPF_STAGE_SCAN, stream);
-        SPF_HIP(spf::launch_tile_scan(*st, RT, stream));
+        SPF_HIP(spf::launch_tile_scan(*st, RT, d->S * d->V * spf_raster_view_partial_blocks(d->G), stream));
     }
     return SPF_OK;
 }
@@ -166,7 +166,7 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     rc = check_inputs(d, in);
     if (rc) return rc;
     if (!st || !st->rec || !st->rect || !st->tile_start || !st->tile_fill || !st->counters || !st->final_T ||
-        !st->n_contrib)
+        !st->n_contrib || !st->pair_off || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_render is null");
     if (capacity > 0 && !st->pairs) return fail(SPF_E_INVALID, "pairs is null but capacity > 0");
     if (!out || !out->image || !out->depth || !out->alpha) return fail(SPF_E_INVALID, "an output pointer is null");
@@ -188,23 +188,24 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     return SPF_OK;
 }
 
-int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g, void* stream_) {
+int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g,
+                        uint64_t capacity, void* stream_) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!st || !st->rec || !st->radii || !st->tile_start || !st->pairs || !st->final_T || !st->n_contrib)
+    if (!st || !st->rec || !st->radii || !st->rect || !st->tile_start || !st->pairs || !st->final_T ||
+        !st->n_contrib || !st->pair_off)
         return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
-    if (!g || !g->grec || !g->dL_dmeans3D || !g->dL_dopacities)
-        return fail(SPF_E_INVALID, "grec, dL_dmeans3D and dL_dopacities are required");
+    if (!g || !g->gpair || !g->dL_dmeans3D || !g->dL_dopacities)
+        return fail(SPF_E_INVALID, "gpair, dL_dmeans3D and dL_dopacities are required");
     if (g->dL_dviewmatrix && !g->vpartial) return fail(SPF_E_INVALID, "vpartial is required with dL_dviewmatrix");
     if ((g->dL_dscales == nullptr) != (g->dL_drotations == nullptr))
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int T = tiles_x * tiles_y;
-    const size_t RG = (size_t)d->S * d->V * d->G;
-    SPF_HIP(hipMemsetAsync(g->grec, 0, sizeof(float) * spf::kRec * RG, stream));
+    SPF_HIP(hipMemsetAsync(g->gpair, 0, sizeof(float) * spf::kRec * (size_t)(capacity ? capacity : 1), stream));
     {
         StageScope t(SPF_STAGE_RENDER_BWD, stream);
         SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, stream));

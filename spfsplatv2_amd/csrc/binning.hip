@@ -17,33 +17,33 @@ namespace spf {
 // ---- scan of tile counts: single block, n = R*T is small (<= a few 10^5) --------------------
 constexpr int kScanThreads = 1024;
 
-__global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
-                                                                     uint32_t* __restrict__ start,
-                                                                     uint32_t* __restrict__ fill,
-                                                                     uint32_t* __restrict__ counters, int n) {
-    __shared__ uint32_t s_wsum[kScanThreads / kWave];
-    __shared__ uint32_t s_wmax[kScanThreads / kWave];
+// Exclusive scan of in[0..n) by one 1024-thread block; returns (total, max) to every thread.
+__device__ __forceinline__ void block_exclusive_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                     uint32_t* __restrict__ zero_fill, int n, uint32_t* s_wsum,
+                                                     uint32_t* s_wmax, uint32_t& total, uint32_t& gmax) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + kScanThreads - 1) / kScanThreads;
     const int b = tid * chunk, e = min(n, b + chunk);
     uint32_t sum = 0, mx = 0;
     for (int i = b; i < e; ++i) {
-        const uint32_t c = count[i];
+        const uint32_t c = in[i];
         sum += c;
         mx = max(mx, c);
     }
-    // inclusive scan of per-thread sums inside the wave
-    uint32_t inc = sum;
+    uint32_t inc = sum;   // inclusive scan of per-thread sums inside the wave
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) {
         const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
         if (lane >= o) inc += y;
     }
     mx = wave_max_u32(mx);
+    __syncthreads();      // previous use of the scratch is over
     if (lane == kWave - 1) s_wsum[wave] = inc;
     if (lane == 0) s_wmax[wave] = mx;
     __syncthreads();
-    uint32_t woff = 0, total = 0, gmax = 0;
+    uint32_t woff = 0;
+    total = 0;
+    gmax = 0;
     for (int w = 0; w < kScanThreads / kWave; ++w) {
         const uint32_t x = s_wsum[w];
         if (w < wave) woff += x;
@@ -52,16 +52,30 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
     }
     uint32_t run = woff + inc - sum;  // exclusive prefix of this thread's chunk
     for (int i = b; i < e; ++i) {
-        start[i] = run;
-        fill[i] = 0;
-        run += count[i];
+        const uint32_t c = in[i];
+        out[i] = run;
+        if (zero_fill) zero_fill[i] = 0;
+        run += c;
     }
-    if (tid == 0) {
+}
+
+__global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
+                                                                     uint32_t* __restrict__ start,
+                                                                     uint32_t* __restrict__ fill,
+                                                                     uint32_t* __restrict__ counters, int n,
+                                                                     const uint32_t* __restrict__ blk_total,
+                                                                     uint32_t* __restrict__ blk_base, int nb) {
+    __shared__ uint32_t s_wsum[kScanThreads / kWave];
+    __shared__ uint32_t s_wmax[kScanThreads / kWave];
+    uint32_t total, gmax, t2, m2;
+    block_exclusive_scan(count, start, fill, n, s_wsum, s_wmax, total, gmax);       // tile lists
+    block_exclusive_scan(blk_total, blk_base, nullptr, nb, s_wsum, s_wmax, t2, m2);  // Gaussian-major pair ids
+    if (threadIdx.x == 0) {
         start[n] = total;
         counters[0] = total;
         counters[1] = gmax;
         counters[2] = 0;
-        counters[3] = 0;
+        counters[3] = t2;   // == total (both count the same pairs)
     }
 }
 
@@ -75,8 +89,11 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
                                                                uint32_t* __restrict__ tile_fill,
                                                                uint32_t* __restrict__ counters,
                                                                uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                               const uint32_t* __restrict__ blk_base,
+                                                               uint32_t* __restrict__ pair_off,
                                                                int G, int T, int tiles_x, int lds) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases
+    __shared__ uint32_t s_wtot[4];
     uint32_t* s_cnt = s_bin;
     uint32_t* s_base = s_bin + T;
     const int r = blockIdx.y;
@@ -90,6 +107,21 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     const uint32_t rc = live ? rect[rg] : 0u;
     const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
     const bool any = x1 > x0 && y1 > y0;
+    {   // Gaussian-major pair numbering: exclusive scan of pairs-per-Gaussian inside the block + block base
+        const uint32_t cnt = any ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
+            if (lane >= o) inc += y;
+        }
+        if (lane == kWave - 1) s_wtot[wave] = inc;
+        __syncthreads();
+        uint32_t off = blk_base[(size_t)r * gridDim.x + blockIdx.x] + inc - cnt;
+        for (int w = 0; w < wave; ++w) off += s_wtot[w];
+        if (live) pair_off[rg] = off;
+    }
     const uint64_t key = any ? (((uint64_t)__float_as_uint(rec[rg * kRec + 6]) << 32) | (uint32_t)g) : 0ull;
     const size_t tb = (size_t)r * T;
     if (!lds) {
@@ -195,8 +227,9 @@ __global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint3
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-hipError_t launch_tile_scan(const SpfState& st, int RT, hipStream_t stream) {
-    spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.counters, RT);
+hipError_t launch_tile_scan(const SpfState& st, int RT, int nb, hipStream_t stream) {
+    spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.counters, RT,
+                                                         st.blk_total, st.blk_base, nb);
     return hipGetLastError();
 }
 
@@ -205,7 +238,8 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
-        st.rec, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, d.G, T, tiles_x, lds);
+        st.rec, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
+        d.G, T, tiles_x, lds);
     return hipGetLastError();
 }
 

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
     // in the same few tiles, so this removes most of the L2 atomic traffic.  lds_hist = 0 (T too large for
     // LDS): straight global atomics.
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    __shared__ uint32_t s_wcnt[4];
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     const bool live = g < d.G;
@@ -264,8 +265,13 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
         }
+        // pairs produced by this block for this render (feeds the Gaussian-major pair numbering)
+        const uint32_t wsum = wave_sum_u32(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u);
+        if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = wsum;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            st.blk_total[(size_t)r * gridDim.x + blockIdx.x] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         if (lds_hist) {
-            __syncthreads();
             uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
             for (int t = threadIdx.x; t < T; t += kBlock) {
                 const uint32_t c = s_hist[t];
@@ -274,8 +280,8 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
                     s_hist[t] = 0;
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 }
 
@@ -330,13 +336,25 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
 
         const bool vis = live && st.radii[rg] > 0;
         if (vis) {
+            // sum the screen-space gradient records of this Gaussian's (Gaussian, tile) pairs
+            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+            {
+                const uint32_t rc = st.rect[rg];
+                const int npair = (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
+                const float4* __restrict__ gp =
+                    reinterpret_cast<const float4*>(gr.gpair + (size_t)st.pair_off[rg] * kRec);
+                for (int i = 0; i < npair; ++i) {
+                    const float4 a0 = gp[3 * i], a1 = gp[3 * i + 1], a2 = gp[3 * i + 2];
+                    g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
+                    g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
+                    g2.x += a2.x; g2.y += a2.y;
+                }
+            }
             const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
             const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
             const Sym3 Sg = scaled(Sg0, sc * sc);
             float dp[3] = {0.f, 0.f, 0.f};
             float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float4* __restrict__ gp = reinterpret_cast<const float4*>(gr.grec + rg * kRec);
-            const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
             const float gx = g0.x, gy = g0.y, gA = g0.z, gB = g0.w, gC = g1.x;
             const float gdepth = g2.y;
             float gcol[3] = {g1.z, g1.w, g2.x};

@@ -145,48 +145,116 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay.  Per-Gaussian partial gradients are summed across the wave with
-// DPP adds and leave the wave as ONE 10-lane global atomic instruction per (wave, Gaussian).
+// Backward: back-to-front replay, one 4x4 pixel block per DPP row (16 lanes).
+//
+// A pixel-aligned Gaussian covers ~5x5 pixels, so inside an 8x8 sub-tile only ~1 lane in 4 does useful work
+// and the cross-lane reduction of its ten partial gradients is paid for the whole wave.  Here every row of 16
+// lanes owns a 4x4 block and walks ITS OWN list (a 32-bit mask per block per 32 staged entries, built with
+// __ballot while staging), so the four rows of a wave replay four different Gaussians at once; the reduction
+// stays inside the row (5 DPP adds per value, no cross-row step) and lane 15 of the row issues the atomics.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_sum_to15(float x) {
+    float t = x;
+    t += dpp_f<0x111>(x);             // row_shr:1
+    t += dpp_f<0x112>(x);             // row_shr:2
+    t += dpp_f<0x113>(x);             // row_shr:3
+    t += dpp_f<0x114, 0xf, 0xe>(t);   // row_shr:4, banks 1-3
+    t += dpp_f<0x118, 0xf, 0xc>(t);   // row_shr:8, banks 2-3
+    return t;                         // lane 15 of every row holds the row total
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+}
+
+// max over the 16 lanes of a row, result in every lane (xor-1, xor-2, half-mirror, mirror butterflies)
+__device__ __forceinline__ uint32_t row_max_all(uint32_t x) {
+    x = max(x, dpp_u<0xB1>(x));    // quad_perm [1,0,3,2]
+    x = max(x, dpp_u<0x4E>(x));    // quad_perm [2,3,0,1]
+    x = max(x, dpp_u<0x141>(x));   // row_half_mirror
+    x = max(x, dpp_u<0x140>(x));   // row_mirror
+    return x;
+}
+
+// 16-bit mask: which 4x4 blocks of tile (tx,ty) can be touched by a Gaussian at (gx,gy), squared cull radius r2
+__device__ __forceinline__ uint32_t block_bits(float gx, float gy, float r2, int tx, int ty) {
+    float ddx[4], ddy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = (float)(tx * kTile + 4 * k), y0 = (float)(ty * kTile + 4 * k);
+        const float dx = fmaxf(fmaxf(x0 - gx, gx - (x0 + 3.f)), 0.f);
+        const float dy = fmaxf(fmaxf(y0 - gy, gy - (y0 + 3.f)), 0.f);
+        ddx[k] = dx * dx;
+        ddy[k] = dy * dy;
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int by = 0; by < 4; ++by)
+#pragma unroll
+        for (int bx = 0; bx < 4; ++bx)
+            if (!(ddx[bx] + ddy[by] > r2)) bits |= 1u << (by * 4 + bx);
+    return bits;
+}
+
+constexpr int kAcc = 10;
+
+__device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t slot, const float* acc) {
+    float4* __restrict__ o = reinterpret_cast<float4*>(gpair + (size_t)slot * kRec);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    o[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+}
+
 __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
     const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    float* __restrict__ grec, int G, int H, int W, int T, int tiles_x, int RT) {
+    const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off, float* __restrict__ gpair, int G, int H,
+    int W, int T, int tiles_x, int RT) {
     __shared__ float4 s_p0[kStage];
     __shared__ float2 s_p1[kStage];
     __shared__ float4 s_p2[kStage];
-    __shared__ uint32_t s_gid[kStage];
-    __shared__ uint64_t s_mask[4][4];
+    __shared__ uint32_t s_slot[kStage];           // Gaussian-major pair index of each staged entry
+    __shared__ float s_acc[kStage][kAcc];         // per-entry gradient accumulators of the whole tile
+    __shared__ uint32_t s_mask[kStage / 32][16];   // [32-entry chunk][4x4 block]
     __shared__ uint32_t s_wmax[4];
 
-    TileCtx c;
-    if (!tile_ctx(c, RT, T, tiles_x, H, W)) return;
-    const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
-    const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    if (vid >= RT) return;
+    const int r = vid / T, tile = vid - r * T;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
+    const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1);
+    const int beta = by * 4 + bx;
+    const int px = tx * kTile + bx * 4 + (l16 & 3), py = ty * kTile + by * 4 + (l16 >> 2);
+    const bool inside = px < W && py < H;
+
+    const uint32_t beg = tile_start[(size_t)r * T + tile];
+    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
     if (n == 0) return;
-    const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
-    float* __restrict__ grec_r = grec + (size_t)c.r * G * kRec;
-    const float fx = (float)c.px, fy = (float)c.py;
-    const size_t P = (size_t)H * W, pix = (size_t)c.py * W + c.px;
+    const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
+    const float fx = (float)px, fy = (float)py;
+    const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
 
     float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
     uint32_t ncon = 0;
-    if (c.inside) {
-        T_final = final_T[(size_t)c.r * P + pix];
-        ncon = n_contrib[(size_t)c.r * P + pix];
+    if (inside) {
+        T_final = final_T[(size_t)r * P + pix];
+        ncon = n_contrib[(size_t)r * P + pix];
         if (dL_dimage) {
-            const float* __restrict__ gi = dL_dimage + (size_t)c.r * 3 * P;
+            const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
             gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
         }
-        if (dL_ddepth) gD = dL_ddepth[(size_t)c.r * P + pix];
-        if (dL_dalpha) gA = dL_dalpha[(size_t)c.r * P + pix];
+        if (dL_ddepth) gD = dL_ddepth[(size_t)r * P + pix];
+        if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
     }
-    const float* __restrict__ bg = bg_all + 3 * c.r;
+    const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
 
-    const uint32_t wmax = wave_max_u32(ncon);
-    if (c.lane == 0) s_wmax[c.wave] = wmax;
+    const uint32_t rowmax = row_max_all(ncon);
+    const uint32_t wmax = wave_max_u32(rowmax);
+    if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
     if (bmax == 0) return;
@@ -195,48 +263,64 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f;   // colour/depth behind the current entry
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lD = 0.f;
 
+    bool staged = false;
     for (int base = (int)((bmax - 1) / kStage) * kStage; base >= 0; base -= kStage) {
+        // flush the previous round's accumulators: ONE plain 48-byte store per (Gaussian, tile) pair
+        if (staged) flush_pair(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
         uint32_t bits = 0;
         const uint32_t idx = (uint32_t)base + threadIdx.x;
-        if (idx < n && idx < bmax) {
+        staged = idx < n && idx < bmax;
+        if (staged) {
             const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
             s_p0[threadIdx.x] = a;
             s_p1[threadIdx.x] = make_float2(b.x, b.y);
             s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
-            s_gid[threadIdx.x] = gid;
-            bits = subtile_bits(a.x, a.y, b.w, c.tx, c.ty);
+            const size_t rg = (size_t)r * G + gid;
+            const uint32_t rc = rect[rg];
+            const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
+            s_slot[threadIdx.x] = pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+#pragma unroll
+            for (int k = 0; k < kAcc; ++k) s_acc[threadIdx.x][k] = 0.f;
+            bits = block_bits(a.x, a.y, b.w, tx, ty);
         }
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t m = __ballot((bits >> w) & 1u);
-            if (c.lane == 0) s_mask[c.wave][w] = m;
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t m = __ballot((bits >> k) & 1u);
+            if (lane == 0) {
+                s_mask[2 * wave][k] = (uint32_t)m;
+                s_mask[2 * wave + 1][k] = (uint32_t)(m >> 32);
+            }
         }
         __syncthreads();
-        for (int ch = 3; ch >= 0; --ch) {
-            const int cbase = base + ch * 64;
-            if ((uint32_t)cbase >= wmax) continue;
-            uint64_t m = readfirstlane64(s_mask[ch][c.wave]);
-            if ((uint32_t)cbase + 64u > wmax) m &= (1ull << (wmax - (uint32_t)cbase)) - 1ull;
-            while (m) {
-                const int bit = 63 - __builtin_clzll(m);
-                m &= ~(1ull << bit);
-                const int j = ch * 64 + bit;
-                const uint32_t pos = (uint32_t)base + (uint32_t)j;
+        for (int q = kStage / 32 - 1; q >= 0; --q) {
+            const uint32_t qbase = (uint32_t)base + (uint32_t)q * 32u;
+            if (qbase >= wmax) continue;
+            uint32_t m = s_mask[q][beta];
+            if (qbase >= rowmax) m = 0;
+            else if (qbase + 32u > rowmax) m &= (1u << (rowmax - qbase)) - 1u;
+            while (__ballot(m != 0)) {
+                const bool act = m != 0;
+                const int bit = act ? 31 - __clz((int)m) : 0;
+                m &= ~(1u << bit);
+                const int j = q * 32 + bit;
+                const uint32_t pos = qbase + (uint32_t)bit;
                 const float4 p0 = s_p0[j];
                 const float2 p1 = s_p1[j];
                 const float dx = p0.x - fx, dy = p0.y - fy;
                 const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
                 const float Gv = __expf(power);
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
-                const bool hit = pos < ncon && power <= 0.f && alpha >= kAlphaMin;
-                if (__ballot(hit) == 0) continue;
+                const bool hit = act && pos < ncon && power <= 0.f && alpha >= kAlphaMin;
+                const uint64_t hb = __ballot(hit);
+                if (hb == 0) continue;
                 float r_dx = 0.f, r_dy = 0.f, r_dA = 0.f, r_dB = 0.f, r_dC = 0.f, r_do = 0.f;
                 float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_dd = 0.f;
                 if (hit) {
                     const float4 p2 = s_p2[j];
-                    Tr = Tr / (1.f - alpha);
+                    const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    Tr = Tr * inv1ma;
                     const float w = alpha * Tr;
                     // colour accumulated behind this entry (recurrence, back to front)
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
@@ -250,37 +334,38 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
                     last_alpha = alpha;
                     // image = C + T_final * bg and alpha_out = 1 - T_final both see alpha only through
                     // T_final: dT_final/dalpha = -T_final / (1 - alpha)
-                    dL_dalpha_ += (T_final / (1.f - alpha)) * tail;
+                    dL_dalpha_ += (T_final * inv1ma) * tail;
                     r_c0 = w * gI0; r_c1 = w * gI1; r_c2 = w * gI2; r_dd = w * gD;
                     // [3DGS-grad] the min(0.99, .) clamp is straight-through
                     const float dL_dG = p1.y * dL_dalpha_;
-                    const float s = dL_dG * Gv;
+                    const float sg = dL_dG * Gv;
                     r_do = Gv * dL_dalpha_;
-                    r_dx = -s * (p0.z * dx + p0.w * dy);
-                    r_dy = -s * (p1.x * dy + p0.w * dx);
-                    r_dA = -0.5f * s * dx * dx;
-                    r_dB = -s * dx * dy;
-                    r_dC = -0.5f * s * dy * dy;
+                    r_dx = -sg * (p0.z * dx + p0.w * dy);
+                    r_dy = -sg * (p1.x * dy + p0.w * dx);
+                    r_dA = -0.5f * sg * dx * dx;
+                    r_dB = -sg * dx * dy;
+                    r_dC = -0.5f * sg * dy * dy;
                 }
-                r_dx = wave_sum_to63(r_dx); r_dy = wave_sum_to63(r_dy);
-                r_dA = wave_sum_to63(r_dA); r_dB = wave_sum_to63(r_dB); r_dC = wave_sum_to63(r_dC);
-                r_do = wave_sum_to63(r_do);
-                r_c0 = wave_sum_to63(r_c0); r_c1 = wave_sum_to63(r_c1); r_c2 = wave_sum_to63(r_c2);
-                r_dd = wave_sum_to63(r_dd);
-                // gather the ten totals (lane 63) into lanes 0..9 and issue one atomic instruction
-                float val = 0.f;
-#define SPF_PICK(k, x) { const float t_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63)); if (c.lane == k) val = t_; }
-                SPF_PICK(0, r_dx) SPF_PICK(1, r_dy) SPF_PICK(2, r_dA) SPF_PICK(3, r_dB) SPF_PICK(4, r_dC)
-                SPF_PICK(5, r_do) SPF_PICK(6, r_c0) SPF_PICK(7, r_c1) SPF_PICK(8, r_c2) SPF_PICK(9, r_dd)
-#undef SPF_PICK
-                if (c.lane < 10) {
-                    const uint32_t gid = s_gid[j];
-                    atomicAdd(grec_r + (size_t)gid * kRec + c.lane, val);
+                r_dx = row_sum_to15(r_dx); r_dy = row_sum_to15(r_dy);
+                r_dA = row_sum_to15(r_dA); r_dB = row_sum_to15(r_dB); r_dC = row_sum_to15(r_dC);
+                r_do = row_sum_to15(r_do);
+                r_c0 = row_sum_to15(r_c0); r_c1 = row_sum_to15(r_c1); r_c2 = row_sum_to15(r_c2);
+                r_dd = row_sum_to15(r_dd);
+                const bool rowhit = ((hb >> (lane & 48)) & 0xffffull) != 0;
+                if (l16 == 15 && rowhit) {
+                    // the tile's 16 blocks meet in LDS (ds_add_f32); HBM sees one record per pair
+                    float* gp = s_acc[j];
+                    atomicAdd(gp + 0, r_dx); atomicAdd(gp + 1, r_dy);
+                    atomicAdd(gp + 2, r_dA); atomicAdd(gp + 3, r_dB); atomicAdd(gp + 4, r_dC);
+                    atomicAdd(gp + 5, r_do);
+                    atomicAdd(gp + 6, r_c0); atomicAdd(gp + 7, r_c1); atomicAdd(gp + 8, r_c2);
+                    if (dL_ddepth) atomicAdd(gp + 9, r_dd);
                 }
             }
         }
         __syncthreads();
     }
+    if (staged) flush_pair(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
@@ -299,8 +384,8 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
     spf_render_bwd_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, in.bg, st.final_T,
-                                                       st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha, g.grec,
-                                                       d.G, d.H, d.W, T, tiles_x, RT);
+                                                       st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha, st.rect,
+                                                       st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
     return hipGetLastError();
 }
 

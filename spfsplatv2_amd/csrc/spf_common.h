@@ -17,7 +17,8 @@ constexpr int kMaxLdsTiles = 4096;  // per-render tile histograms up to this man
 
 // Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
 // 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).
-// Gradient record: 0 dx, 1 dy (pixel space), 2 dA, 3 dB, 4 dC, 5 dopacity, 6..8 drgb, 9 ddepth.
+// Gradient record (one per (Gaussian, tile) pair): 0 dx, 1 dy (pixel space), 2 dA, 3 dB, 4 dC, 5 dopacity,
+// 6..8 drgb, 9 ddepth, 10..11 unused.
 
 constexpr float kNearCull = 0.2f;
 constexpr float kLowPass = 0.3f;
@@ -67,6 +68,12 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
         uint32_t y = (uint32_t)__shfl_xor((int)x, o, 64);
         x = x > y ? x : y;
     }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o, 64);
     return x;
 }
 

@@ -73,6 +73,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     rec = torch.empty((R * G, _REC), **f32)
     radii = torch.empty((R * G,), **i32)
     rect = torch.empty((R * G,), **i32)
+    nblk = lib.spf_raster_view_partial_blocks(G)
+    pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
     tiles = torch.empty((3 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | counters
     counters = tiles[3 * R * T + 1:]
     final_T = torch.empty((R * P,), **f32)
@@ -84,7 +86,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
                          _ptr(view_scale))
-    st = _state_struct(rec, radii, rect, tiles, None, final_T, n_contrib, R * T)
+    st = _state_struct(rec, radii, rect, tiles, None, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
     _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
                "spf_raster_forward_project")
@@ -103,12 +105,14 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
                                              capacity, max_tile, stream),
                "spf_raster_forward_render")
-    return (image, depth, alpha, radii.view(S, V, G)), (rec, radii, rect, tiles, pairs, final_T, n_contrib)
+    return ((image, depth, alpha, radii.view(S, V, G)),
+            (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib))
 
 
-def _state_struct(rec, radii, rect, tiles, pairs, final_T, n_contrib, RT):
+def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:RT]), _ptr(tiles[RT:2 * RT + 1]),
                          _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:]), _ptr(pairs),
+                         _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib))
 
 
@@ -116,7 +120,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
-    rec, radii, rect, tiles, pairs, final_T, n_contrib = state
+    rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
     S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode = geom
     R = S * V
     dev = means3D.device
@@ -128,7 +132,8 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
-    grec = torch.empty((R * G, _REC), **f32)
+    capacity = pairs.numel()
+    gpair = torch.empty((capacity, _REC), **f32)
     d_means = torch.empty_like(means3D)
     d_opac = torch.empty_like(opacities)
     d_scales = torch.empty_like(scales) if want["scales_rot"] else None
@@ -141,11 +146,11 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
                          _ptr(view_scale))
-    st = _state_struct(rec, radii, rect, tiles, pairs, final_T, n_contrib, R * T)
-    gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(grec), _ptr(vpartial),
+    st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
+    gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(gpair), _ptr(vpartial),
                        _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
                        _ptr(d_view), _ptr(d_m2d))
-    _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr),
+    _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity,
                                        _stream_ptr(dev)), "spf_raster_backward")
     return d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d
 
@@ -220,10 +225,10 @@ class _DecoderRender(torch.autograd.Function):
         want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
                     colors=need[9], view=need[0], means2D=False)
         d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, _ = _backward_impl(
-            saved[:11], saved[11:18], ctx.geom, (g_image, g_depth, g_alpha), want)
+            saved[:11], saved[11:19], ctx.geom, (g_image, g_depth, g_alpha), want)
         d_ext = None
         if need[0]:
-            view, near = saved[6], saved[18]
+            view, near = saved[6], saved[19]
             d_ext = torch.empty_like(view)
             cam = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(view), None, None, None,
                                  view.shape[0] * view.shape[1], 1 if scale_invariant else 0)
