@@ -102,8 +102,7 @@ typedef struct SpfGrads {
     const float* dL_ddepth;   /* [R,1,H,W] */
     const float* dL_dalpha;   /* [R,1,H,W] */
     float* gpair;             /* [capacity,12] scratch: screen-space gradient of every (Gaussian, tile) pair, written
-                                 once per pair by its tile (no global atomics), indexed by pair_off + k; the
-                                 library zeroes it */
+                                 once per pair by its tile (no global atomics, no memset), indexed by pair_off + k */
     float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
                                  nblk = spf_raster_view_partial_blocks(G) */
     float* dL_dmeans3D;       /* [S,G,3] */
@@ -164,7 +163,8 @@ int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int
                int64_t stride_b, int64_t stride_n, int32_t dtype, float base, float fwd, void* stream);
 
 /* Per-stage device timing with HIP events recorded on the launch stream around every kernel
- * stage.  spf_stage_timing_enable(1) clears the log and starts recording (up to
+ * stage.  spf_stage_timing_enable(mask) clears the log and starts recording the stages whose bit
+ * (1 << SPF_STAGE_x) is set in `mask` (0 = off, -1 = all) (up to
  * SPF_STAGE_LOG launches per stage are kept); spf_stage_times_ms synchronises on the recorded
  * events and returns, per stage, the summed device time and the number of launches logged since
  * enable -- average launch duration = total_ms[i] / count[i]. */
@@ -180,7 +180,7 @@ enum {
     SPF_STAGE_COUNT = 8
 };
 #define SPF_STAGE_LOG 1024
-int spf_stage_timing_enable(int32_t on);
+int spf_stage_timing_enable(int32_t mask);
 int spf_stage_times_ms(float* total_ms /* host, [SPF_STAGE_COUNT] */,
                        int32_t* count /* host, [SPF_STAGE_COUNT] */);
 const char* spf_stage_kernel_name(int32_t stage);

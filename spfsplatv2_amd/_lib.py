@@ -102,8 +102,17 @@ def check(rc: int, what: str) -> None:
         raise SpfError(f"{what} failed (code {rc}): {msg}")
 
 
-def stage_timing_enable(on: bool) -> None:
-    check(load().spf_stage_timing_enable(1 if on else 0), "spf_stage_timing_enable")
+def stage_timing_enable(stages=True) -> None:
+    """True = all stages, False = off, or an iterable of stage names (see STAGE_NAMES)."""
+    if stages is True:
+        mask = -1
+    elif not stages:
+        mask = 0
+    else:
+        mask = 0
+        for s in stages:
+            mask |= 1 << STAGE_NAMES.index(s)
+    check(load().spf_stage_timing_enable(mask), "spf_stage_timing_enable")
 
 
 def stage_times() -> dict[str, tuple[float, int]]:

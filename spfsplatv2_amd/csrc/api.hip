@@ -45,14 +45,14 @@ struct StageLog {
     int used = 0;
 };
 StageLog g_log[SPF_STAGE_COUNT];
-bool g_timing = false;
+uint32_t g_timing = 0;   // bit i: record stage i
 
 struct StageScope {
     int stage;
     hipStream_t stream;
     int slot = -1;
     StageScope(int st, hipStream_t s) : stage(st), stream(s) {
-        if (!g_timing) return;
+        if (!((g_timing >> stage) & 1u)) return;
         StageLog& L = g_log[stage];
         if (L.used >= SPF_STAGE_LOG) return;
         if (L.used >= L.created) {
@@ -205,7 +205,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int T = tiles_x * tiles_y;
-    SPF_HIP(hipMemsetAsync(g->gpair, 0, sizeof(float) * spf::kRec * (size_t)(capacity ? capacity : 1), stream));
+    (void)capacity;   // every pair record is written exactly once by its tile: no memset of gpair
     {
         StageScope t(SPF_STAGE_RENDER_BWD, stream);
         SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, stream));
@@ -231,8 +231,8 @@ int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int
     return SPF_OK;
 }
 
-int spf_stage_timing_enable(int32_t on) {
-    g_timing = on != 0;
+int spf_stage_timing_enable(int32_t mask) {
+    g_timing = (uint32_t)mask;
     if (g_timing)
         for (int s = 0; s < SPF_STAGE_COUNT; ++s) g_log[s].used = 0;
     return SPF_OK;

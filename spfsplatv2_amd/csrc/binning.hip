@@ -25,10 +25,23 @@ __device__ __forceinline__ void block_exclusive_scan(const uint32_t* __restrict_
     const int chunk = (n + kScanThreads - 1) / kScanThreads;
     const int b = tid * chunk, e = min(n, b + chunk);
     uint32_t sum = 0, mx = 0;
-    for (int i = b; i < e; ++i) {
-        const uint32_t c = in[i];
-        sum += c;
-        mx = max(mx, c);
+    constexpr int kRegs = 16;          // the common case keeps the thread's chunk in registers: one load latency
+    uint32_t v[kRegs];
+    const bool in_regs = chunk <= kRegs;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) v[k] = (b + k < e) ? in[b + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) {
+            sum += v[k];
+            mx = max(mx, v[k]);
+        }
+    } else {
+        for (int i = b; i < e; ++i) {
+            const uint32_t c = in[i];
+            sum += c;
+            mx = max(mx, c);
+        }
     }
     uint32_t inc = sum;   // inclusive scan of per-thread sums inside the wave
 #pragma unroll
@@ -51,11 +64,21 @@ __device__ __forceinline__ void block_exclusive_scan(const uint32_t* __restrict_
         gmax = max(gmax, s_wmax[w]);
     }
     uint32_t run = woff + inc - sum;  // exclusive prefix of this thread's chunk
-    for (int i = b; i < e; ++i) {
-        const uint32_t c = in[i];
-        out[i] = run;
-        if (zero_fill) zero_fill[i] = 0;
-        run += c;
+    if (in_regs) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k)
+            if (b + k < e) {
+                out[b + k] = run;
+                if (zero_fill) zero_fill[b + k] = 0;
+                run += v[k];
+            }
+    } else {
+        for (int i = b; i < e; ++i) {
+            const uint32_t c = in[i];
+            out[i] = run;
+            if (zero_fill) zero_fill[i] = 0;
+            run += c;
+        }
     }
 }
 
@@ -243,14 +266,14 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     return hipGetLastError();
 }
 
-// Size classes: (1, 512], (512, 2048], (2048, 8192], (8192, 16384], > 16384 (global fallback).
+// Size classes: (1, 2048], (2048, 8192], (8192, 16384], > 16384 (global fallback).
 hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
-    if (mx > 1)
-        spf_sort_tiles_lds_kernel<256><<<RT, 256, 512 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1, 512);
-    if (mx > 512)
-        spf_sort_tiles_lds_kernel<256><<<RT, 256, 2048 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 512, 2048);
+    if (mx > 1) {
+        const uint32_t cap = mx <= 512 ? 512 : 2048;
+        spf_sort_tiles_lds_kernel<256><<<RT, 256, cap * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1, cap);
+    }
     if (mx > 2048)
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {

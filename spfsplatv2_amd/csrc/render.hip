@@ -1,17 +1,19 @@
 // 16x16-tile alpha compositing, forward and backward, for gfx950 (wave64).
 //
-// Block = one tile = 256 threads = 4 waves; wave w owns the 8x8 sub-tile (w&1, w>>1), so a
-// whole wave can drop a Gaussian with ONE scalar decision:
-//   * the tile's depth-sorted list is staged 256 entries at a time into LDS (one coalesced
-//     8-byte key load + one 48-byte record gather per thread),
-//   * while staging, each thread tests its entry against the four sub-tiles with a conservative
-//     bound (record field 7, see project.hip) and the results are turned into 64-bit wave masks
-//     with __ballot -- afterwards every wave walks only the set bits of its own masks (scalar
-//     s_ff1 loop), reading the entry back from LDS as a broadcast,
-//   * per-lane early termination (T < 1e-4) is folded into a wave ballot and a block-wide
-//     __syncthreads_and so a saturated tile stops streaming its list.
-// A culled entry is one whose alpha is < 1/255 at every pixel of the sub-tile, i.e. one the
-// per-pixel loop would have skipped anyway, so results are identical to the un-culled loop.
+// Block = one tile = 256 threads = 4 waves; wave w owns the 8x8 sub-tile (w&1, w>>1) and every DPP row
+// (16 lanes) of a wave owns one 4x4 pixel block.  A pixel-aligned Gaussian covers ~5x5 pixels, so most
+// (block, Gaussian) combinations of a tile are empty:
+//   * the tile's depth-sorted list is staged 256 entries at a time into LDS (one coalesced 8-byte key load +
+//     one 48-byte record gather per thread),
+//   * while staging, each thread tests its entry against the tile's sixteen 4x4 blocks with a conservative
+//     bound (record field 7, see project.hip); __ballot turns the results into one 32-bit mask per block per 32
+//     staged entries,
+//   * every row then walks only the set bits of ITS block's masks, so the four rows of a wave composite four
+//     different Gaussians at the same time; entries are read back from LDS (four addresses per wave),
+//   * per-lane early termination (T < 1e-4) is folded into row / wave ballots and a block-wide
+//     __syncthreads_and, so a saturated tile stops streaming its list.
+// A culled (block, entry) is one whose alpha is < 1/255 at every pixel of the block, i.e. one the per-pixel loop
+// would have skipped anyway, so results are identical to the un-culled loop.
 //
 // Semantics: SURVEY.md Appendix B #10/#11 (restated in oracle/splat_ref.py::composite).
 #include "spf_common.h"
@@ -20,12 +22,14 @@ namespace spf {
 
 constexpr int kStage = 256;  // list entries staged per round (one per thread)
 
-struct TileCtx {
-    int r, tile, tx, ty, wave, lane, px, py;
+struct BlockCtx {
+    int r, tile, tx, ty, wave, lane, row, l16, beta, px, py;
     bool inside;
 };
 
-__device__ __forceinline__ bool tile_ctx(TileCtx& c, int RT, int T, int tiles_x, int H, int W) {
+// Work decomposition shared by forward and backward: block = tile, wave = 8x8 sub-tile, DPP row (16 lanes)
+// = 4x4 pixel block `beta` (row-major over the tile's 4x4 grid of blocks).
+__device__ __forceinline__ bool block_ctx(BlockCtx& c, int RT, int T, int tiles_x, int H, int W) {
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return false;
     c.r = vid / T;
@@ -34,134 +38,45 @@ __device__ __forceinline__ bool tile_ctx(TileCtx& c, int RT, int T, int tiles_x,
     c.tx = c.tile - c.ty * tiles_x;
     c.wave = threadIdx.x >> 6;
     c.lane = threadIdx.x & 63;
-    c.px = c.tx * kTile + (c.wave & 1) * 8 + (c.lane & 7);
-    c.py = c.ty * kTile + (c.wave >> 1) * 8 + (c.lane >> 3);
+    c.row = c.lane >> 4;
+    c.l16 = c.lane & 15;
+    const int bx = (c.wave & 1) * 2 + (c.row & 1), by = (c.wave >> 1) * 2 + (c.row >> 1);
+    c.beta = by * 4 + bx;
+    c.px = c.tx * kTile + bx * 4 + (c.l16 & 3);
+    c.py = c.ty * kTile + by * 4 + (c.l16 >> 2);
     c.inside = c.px < W && c.py < H;
     return true;
 }
 
-// 4-bit mask: which 8x8 sub-tiles of tile (tx,ty) can be touched by a Gaussian at (gx,gy) with
-// squared cull radius r2.
-__device__ __forceinline__ uint32_t subtile_bits(float gx, float gy, float r2, int tx, int ty) {
-    uint32_t bits = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const float x0 = (float)(tx * kTile + (w & 1) * 8), y0 = (float)(ty * kTile + (w >> 1) * 8);
-        const float dx = fmaxf(fmaxf(x0 - gx, gx - (x0 + 7.f)), 0.f);
-        const float dy = fmaxf(fmaxf(y0 - gy, gy - (y0 + 7.f)), 0.f);
-        if (!(dx * dx + dy * dy > r2)) bits |= 1u << w;
-    }
-    return bits;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Forward
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ counters, uint64_t capacity, const float* __restrict__ bg_all,
-    float* __restrict__ image, float* __restrict__ depth_out, float* __restrict__ alpha_out,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W, int T, int tiles_x, int RT) {
-    __shared__ float4 s_p0[kStage];   // x, y, A, B
-    __shared__ float2 s_p1[kStage];   // C, opacity
-    __shared__ float4 s_p2[kStage];   // r, g, b, depth
-    __shared__ uint64_t s_mask[4][4];  // [staged chunk of 64][consumer wave]
-
-    if (counters[0] > capacity) return;
-    TileCtx c;
-    if (!tile_ctx(c, RT, T, tiles_x, H, W)) return;
-    const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
-    const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
-    const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
-    const float fx = (float)c.px, fy = (float)c.py;
-
-    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    bool done = !c.inside;
-    bool wave_done = __ballot(!done) == 0;
-
-    for (uint32_t base = 0; base < n; base += kStage) {
-        // ---- stage ----
-        uint32_t bits = 0;
-        const uint32_t idx = base + threadIdx.x;
-        if (idx < n) {
-            const uint32_t gid = (uint32_t)pairs[beg + idx];
-            const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
-            const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[threadIdx.x] = a;
-            s_p1[threadIdx.x] = make_float2(b.x, b.y);
-            s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
-            bits = subtile_bits(a.x, a.y, b.w, c.tx, c.ty);
-        }
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t m = __ballot((bits >> w) & 1u);
-            if (c.lane == 0) s_mask[c.wave][w] = m;
-        }
-        __syncthreads();
-        // ---- consume ----
-        if (!wave_done) {
-            for (int ch = 0; ch < 4; ++ch) {
-                uint64_t m = readfirstlane64(s_mask[ch][c.wave]);
-                while (m) {
-                    const int j = ch * 64 + __builtin_ctzll(m);
-                    m &= m - 1;
-                    const float4 p0 = s_p0[j];
-                    const float2 p1 = s_p1[j];
-                    const float dx = p0.x - fx, dy = p0.y - fy;
-                    const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
-                    const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
-                    const bool hit = !done && power <= 0.f && alpha >= kAlphaMin;
-                    if (hit) {
-                        const float test_T = Tr * (1.f - alpha);
-                        if (test_T < kTMin) {
-                            done = true;
-                        } else {
-                            const float4 p2 = s_p2[j];
-                            const float w = alpha * Tr;
-                            C0 += p2.x * w; C1 += p2.y * w; C2 += p2.z * w; Dp += p2.w * w;
-                            Tr = test_T;
-                            last = base + j + 1;
-                        }
-                    }
-                }
-                if (__ballot(!done) == 0) { wave_done = true; break; }
-            }
-        }
-        if (__syncthreads_and(wave_done)) break;
-    }
-    if (c.inside) {
-        const float* __restrict__ bg = bg_all + 3 * c.r;
-        const size_t P = (size_t)H * W, pix = (size_t)c.py * W + c.px;
-        float* __restrict__ img = image + (size_t)c.r * 3 * P;
-        img[pix] = C0 + Tr * bg[0];
-        img[P + pix] = C1 + Tr * bg[1];
-        img[2 * P + pix] = C2 + Tr * bg[2];
-        depth_out[(size_t)c.r * P + pix] = Dp;
-        alpha_out[(size_t)c.r * P + pix] = 1.0f - Tr;
-        final_T[(size_t)c.r * P + pix] = Tr;
-        n_contrib[(size_t)c.r * P + pix] = last;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Backward: back-to-front replay, one 4x4 pixel block per DPP row (16 lanes).
-//
-// A pixel-aligned Gaussian covers ~5x5 pixels, so inside an 8x8 sub-tile only ~1 lane in 4 does useful work
-// and the cross-lane reduction of its ten partial gradients is paid for the whole wave.  Here every row of 16
-// lanes owns a 4x4 block and walks ITS OWN list (a 32-bit mask per block per 32 staged entries, built with
-// __ballot while staging), so the four rows of a wave replay four different Gaussians at once; the reduction
-// stays inside the row (5 DPP adds per value, no cross-row step) and lane 15 of the row issues the atomics.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float row_sum_to15(float x) {
+// First three steps of the row reduction (lane i <- x[i] + x[i-1] + x[i-2] + x[i-3]); hipcc fuses each
+// into one v_add_f32_dpp.
+__device__ __forceinline__ float row_sum4(float x) {
     float t = x;
     t += dpp_f<0x111>(x);             // row_shr:1
     t += dpp_f<0x112>(x);             // row_shr:2
     t += dpp_f<0x113>(x);             // row_shr:3
-    t += dpp_f<0x114, 0xf, 0xe>(t);   // row_shr:4, banks 1-3
-    t += dpp_f<0x118, 0xf, 0xc>(t);   // row_shr:8, banks 2-3
-    return t;                         // lane 15 of every row holds the row total
+    return t;
 }
+
+// Last two steps (row_shr:4 on banks 1-3, row_shr:8 on banks 2-3) for N values at once: lane 15 of every row
+// ends with the row total.  Written as asm because hipcc lowers a bank-masked update_dpp to
+// v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one v_add_f32_dpp whose masked-off lanes simply keep
+// their value.  The leading s_nop covers the VALU-write -> DPP-read hazard (2 wait states) that the compiler
+// does not insert around inline asm; inside the block every DPP source was written >= 2 instructions earlier.
+#define SPF_DPP4(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+#define SPF_DPP8(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+__device__ __forceinline__ void row_finish9(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5,
+                                            float& a6, float& a7, float& a8) {
+    asm volatile("s_nop 1\n\t" SPF_DPP4(0) SPF_DPP4(1) SPF_DPP4(2) SPF_DPP4(3) SPF_DPP4(4) SPF_DPP4(5) SPF_DPP4(6)
+                 SPF_DPP4(7) SPF_DPP4(8) SPF_DPP8(0) SPF_DPP8(1) SPF_DPP8(2) SPF_DPP8(3) SPF_DPP8(4) SPF_DPP8(5)
+                 SPF_DPP8(6) SPF_DPP8(7) SPF_DPP8(8)
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
+}
+__device__ __forceinline__ void row_finish1(float& a0) {
+    asm volatile("s_nop 1\n\t" SPF_DPP4(0) "s_nop 1\n\t" SPF_DPP8(0) : "+v"(a0));
+}
+#undef SPF_DPP4
+#undef SPF_DPP8
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -197,6 +112,112 @@ __device__ __forceinline__ uint32_t block_bits(float gx, float gy, float r2, int
     return bits;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward: front-to-back compositing, one 4x4 pixel block per DPP row (see the header comment).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ counters, uint64_t capacity, const float* __restrict__ bg_all,
+    float* __restrict__ image, float* __restrict__ depth_out, float* __restrict__ alpha_out,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W, int T, int tiles_x, int RT) {
+    __shared__ float4 s_p0[kStage];   // x, y, A, B
+    __shared__ float2 s_p1[kStage];   // C, opacity
+    __shared__ float4 s_p2[kStage];   // r, g, b, depth
+    __shared__ uint32_t s_mask[kStage / 32][16];   // [32-entry chunk][4x4 block]
+
+    if (counters[0] > capacity) return;
+    BlockCtx c;
+    if (!block_ctx(c, RT, T, tiles_x, H, W)) return;
+    const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
+    const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
+    const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
+    const float fx = (float)c.px, fy = (float)c.py;
+
+    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !c.inside;
+    bool row_done = false;
+    bool wave_done = __ballot(!done) == 0;
+
+    for (uint32_t base = 0; base < n; base += kStage) {
+        // ---- stage: one list entry per thread, plus the 4x4-block masks of the staged entries ----
+        uint32_t bits = 0;
+        const uint32_t idx = base + threadIdx.x;
+        if (idx < n) {
+            const uint32_t gid = (uint32_t)pairs[beg + idx];
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
+            const float4 a = rp[0], b = rp[1], cc = rp[2];
+            s_p0[threadIdx.x] = a;
+            s_p1[threadIdx.x] = make_float2(b.x, b.y);
+            s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
+            bits = block_bits(a.x, a.y, b.w, c.tx, c.ty);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t m = __ballot((bits >> k) & 1u);
+            if (c.lane == 0) {
+                s_mask[2 * c.wave][k] = (uint32_t)m;
+                s_mask[2 * c.wave + 1][k] = (uint32_t)(m >> 32);
+            }
+        }
+        __syncthreads();
+        // ---- consume: every row walks the set bits of its own block's masks ----
+        if (!wave_done) {
+            const int nq = (int)min((uint32_t)(kStage / 32), (n - base + 31u) / 32u);
+            for (int q = 0; q < nq; ++q) {
+                uint32_t m = row_done ? 0u : s_mask[q][c.beta];
+                while (__ballot(m != 0)) {
+                    const bool act = m != 0;
+                    const int bit = act ? __builtin_ctz(m) : 0;
+                    m &= m - 1u;
+                    const int j = q * 32 + bit;
+                    const float4 p0 = s_p0[j];
+                    const float2 p1 = s_p1[j];
+                    const float dx = p0.x - fx, dy = p0.y - fy;
+                    const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
+                    const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
+                    const bool hit = act && !done && power <= 0.f && alpha >= kAlphaMin;
+                    if (hit) {
+                        const float test_T = Tr * (1.f - alpha);
+                        if (test_T < kTMin) {
+                            done = true;
+                        } else {
+                            const float4 p2 = s_p2[j];
+                            const float w = alpha * Tr;
+                            C0 += p2.x * w; C1 += p2.y * w; C2 += p2.z * w; Dp += p2.w * w;
+                            Tr = test_T;
+                            last = base + (uint32_t)j + 1u;
+                        }
+                    }
+                }
+                // per-row / per-wave early termination from one ballot per 32 entries
+                const uint64_t alive = __ballot(!done);
+                row_done = ((alive >> (c.lane & 48)) & 0xffffull) == 0;
+                if (alive == 0) { wave_done = true; break; }
+            }
+        }
+        if (__syncthreads_and(wave_done)) break;
+    }
+    if (c.inside) {
+        const float* __restrict__ bg = bg_all + 3 * c.r;
+        const size_t P = (size_t)H * W, pix = (size_t)c.py * W + c.px;
+        float* __restrict__ img = image + (size_t)c.r * 3 * P;
+        img[pix] = C0 + Tr * bg[0];
+        img[P + pix] = C1 + Tr * bg[1];
+        img[2 * P + pix] = C2 + Tr * bg[2];
+        depth_out[(size_t)c.r * P + pix] = Dp;
+        alpha_out[(size_t)c.r * P + pix] = 1.0f - Tr;
+        final_T[(size_t)c.r * P + pix] = Tr;
+        n_contrib[(size_t)c.r * P + pix] = last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward: back-to-front replay with the same decomposition.  The ten partial gradients of a
+// (block, Gaussian) pair are reduced inside the row (5 DPP adds per value, no cross-row step); lane 15 adds the
+// row totals into per-entry LDS accumulators shared by the tile's 16 blocks, and when a staging round is over
+// each thread writes ONE 48-byte record for its entry's (Gaussian, tile) pair -- no global atomics.
+// ------------------------------------------------------------------------------------------------
 constexpr int kAcc = 10;
 
 __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t slot, const float* acc) {
@@ -206,6 +227,7 @@ __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t s
     o[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
 }
 
+template <bool DEPTH_GRAD>
 __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
     const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -236,6 +258,13 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     const float fx = (float)px, fy = (float)py;
     const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
+    // Gaussian-major index of list entry idx's (Gaussian, tile) pair
+    auto pair_slot = [&](uint32_t gid) -> uint32_t {
+        const size_t rg = (size_t)r * G + gid;
+        const uint32_t rc = rect[rg];
+        const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
+        return pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    };
 
     float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
     uint32_t ncon = 0;
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
             const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
             gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
         }
-        if (dL_ddepth) gD = dL_ddepth[(size_t)r * P + pix];
+        if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + pix];
         if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
     }
     const float* __restrict__ bg = bg_all + 3 * r;
@@ -257,6 +286,16 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    // Entries behind every pixel's last contributor get a zero record (every pair slot is written exactly once,
+    // so the scratch needs no memset).
+    {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t idx = bmax + threadIdx.x; idx < n; idx += kBlock) {
+            float4* __restrict__ o =
+                reinterpret_cast<float4*>(gpair + (size_t)pair_slot((uint32_t)pairs[beg + idx]) * kRec);
+            o[0] = z; o[1] = z; o[2] = z;
+        }
+    }
     if (bmax == 0) return;
 
     float Tr = T_final;
@@ -277,10 +316,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
             s_p0[threadIdx.x] = a;
             s_p1[threadIdx.x] = make_float2(b.x, b.y);
             s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
-            const size_t rg = (size_t)r * G + gid;
-            const uint32_t rc = rect[rg];
-            const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
-            s_slot[threadIdx.x] = pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_slot[threadIdx.x] = pair_slot(gid);
 #pragma unroll
             for (int k = 0; k < kAcc; ++k) s_acc[threadIdx.x][k] = 0.f;
             bits = block_bits(a.x, a.y, b.w, tx, ty);
@@ -335,7 +371,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
                     // image = C + T_final * bg and alpha_out = 1 - T_final both see alpha only through
                     // T_final: dT_final/dalpha = -T_final / (1 - alpha)
                     dL_dalpha_ += (T_final * inv1ma) * tail;
-                    r_c0 = w * gI0; r_c1 = w * gI1; r_c2 = w * gI2; r_dd = w * gD;
+                    r_c0 = w * gI0; r_c1 = w * gI1; r_c2 = w * gI2;
+                    if (DEPTH_GRAD) r_dd = w * gD;
                     // [3DGS-grad] the min(0.99, .) clamp is straight-through
                     const float dL_dG = p1.y * dL_dalpha_;
                     const float sg = dL_dG * Gv;
@@ -346,11 +383,15 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
                     r_dB = -sg * dx * dy;
                     r_dC = -0.5f * sg * dy * dy;
                 }
-                r_dx = row_sum_to15(r_dx); r_dy = row_sum_to15(r_dy);
-                r_dA = row_sum_to15(r_dA); r_dB = row_sum_to15(r_dB); r_dC = row_sum_to15(r_dC);
-                r_do = row_sum_to15(r_do);
-                r_c0 = row_sum_to15(r_c0); r_c1 = row_sum_to15(r_c1); r_c2 = row_sum_to15(r_c2);
-                r_dd = row_sum_to15(r_dd);
+                r_dx = row_sum4(r_dx); r_dy = row_sum4(r_dy);
+                r_dA = row_sum4(r_dA); r_dB = row_sum4(r_dB); r_dC = row_sum4(r_dC);
+                r_do = row_sum4(r_do);
+                r_c0 = row_sum4(r_c0); r_c1 = row_sum4(r_c1); r_c2 = row_sum4(r_c2);
+                row_finish9(r_dx, r_dy, r_dA, r_dB, r_dC, r_do, r_c0, r_c1, r_c2);
+                if (DEPTH_GRAD) {
+                    r_dd = row_sum4(r_dd);
+                    row_finish1(r_dd);
+                }
                 const bool rowhit = ((hb >> (lane & 48)) & 0xffffull) != 0;
                 if (l16 == 15 && rowhit) {
                     // the tile's 16 blocks meet in LDS (ds_add_f32); HBM sees one record per pair
@@ -359,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
                     atomicAdd(gp + 2, r_dA); atomicAdd(gp + 3, r_dB); atomicAdd(gp + 4, r_dC);
                     atomicAdd(gp + 5, r_do);
                     atomicAdd(gp + 6, r_c0); atomicAdd(gp + 7, r_c1); atomicAdd(gp + 8, r_c2);
-                    if (dL_ddepth) atomicAdd(gp + 9, r_dd);
+                    if (DEPTH_GRAD) atomicAdd(gp + 9, r_dd);
                 }
             }
         }
@@ -383,9 +424,14 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
                              int tiles_x, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    spf_render_bwd_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, in.bg, st.final_T,
-                                                       st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha, st.rect,
-                                                       st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
+    if (g.dL_ddepth)
+        spf_render_bwd_kernel<true><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha,
+            st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
+    else
+        spf_render_bwd_kernel<false><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha,
+            st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
     return hipGetLastError();
 }
 
