@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-free", action="store_true", help="fixed pair-buffer capacity, no per-step read-back")
+    ap.add_argument("--allreduce", action="store_true",
+                    help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
+                         "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +122,13 @@ def main():
     from spfsplatv2_amd import _lib, synthetic as syn
 
     S, V = args.scenes, args.views
-    batch_cpu = syn.make_batch(args.config, S, V, seed=1000 + rank, s_mult=args.s_mult)
+    from spfsplatv2_amd import shard
+    if args.allreduce:      # same scenes everywhere, rank-specific target poses
+        batch_cpu = syn.make_batch(args.config, S, V, seed=1000, s_mult=args.s_mult)
+        pg = torch.Generator().manual_seed(7000 + rank)
+        batch_cpu.extrinsics = torch.stack([syn.target_poses(pg, V) for _ in range(S)])
+    else:                   # independent scenes per rank (scene-first sharding of a larger batch)
+        batch_cpu = syn.make_batch(args.config, S, V, seed=1000 + rank, s_mult=args.s_mult)
     b = batch_cpu.to(dev)
     h, w = b.image_shape
     G, K = b.means.shape[1], b.harmonics.shape[-1]
@@ -137,6 +146,8 @@ def main():
             enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
         loss = torch.nn.functional.mse_loss(color, b.target)
         loss.backward()
+        if args.allreduce:
+            shard.allreduce_gaussian_grads([leaves[n].grad for n in names[:5]])
         return loss
 
     def barrier():
@@ -201,7 +212,8 @@ def main():
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
                        "s_mult": args.s_mult, "pair_buffer": "capacity" if args.sync_free else "exact",
-                       "sharding": "scene-first, no data-path collective"},
+                       "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
+                                    if args.allreduce else "scene-first, no data-path collective")},
             "roofline": {"bound": "hbm", "kernel": _lib.stage_kernel_name(dom), "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "launch_ms": round(dom_ms, 5),

@@ -131,7 +131,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
     const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
     const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
     const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
-    const float fx = (float)c.px, fy = (float)c.py;
+    float fx = (float)c.px, fy = (float)c.py;
+    asm volatile("" : "+v"(fx), "+v"(fy));   // keep the converted coordinates live (no per-iteration v_cvt)
 
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
@@ -176,19 +177,17 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
                     const float dx = p0.x - fx, dy = p0.y - fy;
                     const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
                     const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
+                    const float4 p2 = s_p2[j];
+                    // branch-free body: predicates fold into selects, every lane runs the same ~35 instructions
                     const bool hit = act && !done && power <= 0.f && alpha >= kAlphaMin;
-                    if (hit) {
-                        const float test_T = Tr * (1.f - alpha);
-                        if (test_T < kTMin) {
-                            done = true;
-                        } else {
-                            const float4 p2 = s_p2[j];
-                            const float w = alpha * Tr;
-                            C0 += p2.x * w; C1 += p2.y * w; C2 += p2.z * w; Dp += p2.w * w;
-                            Tr = test_T;
-                            last = base + (uint32_t)j + 1u;
-                        }
-                    }
+                    const float test_T = Tr * (1.f - alpha);
+                    const bool stop = hit && test_T < kTMin;
+                    const bool take = hit && !stop;
+                    done = done || stop;
+                    const float w = take ? alpha * Tr : 0.f;
+                    C0 = fmaf(p2.x, w, C0); C1 = fmaf(p2.y, w, C1); C2 = fmaf(p2.z, w, C2); Dp = fmaf(p2.w, w, Dp);
+                    Tr = take ? test_T : Tr;
+                    last = take ? base + (uint32_t)j + 1u : last;
                 }
                 // per-row / per-wave early termination from one ballot per 32 entries
                 const uint64_t alive = __ballot(!done);
