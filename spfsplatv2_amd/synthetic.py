@@ -125,6 +125,8 @@ CONFIGS = {
     "C5": (500000, (512, 512), (512, 512), 2, 16),
     # small parity-test scenes (oracle finishes in seconds): up to 2 x 64 x 64 Gaussians
     "TEST": (4096, (64, 64), (64, 64), 2, 1),
+    # many Gaussians per tile (exercises the long-list sort classes): up to 2 x 256 x 256 Gaussians
+    "TESTBIG": (70000, (32, 32), (256, 256), 2, 1),
 }
 
 

@@ -1,0 +1,194 @@
+"""More GPU parity: long tile lists (every sort size class), colours-precomputed and orthographic entry points,
+gradient switches, degenerate inputs, and size-independent properties at BASELINE's full C2 size."""
+import pytest
+import torch
+
+from spfsplatv2_amd import synthetic as syn
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("G,expect_min_list", [(9000, 2049), (40000, 8193), (70000, 16385)])
+def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list):
+    """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and the global-memory
+    fallback above 16384 entries."""
+    batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G)
+    batch.opacities = batch.opacities * 0.03        # keep transmittance alive deep into the lists
+    prod = util.run_product(batch)
+    assert prod["stats"]["max_tile_list"] >= expect_min_list, prod["stats"]
+    ref = util.run_oracle(batch, torch.float64)
+    # thousands of entries per pixel -> proportionally more knife-edge pixels to exclude from the RGB gate
+    rep = util.compare(prod, ref, max_fragile_frac=0.08)
+    assert not rep["fails"], rep
+
+
+def test_render_cuda_colors_precomp_matches_oracle(hip_lib):
+    """`render_cuda(..., use_sh=False)` -> colors_precomp path (cuda_splatting.py:131-132)."""
+    import spfsplatv2_amd as spf
+    from oracle import glue_ref, splat_ref
+    b = syn.make_batch("TEST", 3, 1, seed=31, s_mult=12.0, G=900, K=1, image_hw=(48, 80))
+    b.harmonics = b.harmonics.abs()                     # colours used as given
+    bg = torch.rand(3, 3, generator=torch.Generator().manual_seed(1))
+    dev = "cuda"
+    harm = b.harmonics.to(dev).requires_grad_(True)
+    img, dep = spf.render_cuda(b.extrinsics[:, 0].to(dev), b.intrinsics[:, 0].to(dev), b.near[:, 0].to(dev),
+                               b.far[:, 0].to(dev), b.image_shape, bg.to(dev), b.means.to(dev), b.covariances.to(dev),
+                               harm, b.opacities.to(dev), b.rotations.to(dev), b.scales.to(dev),
+                               scale_invariant=True, use_sh=False, enable_cov_grad=True, enable_sh_grad=True)
+    assert img.shape == (3, 3, 48, 80) and dep.shape == (3, 1, 48, 80)
+    img.sum().backward()
+    args = glue_ref.callsite_args(b.extrinsics[:, 0], b.intrinsics[:, 0], b.near[:, 0], b.far[:, 0], b.image_shape,
+                                  bg, b.means, b.harmonics, b.opacities, b.rotations, b.scales, use_sh=False)
+    for i, a in enumerate(args):
+        col = a["colors_precomp"].double().requires_grad_(True)
+        oi, od, oa, _, frag = splat_ref.rasterize(
+            a["means3D"].double(), a["scales"].double(), a["rotations"].double(), a["opacities"].double(), None,
+            col, a["viewmatrix"].double(), a["projmatrix"].double(), a["bg"].double(), a["tanfovx"], a["tanfovy"],
+            48, 80, 0, want_fragile=True)
+        ok = ~frag
+        assert float(((img[i].detach().cpu().double() - oi).abs() * ok).max()) < 1e-4
+        assert float(((dep[i].detach().cpu().double() - od).abs() * ok).max()) < 1e-4 * float(od.max())
+        oi.sum().backward()
+        assert util.rel_linf(harm.grad[i, :, :, 0], col.grad) < 1e-3
+
+
+def test_orthographic_matches_oracle(hip_lib):
+    import spfsplatv2_amd as spf
+    from oracle import glue_ref, splat_ref
+    b = syn.make_batch("TEST", 2, 1, seed=32, s_mult=25.0, G=1200, K=4, image_hw=(64, 64))
+    dev = "cuda"
+    width, height = torch.tensor([6.0, 9.0]), torch.tensor([6.0, 7.0])
+    near, far = torch.tensor([0.5, 0.5]), torch.tensor([60.0, 60.0])
+    out = spf.render_cuda_orthographic(b.extrinsics[:, 0].to(dev), width.to(dev), height.to(dev), near.to(dev),
+                                       far.to(dev), (40, 56), torch.zeros(2, 3, device=dev), b.means.to(dev),
+                                       b.covariances.to(dev), b.harmonics.to(dev), b.opacities.to(dev),
+                                       b.rotations.to(dev), b.scales.to(dev), fov_degrees=0.1)
+    args = glue_ref.orthographic_callsite_args(b.extrinsics[:, 0], width, height, near, far, (40, 56),
+                                               torch.zeros(2, 3), b.means, b.harmonics, b.opacities, b.rotations,
+                                               b.scales)
+    for i, a in enumerate(args):
+        oi, _, oa, _, frag = splat_ref.rasterize(
+            a["means3D"].double(), a["scales"].double(), a["rotations"].double(), a["opacities"].double(),
+            a["shs"].double(), None, a["viewmatrix"].double(), a["projmatrix"].double(), a["bg"].double(),
+            a["tanfovx"], a["tanfovy"], 40, 56, a["sh_degree"], want_fragile=True)
+        assert float(oa.max()) > 0.05                                  # something is actually visible
+        # tan(fov/2) ~ 9e-4: pixel centres are products of ~1e3-sized factors, float32 positions wobble by ~1e-3 px
+        assert float(((out[i].cpu().double() - oi).abs() * ~frag).max()) < 2e-3
+
+
+def test_grad_switches(hip_lib):
+    """enable_cov_grad=False -> no gradient to scales/rotations; enable_sh_grad=False -> none to SH
+    (SURVEY.md Appendix B #12); everything else unchanged."""
+    import spfsplatv2_amd as spf
+    b = syn.make_batch("TEST", 1, 2, seed=33, s_mult=10.0, G=600, K=4, image_hw=(48, 48)).to("cuda")
+
+    def run(cov, sh):
+        leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in util.GRAD_NAMES}
+        color, _, _ = spf.render_views(leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape,
+                                       torch.zeros(3, device="cuda"), leaves["means"], leaves["harmonics"],
+                                       leaves["opacities"], leaves["rotations"], leaves["scales"],
+                                       enable_cov_grad=cov, enable_sh_grad=sh)
+        ((color - b.target) ** 2).mean().backward()
+        return {n: leaves[n].grad for n in util.GRAD_NAMES}
+
+    full, off = run(True, True), run(False, False)
+    assert off["scales"] is None and off["rotations"] is None and off["harmonics"] is None
+    for n in ("means", "opacities", "extrinsics"):
+        assert util.rel_linf(off[n], full[n]) < 1e-4
+
+
+def test_degenerate_inputs(hip_lib):
+    import spfsplatv2_amd as spf
+    dev = "cuda"
+    b = syn.make_batch("C1", 1, 1, seed=34, s_mult=30.0)
+    # (a) everything behind the camera: D = 0, image = background exactly
+    means = b.means.clone()
+    means[..., 2] = -5.0
+    bg = torch.tensor([0.25, 0.5, 0.75], device=dev)
+    color, depth, alpha = spf.render_views(b.extrinsics.to(dev), b.intrinsics.to(dev), b.near.to(dev), b.far.to(dev),
+                                           (64, 64), bg, means.to(dev).requires_grad_(True), b.harmonics.to(dev),
+                                           b.opacities.to(dev), b.rotations.to(dev), b.scales.to(dev))
+    assert spf.last_forward_stats()["num_pairs"] == 0
+    assert torch.equal(color[0, 0], bg[:, None, None].expand(3, 64, 64)) and float(alpha.abs().max()) == 0.0
+    color.sum().backward()                               # backward with zero pairs must not fault
+    # (b) one Gaussian, image smaller than a tile, odd size
+    one = syn.make_batch("C1", 1, 1, seed=35, s_mult=200.0, G=1, image_hw=(7, 11))
+    prod = util.run_product(one)
+    ref = util.run_oracle(one, torch.float64)
+    rep = util.compare(prod, ref)
+    assert not rep["fails"], rep
+    # (c) NaN / inf parameters are culled, the rest renders
+    bad = syn.make_batch("C1", 1, 1, seed=36, s_mult=30.0)
+    bad.means[0, :5] = float("nan")
+    bad.scales[0, 5:9] = float("inf")
+    c2, _, _ = spf.render_views(bad.extrinsics.to(dev), bad.intrinsics.to(dev), bad.near.to(dev), bad.far.to(dev),
+                                (64, 64), bg, bad.means.to(dev), bad.harmonics.to(dev), bad.opacities.to(dev),
+                                bad.rotations.to(dev), bad.scales.to(dev))
+    assert bool(torch.isfinite(c2).all())
+
+
+@pytest.fixture(scope="module")
+def c2_batch():
+    return syn.make_batch("C2", 2, 2, seed=1000).to("cuda")
+
+
+def _render(b, means=None, colors=None, opac=None, bg=(0.0, 0.0, 0.0), harm=None):
+    import spfsplatv2_amd as spf
+    harm = b.harmonics if harm is None else harm
+    return spf.render_views(b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape,
+                            torch.tensor(bg, device="cuda"), b.means if means is None else means, harm,
+                            b.opacities if opac is None else opac, b.rotations, b.scales,
+                            use_sh=colors is None, enable_cov_grad=True, enable_sh_grad=True) \
+        if colors is None else \
+        spf.render_views(b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape, torch.tensor(bg, device="cuda"),
+                         b.means if means is None else means, colors, b.opacities if opac is None else opac,
+                         b.rotations, b.scales, use_sh=False, enable_cov_grad=True, enable_sh_grad=True)
+
+
+def test_full_size_properties(hip_lib, c2_batch):
+    """BASELINE config 2 size (65,536 Gaussians, 256x256): properties that need no oracle."""
+    b = c2_batch
+    img, dep, alp = _render(b)
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(dep).all())
+    assert float(alp.min()) >= 0.0 and float(alp.max()) <= 1.0 and float(alp.mean()) > 0.3
+    img2, dep2, alp2 = _render(b)
+    assert torch.equal(img, img2) and torch.equal(dep, dep2)                      # forward is bit-stable
+    # background enters as T_final * bg = (1 - alpha) * bg
+    bgc = (0.3, 0.6, 0.9)
+    img_bg, _, _ = _render(b, bg=bgc)
+    want = img + (1 - alp) * torch.tensor(bgc, device="cuda")[None, None, :, None, None]
+    assert float((img_bg - want).abs().max()) < 2e-6
+    # colours given directly: the image is linear in them (blend weights depend on geometry/opacity only)
+    gen = torch.Generator().manual_seed(5)
+    c1 = torch.rand(b.harmonics.shape, generator=gen).cuda()
+    c2 = torch.rand(b.harmonics.shape, generator=gen).cuda()
+    i1, _, _ = _render(b, colors=c1)
+    i2, _, _ = _render(b, colors=c2)
+    i12, _, _ = _render(b, colors=c1 + c2)
+    assert float((i12 - i1 - i2).abs().max()) < 5e-6
+    # order of the Gaussians in memory does not matter (depth ties aside)
+    perm = torch.randperm(b.means.shape[1], generator=gen).cuda()
+    bp = syn.Batch(**{**b.__dict__, "means": b.means[:, perm], "scales": b.scales[:, perm],
+                      "rotations": b.rotations[:, perm], "opacities": b.opacities[:, perm],
+                      "harmonics": b.harmonics[:, perm]})
+    ip, _, _ = _render(bp)
+    assert float((ip - img).abs().max()) < 1e-5
+
+
+def test_full_size_gradient_checksum(hip_lib, c2_batch):
+    """With loss = sum(image), bg = 0 and colours given directly: d loss / d colour_g = sum over pixels of the blend
+    weight, so sum_g dL/dcolour_g[c] = sum_pixels (1 - T_final) = sum(alpha) for every channel -- a checksum over
+    D = 350k (Gaussian, tile) pairs that exercises binning, sort order, LDS accumulation and the pair records."""
+    b = c2_batch
+    col = torch.rand(b.harmonics.shape, generator=torch.Generator().manual_seed(6)).cuda().requires_grad_(True)
+    img, _, alp = _render(b, colors=col)
+    img.sum().backward()
+    per_scene = col.grad[..., 0].sum(dim=1)                      # [S,3]
+    want = alp.sum(dim=(1, 2, 3, 4))                             # [S]
+    assert float(((per_scene - want[:, None]).abs() / want[:, None]).max()) < 1e-4
+    # opacity gradient of the same loss is finite and not identically zero
+    op = b.opacities.clone().requires_grad_(True)
+    i2, _, _ = _render(b, opac=op)
+    i2.sum().backward()
+    assert bool(torch.isfinite(op.grad).all()) and float(op.grad.abs().max()) > 0
