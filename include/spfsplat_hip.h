@@ -45,6 +45,7 @@ extern "C" {
 #define SPF_E_CAPACITY (-3)  /* pair buffer smaller than the number of (Gaussian, tile) pairs */
 
 #define SPF_TILE 16          /* square tile edge in pixels */
+#define SPF_DENSE_AREA 20    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
 
 /* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.
  * All scenes hold G Gaussians with K SH coefficients per colour channel (stride); the SH basis is
@@ -80,6 +81,9 @@ typedef struct SpfState {
     uint32_t* tile_count;  /* [R*T]     Gaussians per tile */
     uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D */
     uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */
+    uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
+                                        area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
+                                        "rows" render kernels, the others the sparse "lists" kernels */
     uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: unused */
     uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
     uint32_t* pair_off;    /* [R*G]     index of the Gaussian's first (Gaussian, tile) pair in Gaussian-major order:

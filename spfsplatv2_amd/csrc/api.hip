@@ -72,7 +72,7 @@ struct StageScope {
 
 const char* kStageKernel[SPF_STAGE_COUNT] = {
     "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_lds_kernel",
-    "spf_render_fwd_kernel",  "spf_render_bwd_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
+    "spf_render_fwd_lists_kernel", "spf_render_bwd_lists_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
 
 int check_dims(const SpfDims* d) {
     if (!d) return fail(SPF_E_INVALID, "dims is null");
@@ -142,7 +142,7 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     rc = check_inputs(d, in);
     if (rc) return rc;
     if (!st || !st->rec || !st->radii || !st->rect || !st->tile_count || !st->tile_start || !st->tile_fill ||
-        !st->counters || !st->blk_total || !st->blk_base)
+        !st->tile_flags || !st->counters || !st->blk_total || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
@@ -165,8 +165,8 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!st || !st->rec || !st->rect || !st->tile_start || !st->tile_fill || !st->counters || !st->final_T ||
-        !st->n_contrib || !st->pair_off || !st->blk_base)
+    if (!st || !st->rec || !st->rect || !st->tile_start || !st->tile_fill || !st->tile_flags || !st->counters ||
+        !st->final_T || !st->n_contrib || !st->pair_off || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_render is null");
     if (capacity > 0 && !st->pairs) return fail(SPF_E_INVALID, "pairs is null but capacity > 0");
     if (!out || !out->image || !out->depth || !out->alpha) return fail(SPF_E_INVALID, "an output pointer is null");
@@ -194,8 +194,8 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!st || !st->rec || !st->radii || !st->rect || !st->tile_start || !st->pairs || !st->final_T ||
-        !st->n_contrib || !st->pair_off)
+    if (!st || !st->rec || !st->radii || !st->rect || !st->tile_start || !st->tile_flags || !st->pairs ||
+        !st->final_T || !st->n_contrib || !st->pair_off)
         return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
     if (!g || !g->gpair || !g->dL_dmeans3D || !g->dL_dopacities)
         return fail(SPF_E_INVALID, "gpair, dL_dmeans3D and dL_dopacities are required");

@@ -16,6 +16,8 @@
 // would have skipped anyway, so results are identical to the un-culled loop.
 //
 // Semantics: SURVEY.md Appendix B #10/#11 (restated in oracle/splat_ref.py::composite).
+#include <stdlib.h>
+
 #include "spf_common.h"
 
 namespace spf {
@@ -115,11 +117,12 @@ __device__ __forceinline__ uint32_t block_bits(float gx, float gy, float r2, int
 // ------------------------------------------------------------------------------------------------
 // Forward: front-to-back compositing, one 4x4 pixel block per DPP row (see the header comment).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
+__global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ counters, uint64_t capacity, const float* __restrict__ bg_all,
-    float* __restrict__ image, float* __restrict__ depth_out, float* __restrict__ alpha_out,
-    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W, int T, int tiles_x, int RT) {
+    const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
+    const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
+    float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
+    int T, int tiles_x, int RT, uint32_t dense_thr) {
     __shared__ float4 s_p0[kStage];   // x, y, A, B
     __shared__ float2 s_p1[kStage];   // C, opacity
     __shared__ float4 s_p2[kStage];   // r, g, b, depth
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
     if (!block_ctx(c, RT, T, tiles_x, H, W)) return;
     const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
     const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
+    if (!tile_is_dense(tile_flags[(size_t)c.r * T + c.tile], n, dense_thr)) return;   // sparse tiles: lists kernel
     const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
     float fx = (float)c.px, fy = (float)c.py;
     asm volatile("" : "+v"(fx), "+v"(fy));   // keep the converted coordinates live (no per-iteration v_cvt)
@@ -212,6 +216,131 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward for sparse tiles ("lists"): Gaussian-parallel footprint scatter + pixel-parallel private lists.
+//
+//   phase A  thread i owns staged entry i and ORs bit i into the candidate words of exactly the pixels inside its
+//            conservative cull disc (LDS atomics; ~9 pixels for a pixel-aligned Gaussian) -- every lane works on a
+//            different Gaussian, nothing is wasted on empty (pixel, Gaussian) combinations;
+//   phase B  thread p owns pixel p (x = p & 15, y = p >> 4) and walks the set bits of ITS eight 32-bit words in
+//            list order, gathering each candidate from LDS and compositing it.
+// A pixel outside the disc has alpha < 1/255 for that Gaussian, so the result equals the plain per-pixel loop.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scatter_footprint(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2,
+                                                  int X0, int Y0) {
+    const DiscBox b = disc_box(gx, gy, r2);
+    if (!b.any) return;
+    const int xlo = (int)fmaxf((float)X0, b.xlo), xhi = (int)fminf((float)(X0 + kTile - 1), b.xhi);
+    const int ylo = (int)fmaxf((float)Y0, b.ylo), yhi = (int)fminf((float)(Y0 + kTile - 1), b.yhi);
+    uint32_t* __restrict__ wp = s_pm[i >> 5];
+    const uint32_t bit = 1u << (i & 31);
+    for (int y = ylo; y <= yhi; ++y) {
+        const float dy = (float)y - gy, dy2 = dy * dy;
+        for (int x = xlo; x <= xhi; ++x) {
+            const float dx = (float)x - gx;
+            if (!(dx * dx + dy2 > r2)) atomicOr(&wp[(y - Y0) * kTile + (x - X0)], bit);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
+    const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
+    float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
+    int T, int tiles_x, int RT, uint32_t dense_thr) {
+    __shared__ float4 s_p0[kStage];   // x, y, A, B
+    __shared__ float4 s_p1[kStage];   // C, opacity, cull r^2, depth
+    __shared__ float4 s_p2[kStage];   // r, g, b, -
+    __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
+
+    if (counters[0] > capacity) return;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    if (vid >= RT) return;
+    const int r = vid / T, tile = vid - r * T;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tid = threadIdx.x;
+    const int X0 = tx * kTile, Y0 = ty * kTile;
+    const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const uint32_t beg = tile_start[(size_t)r * T + tile];
+    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
+    if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
+    float fx = (float)px, fy = (float)py;
+    asm volatile("" : "+v"(fx), "+v"(fy));
+
+    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+    bool wave_done = __ballot(!done) == 0;
+
+    for (uint32_t base = 0; base < n; base += kStage) {
+        const int nw = (int)((min((uint32_t)kStage, n - base) + 31u) >> 5);
+        for (int w = 0; w < nw; ++w) s_pm[w][tid] = 0u;
+        const uint32_t idx = base + tid;
+        float gx = 0.f, gy = 0.f, r2 = -1.f;
+        if (idx < n) {
+            const uint32_t gid = (uint32_t)pairs[beg + idx];
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
+            const float4 a = rp[0], b = rp[1], cc = rp[2];
+            s_p0[tid] = a;
+            s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
+            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, 0.f);
+            gx = a.x; gy = a.y; r2 = b.w;
+        }
+        __syncthreads();
+        scatter_footprint(s_pm, tid, gx, gy, r2, X0, Y0);
+        __syncthreads();
+        if (!wave_done) {
+            int w = 0;
+            uint32_t m = done ? 0u : s_pm[0][tid];
+            while (true) {
+                while (__ballot(m == 0u && w < nw - 1)) {        // lanes whose word is exhausted fetch the next
+                    if (m == 0u && w < nw - 1) {
+                        ++w;
+                        m = s_pm[w][tid];
+                    }
+                }
+                if (__ballot(m != 0u) == 0) break;
+                const bool act = m != 0u;
+                const int bit = act ? __builtin_ctz(m) : 0;
+                m &= m - 1u;
+                const int j = w * 32 + bit;
+                const float4 p0 = s_p0[j];
+                const float4 p1 = s_p1[j];
+                const float4 p2 = s_p2[j];
+                const float dx = p0.x - fx, dy = p0.y - fy;
+                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
+                const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
+                const bool hit = act && power <= 0.f && alpha >= kAlphaMin;
+                const float test_T = Tr * (1.f - alpha);
+                const bool stop = hit && test_T < kTMin;
+                const bool take = hit && !stop;
+                const float wgt = take ? alpha * Tr : 0.f;
+                C0 = fmaf(p2.x, wgt, C0); C1 = fmaf(p2.y, wgt, C1); C2 = fmaf(p2.z, wgt, C2); Dp = fmaf(p1.w, wgt, Dp);
+                Tr = take ? test_T : Tr;
+                last = take ? base + (uint32_t)j + 1u : last;
+                if (stop) { done = true; m = 0u; w = nw - 1; }
+            }
+            wave_done = __ballot(!done) == 0;
+        }
+        if (__syncthreads_and(wave_done)) break;
+    }
+    if (inside) {
+        const float* __restrict__ bg = bg_all + 3 * r;
+        const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
+        float* __restrict__ img = image + (size_t)r * 3 * P;
+        img[pix] = C0 + Tr * bg[0];
+        img[P + pix] = C1 + Tr * bg[1];
+        img[2 * P + pix] = C2 + Tr * bg[2];
+        depth_out[(size_t)r * P + pix] = Dp;
+        alpha_out[(size_t)r * P + pix] = 1.0f - Tr;
+        final_T[(size_t)r * P + pix] = Tr;
+        n_contrib[(size_t)r * P + pix] = last;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward: back-to-front replay with the same decomposition.  The ten partial gradients of a
 // (block, Gaussian) pair are reduced inside the row (5 DPP adds per value, no cross-row step); lane 15 adds the
 // row totals into per-entry LDS accumulators shared by the tile's 16 blocks, and when a staging round is over
@@ -227,12 +356,12 @@ __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t s
 }
 
 template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
+__global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
-    const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
     const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off, float* __restrict__ gpair, int G, int H,
-    int W, int T, int tiles_x, int RT) {
+    int W, int T, int tiles_x, int RT, uint32_t dense_thr) {
     __shared__ float4 s_p0[kStage];
     __shared__ float2 s_p1[kStage];
     __shared__ float4 s_p2[kStage];
@@ -244,6 +373,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return;
     const int r = vid / T, tile = vid - r * T;
+    if (!tile_is_dense(tile_flags[(size_t)r * T + tile],
+                       tile_start[(size_t)r * T + tile + 1] - tile_start[(size_t)r * T + tile], dense_thr))
+        return;                                                             // sparse tiles: lists kernel
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1);
@@ -408,29 +540,268 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_kernel(
     if (staged) flush_pair(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward for sparse tiles ("lists"): three phases per round, no float atomics anywhere.
+//
+// A round takes the next (back-to-front) entries of the tile's list, as many as fit a pool of kPool LDS slots:
+// thread i owns entry hi-1-i and needs one slot per pixel of its cull-disc bounding box clipped to the tile
+// (typically 9-16; a block-wide prefix sum hands out slot ranges, the accepted entries are a prefix of i).
+//   phase A  the owner ORs bit i into the candidate words of the pixels inside its disc (as in the forward);
+//   phase B  thread p owns pixel p: replays ITS candidates back to front (ascending bits; private list, per-lane
+//            LDS gathers) and for every contributor stores the two scalars the Gaussian needs from this pixel,
+//            w = alpha*T and u = G*dL/dalpha, into slot (entry, pixel-within-box): plain ds_write_b64, one writer;
+//   phase C  the owner sums ITS slots against the pixel offsets and the pixels' dL/dC (kept in LDS), in registers,
+//            and writes the pair's 48-byte record.
+// Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPool = 2048;   // (w, u) slots per round: 16 KB
+
+template <bool DEPTH_GRAD>
+__global__ __launch_bounds__(kBlock) void spf_render_bwd_lists_kernel(
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
+    const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
+    float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr) {
+    __shared__ float4 s_p0[kStage];                 // x, y, A, B
+    __shared__ float4 s_p1[kStage];                 // C, opacity, cull r^2, depth
+    __shared__ float4 s_p2[kStage];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
+    __shared__ uint32_t s_pm[kStage / 32][kBlock];  // [32-entry word][pixel]: candidate bits
+    __shared__ float2 s_pool[kPool];                // (w, u) slots of this round's entries
+    __shared__ float4 s_gI[kBlock];                 // per pixel: dL/dC (rgb), dL/ddepth
+    __shared__ uint32_t s_w[4];                     // per-wave scratch (max / scan totals)
+    __shared__ uint32_t s_total;
+
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    if (vid >= RT) return;
+    const int r = vid / T, tile = vid - r * T;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int X0 = tx * kTile, Y0 = ty * kTile;
+    const int lx = tid & 15, ly = tid >> 4;
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < W && py < H;
+    const uint32_t beg = tile_start[(size_t)r * T + tile];
+    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
+    if (n == 0) return;
+    if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
+    float fx = (float)px, fy = (float)py;
+    asm volatile("" : "+v"(fx), "+v"(fy));
+    const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
+    auto pair_slot = [&](uint32_t gid) -> uint32_t {
+        const size_t rg = (size_t)r * G + gid;
+        const uint32_t rc = rect[rg];
+        const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
+        return pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    };
+
+    float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
+    uint32_t ncon = 0;
+    if (inside) {
+        T_final = final_T[(size_t)r * P + pix];
+        ncon = n_contrib[(size_t)r * P + pix];
+        if (dL_dimage) {
+            const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
+            gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
+        }
+        if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + pix];
+        if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
+    }
+    s_gI[tid] = make_float4(gI0, gI1, gI2, gD);
+    const float* __restrict__ bg = bg_all + 3 * r;
+    const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
+
+    const uint32_t wmax = wave_max_u32(ncon);
+    if (lane == 0) s_w[wave] = wmax;
+    __syncthreads();
+    const uint32_t bmax = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+    {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (uint32_t idx = bmax + tid; idx < n; idx += kBlock) {
+            float4* __restrict__ o =
+                reinterpret_cast<float4*>(gpair + (size_t)pair_slot((uint32_t)pairs[beg + idx]) * kRec);
+            o[0] = z; o[1] = z; o[2] = z;
+        }
+    }
+    if (bmax == 0) return;
+
+    float Tr = T_final;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f;   // colour/depth behind the current entry
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lD = 0.f;
+
+    uint32_t hi = bmax;   // entries [0, hi) are still to be replayed
+    while (hi > 0) {
+        // ---- candidates of this round: thread i <-> entry hi-1-i; slot demand; prefix sum ----
+#pragma unroll
+        for (int w = 0; w < kStage / 32; ++w) s_pm[w][tid] = 0u;
+        const bool have = (uint32_t)tid < hi;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a;
+        uint32_t gid = 0;
+        int xl = 0, yl = 0, bw = 0, bh = 0;
+        if (have) {
+            gid = (uint32_t)pairs[beg + (hi - 1u - (uint32_t)tid)];
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
+            a = rp[0]; b = rp[1]; cc = rp[2];
+            const DiscBox db = disc_box(a.x, a.y, b.w);
+            if (db.any) {
+                xl = (int)fmaxf(db.xlo - (float)X0, 0.f);
+                yl = (int)fmaxf(db.ylo - (float)Y0, 0.f);
+                bw = max(0, (int)fminf(db.xhi - (float)X0, (float)(kTile - 1)) - xl + 1);
+                bh = max(0, (int)fminf(db.yhi - (float)Y0, (float)(kTile - 1)) - yl + 1);
+            }
+        }
+        const uint32_t size = (uint32_t)(bw * bh);
+        uint32_t inc = size;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
+            if (lane >= o) inc += y;
+        }
+        __syncthreads();                       // previous round is completely over (s_w, s_pool, s_p* reusable)
+        if (lane == kWave - 1) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t off = inc - size;
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        const bool acc = have && off + size <= (uint32_t)kPool;      // a prefix of the threads
+        const int cnt = __syncthreads_count(acc);                    // >= 1: one entry needs at most 256 slots
+        if (tid == cnt - 1) s_total = off + size;
+        if (acc) {
+            s_p0[tid] = a;
+            s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
+            s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
+                                    __int_as_float(xl | (yl << 4) | (max(bw - 1, 0) << 8) | ((int)off << 12)));
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < s_total; k += kBlock) s_pool[k] = make_float2(0.f, 0.f);
+        // ---- phase A ----
+        if (acc) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
+        __syncthreads();
+        // ---- phase B: ascending bits = descending list position ----
+        const int nw = (cnt + 31) >> 5;
+        if (hi - (uint32_t)cnt < wmax) {
+            // contributors of this pixel are entries < ncon, i.e. thread indices >= hi - ncon
+            const uint32_t jmin = ncon < hi ? hi - ncon : 0u;
+            auto load_word = [&](int w) -> uint32_t {
+                const uint32_t wb = 32u * (uint32_t)w;
+                uint32_t m = s_pm[w][tid];
+                if (jmin >= wb + 32u) m = 0u;
+                else if (jmin > wb) m &= ~((1u << (jmin - wb)) - 1u);
+                return m;
+            };
+            int w = 0;
+            uint32_t m = load_word(0);
+            while (true) {
+                while (__ballot(m == 0u && w < nw - 1)) {
+                    if (m == 0u && w < nw - 1) {
+                        ++w;
+                        m = load_word(w);
+                    }
+                }
+                if (__ballot(m != 0u) == 0) break;
+                const bool act = m != 0u;
+                const int bit = act ? __builtin_ctz(m) : 0;
+                m &= m - 1u;
+                const int j = w * 32 + bit;
+                const float4 p0 = s_p0[j];
+                const float4 p1 = s_p1[j];
+                const float4 p2 = s_p2[j];
+                const float dx = p0.x - fx, dy = p0.y - fy;
+                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
+                const float Gv = __expf(power);
+                const float alpha = fminf(kAlphaMax, p1.y * Gv);
+                const bool hit = act && power <= 0.f && alpha >= kAlphaMin;
+                if (hit) {
+                    const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                    Tr = Tr * inv1ma;
+                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                    accD = last_alpha * lD + (1.f - last_alpha) * accD;
+                    lc0 = p2.x; lc1 = p2.y; lc2 = p2.z; lD = p1.w;
+                    float dL_dalpha_ = (p2.x - acc0) * gI0 + (p2.y - acc1) * gI1 + (p2.z - acc2) * gI2 +
+                                       (p1.w - accD) * gD;
+                    dL_dalpha_ *= Tr;
+                    last_alpha = alpha;
+                    // image = C + T_final*bg and alpha_out = 1 - T_final see alpha only through T_final
+                    dL_dalpha_ += (T_final * inv1ma) * tail;
+                    const int box = __float_as_int(p2.w);
+                    const int k = (box >> 12) + (ly - ((box >> 4) & 15)) * (((box >> 8) & 15) + 1) + (lx - (box & 15));
+                    s_pool[k] = make_float2(alpha * Tr, Gv * dL_dalpha_);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase C ----
+        if (acc) {
+            float Su = 0.f, Sux = 0.f, Suy = 0.f, Suxx = 0.f, Suxy = 0.f, Suyy = 0.f;
+            float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
+            const float2* __restrict__ hp = s_pool + off;
+            for (int yy = 0; yy < bh; ++yy) {
+                const float dy = a.y - (float)(Y0 + yl + yy);
+                const float4* __restrict__ gp = s_gI + (yl + yy) * kTile + xl;
+                for (int xx = 0; xx < bw; ++xx) {
+                    const float2 h = hp[yy * bw + xx];
+                    const float4 gi = gp[xx];
+                    const float dx = a.x - (float)(X0 + xl + xx);
+                    c0 = fmaf(h.x, gi.x, c0); c1 = fmaf(h.x, gi.y, c1); c2 = fmaf(h.x, gi.z, c2);
+                    if (DEPTH_GRAD) cd = fmaf(h.x, gi.w, cd);
+                    Su += h.y;
+                    Sux = fmaf(h.y, dx, Sux); Suy = fmaf(h.y, dy, Suy);
+                    Suxx = fmaf(h.y * dx, dx, Suxx); Suxy = fmaf(h.y * dx, dy, Suxy);
+                    Suyy = fmaf(h.y * dy, dy, Suyy);
+                }
+            }
+            const float o = b.y;   // [3DGS-grad] dL/dG = opacity * dL/dalpha (the 0.99 clamp is straight-through)
+            float4* __restrict__ out = reinterpret_cast<float4*>(gpair + (size_t)pair_slot(gid) * kRec);
+            out[0] = make_float4(-o * (a.z * Sux + a.w * Suy), -o * (b.x * Suy + a.w * Sux), -0.5f * o * Suxx,
+                                 -o * Suxy);
+            out[1] = make_float4(-0.5f * o * Suyy, Su, c0, c1);
+            out[2] = make_float4(c2, cd, 0.f, 0.f);
+        }
+        hi -= (uint32_t)cnt;
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
+static uint32_t dense_threshold() {
+    static const uint32_t v = getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA;
+    return v;
+}
+
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
                              uint64_t capacity, int T, int tiles_x, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    spf_render_fwd_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, st.counters, capacity, in.bg,
-                                                       out.image, out.depth, out.alpha, st.final_T, st.n_contrib, d.G,
-                                                       d.H, d.W, T, tiles_x, RT);
+    // every tile is rendered by exactly one of the two kernels (tile_flags bit 0, set while binning)
+    spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, st.tile_flags,
+                                                             st.counters, capacity, in.bg, out.image, out.depth,
+                                                             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T,
+                                                             tiles_x, RT, dense_threshold());
+    spf_render_fwd_rows_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, st.tile_flags,
+                                                            st.counters, capacity, in.bg, out.image, out.depth,
+                                                            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T,
+                                                            tiles_x, RT, dense_threshold());
     return hipGetLastError();
+}
+
+template <bool DG>
+static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
+                                int tiles_x, int RT, int grid, hipStream_t stream) {
+    spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
+        st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+        g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
+        st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+        g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
                              int tiles_x, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (g.dL_ddepth)
-        spf_render_bwd_kernel<true><<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, st.tile_start, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha,
-            st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
-    else
-        spf_render_bwd_kernel<false><<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, st.tile_start, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha,
-            st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT);
+    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, stream);
+    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, stream);
     return hipGetLastError();
 }
 

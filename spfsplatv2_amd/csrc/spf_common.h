@@ -83,6 +83,29 @@ __device__ __forceinline__ uint64_t readfirstlane64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Pixel bounding box of a Gaussian's conservative cull disc (centre (gx,gy), squared radius r2), padded so that
+// float rounding can only make it larger.  The exact per-pixel test is always `!(dx*dx + dy*dy > r2)`.
+struct DiscBox {
+    float xlo, xhi, ylo, yhi;   // integral values
+    bool any;
+};
+__device__ __forceinline__ DiscBox disc_box(float gx, float gy, float r2) {
+    DiscBox b;
+    b.any = r2 >= 0.f;
+    const float rb = sqrtf(fmaxf(r2, 0.f)) * 1.0001f + 1e-3f;
+    b.xlo = ceilf(gx - rb); b.xhi = floorf(gx + rb);
+    b.ylo = ceilf(gy - rb); b.yhi = floorf(gy + rb);
+    return b;
+}
+// bounding-box area of the disc in pixels, capped at one tile (feeds the per-tile sparse/dense decision)
+__device__ __forceinline__ uint32_t disc_area_capped(float gx, float gy, float r2) {
+    const DiscBox b = disc_box(gx, gy, r2);
+    if (!b.any) return 0u;
+    const float w = fminf(fmaxf(b.xhi - b.xlo + 1.f, 0.f), (float)kTile), h = fminf(fmaxf(b.yhi - b.ylo + 1.f, 0.f), (float)kTile);
+    return (uint32_t)(w * h);
+}
+__device__ __forceinline__ bool tile_is_dense(uint32_t area_sum, uint32_t n, uint32_t thr = SPF_DENSE_AREA) { return area_sum > thr * n; }
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8, so give each XCD one
 // contiguous range of work ids (contiguous renders -> their records stay in that XCD's L2).
 // Speed only; correctness never depends on it.  grid must be a multiple of 8.

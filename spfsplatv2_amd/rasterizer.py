@@ -75,8 +75,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     rect = torch.empty((R * G,), **i32)
     nblk = lib.spf_raster_view_partial_blocks(G)
     pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
-    tiles = torch.empty((3 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | counters
-    counters = tiles[3 * R * T + 1:]
+    tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | tile_flags | counters
+    counters = tiles[4 * R * T + 1:]
     final_T = torch.empty((R * P,), **f32)
     n_contrib = torch.empty((R * P,), **i32)
     image = torch.empty((S, V, 3, H, W), **f32)
@@ -111,7 +111,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:RT]), _ptr(tiles[RT:2 * RT + 1]),
-                         _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:]), _ptr(pairs),
+                         _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:4 * RT + 1]),
+                         _ptr(tiles[4 * RT + 1:]), _ptr(pairs),
                          _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib))
 
@@ -125,9 +126,9 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
-    if capacity_mode and int(tiles[3 * R * T + 1 + 2]) != 0:
+    if capacity_mode and int(tiles[4 * R * T + 1 + 2]) != 0:
         raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
-                            f"({pairs.numel()} < {int(tiles[3 * R * T + 1])}); outputs were not rendered")
+                            f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)

@@ -25,7 +25,7 @@ def test_struct_sizes_match_header():
     from spfsplatv2_amd import _lib
     assert C.sizeof(_lib.SpfDims) == 32
     assert C.sizeof(_lib.SpfInputs) == 11 * 8
-    assert C.sizeof(_lib.SpfState) == 13 * 8
+    assert C.sizeof(_lib.SpfState) == 14 * 8
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
     assert C.sizeof(_lib.SpfGrads) == 13 * 8
 
@@ -35,7 +35,7 @@ def test_host_helpers_no_gpu(hip_lib):
     assert hip_lib.spf_raster_num_tiles(100, 33) == 7 * 3
     assert hip_lib.spf_raster_view_partial_blocks(65536) == 256
     assert hip_lib.spf_raster_view_partial_blocks(257) == 2
-    assert hip_lib.spf_stage_kernel_name(5) == b"spf_render_bwd_kernel"
+    assert hip_lib.spf_stage_kernel_name(5) == b"spf_render_bwd_lists_kernel"
 
 
 def test_argument_validation_without_compute(hip_lib):

@@ -111,8 +111,8 @@ def test_drop_in_rasterizer_surface(hip_lib):
         args["sh_degree"], 1.0, want_fragile=True)
     ((oimg - batch.target[0, 0].double()) ** 2).mean().backward()
     ok = ~frag
-    assert float(((image.cpu().double() - oimg).abs() * ok).max()) < 1e-4
-    assert float(((depth.cpu().double() - odep).abs() * ok).max()) < 1e-4 * float(odep.max())
+    assert float(((image.detach().cpu().double() - oimg).abs() * ok).max()) < 1e-4
+    assert float(((depth.detach().cpu().double() - odep).abs() * ok).max()) < 1e-4 * float(odep.max())
     assert (radii.cpu() != orad).float().mean() < 1e-3
     for k in leaves:
         assert util.rel_linf(leaves[k].grad, ol[k].grad) < 1e-3, k
