@@ -44,6 +44,7 @@ extern "C" {
 #define SPF_E_LAUNCH (-2)    /* a HIP call failed; see spf_last_error() */
 #define SPF_E_CAPACITY (-3)  /* pair buffer smaller than the number of (Gaussian, tile) pairs */
 
+#define SPF_UNKNOWN 0xffffffffu
 #define SPF_TILE 16          /* square tile edge in pixels */
 #define SPF_DENSE_AREA 20    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
 
@@ -84,7 +85,7 @@ typedef struct SpfState {
     uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
                                         area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
                                         "rows" render kernels, the others the sparse "lists" kernels */
-    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: unused */
+    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: number of dense tiles */
     uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
     uint32_t* pair_off;    /* [R*G]     index of the Gaussian's first (Gaussian, tile) pair in Gaussian-major order:
                                         its pair with the k-th tile of its rect (row-major) has index pair_off + k */
@@ -151,14 +152,16 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
 
 /* Forward, stage 2: bin (Gaussian, tile) pairs into per-tile lists, depth-sort every list and
  * composite.  `capacity` = number of uint64 entries st->pairs can hold; `max_tile_hint` = host copy
- * of counters[1] (0 = unknown: every sort size class is launched).  If D > capacity nothing is
+ * of counters[1] (0 = unknown: every sort size class is launched); `dense_tiles_hint` = host copy of counters[3]
+ * (SPF_UNKNOWN = unknown: both the sparse and the dense render kernels are launched; each tile is rendered by
+ * exactly one of them either way).  If D > capacity nothing is
  * rendered, counters[2] is set to 1 and the images are left untouched. */
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
-                              uint64_t capacity, uint32_t max_tile_hint, void* stream);
+                              uint64_t capacity, uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream);
 
 /* Backward of both stages.  `capacity` = number of 12-float records g->gpair can hold (>= D). */
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
-                        const SpfGrads* g, uint64_t capacity, void* stream);
+                        const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
 
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n) for the
  * two outer dims, stride(H) == D and stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.

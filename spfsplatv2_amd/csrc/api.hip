@@ -9,12 +9,14 @@
 namespace spf {
 hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&, int, int, hipStream_t);
 hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, hipStream_t);
-hipError_t launch_tile_scan(const SpfState&, int, int, hipStream_t);
+hipError_t launch_tile_scan(const SpfState&, int, int, uint32_t, hipStream_t);
+uint32_t dense_threshold();
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, hipStream_t);
 hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
+                             uint32_t, hipStream_t);
+hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
                              hipStream_t);
-hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
 hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int, float, float, hipStream_t);
@@ -148,19 +150,21 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
     SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * (size_t)RT, stream));
+    SPF_HIP(hipMemsetAsync(st->tile_flags, 0, sizeof(uint32_t) * (size_t)RT, stream));
     {
         StageScope t(SPF_STAGE_PROJECT, stream);
         SPF_HIP(spf::launch_project_fwd(*d, *in, *st, tiles_x, tiles_y, stream));
     }
     {
         StageScope t(SPF_STAGE_SCAN, stream);
-        SPF_HIP(spf::launch_tile_scan(*st, RT, d->S * d->V * spf_raster_view_partial_blocks(d->G), stream));
+        SPF_HIP(spf::launch_tile_scan(*st, RT, d->S * d->V * spf_raster_view_partial_blocks(d->G),
+                                      spf::dense_threshold(), stream));
     }
     return SPF_OK;
 }
 
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out, uint64_t capacity,
-                              uint32_t max_tile_hint, void* stream_) {
+                              uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream_) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -183,13 +187,13 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     }
     {
         StageScope t(SPF_STAGE_RENDER_FWD, stream);
-        SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, capacity, T, tiles_x, stream));
+        SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, capacity, T, tiles_x, dense_tiles_hint, stream));
     }
     return SPF_OK;
 }
 
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g,
-                        uint64_t capacity, void* stream_) {
+                        uint64_t capacity, uint32_t dense_tiles_hint, void* stream_) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -208,7 +212,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     (void)capacity;   // every pair record is written exactly once by its tile: no memset of gpair
     {
         StageScope t(SPF_STAGE_RENDER_BWD, stream);
-        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, stream));
+        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, dense_tiles_hint, stream));
     }
     {
         StageScope t(SPF_STAGE_PROJECT_BWD, stream);

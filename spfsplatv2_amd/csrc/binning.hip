@@ -85,14 +85,21 @@ __device__ __forceinline__ void block_exclusive_scan(const uint32_t* __restrict_
 __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
                                                                      uint32_t* __restrict__ start,
                                                                      uint32_t* __restrict__ fill,
-                                                                     uint32_t* __restrict__ flags,
+                                                                     const uint32_t* __restrict__ flags,
+                                                                     uint32_t dense_thr,
                                                                      uint32_t* __restrict__ counters, int n,
                                                                      const uint32_t* __restrict__ blk_total,
                                                                      uint32_t* __restrict__ blk_base, int nb) {
     __shared__ uint32_t s_wsum[kScanThreads / kWave];
     __shared__ uint32_t s_wmax[kScanThreads / kWave];
     uint32_t total, gmax, t2, m2;
-    for (int i = threadIdx.x; i < n; i += kScanThreads) flags[i] = 0u;
+    __shared__ uint32_t s_dense;
+    if (threadIdx.x == 0) s_dense = 0;
+    __syncthreads();
+    uint32_t nd = 0;                                                               // tiles the rows kernels take
+    for (int i = threadIdx.x; i < n; i += kScanThreads) nd += tile_is_dense(flags[i], count[i], dense_thr) ? 1u : 0u;
+    nd = wave_sum_u32(nd);
+    if ((threadIdx.x & 63) == 0 && nd) atomicAdd(&s_dense, nd);
     block_exclusive_scan(count, start, fill, n, s_wsum, s_wmax, total, gmax);       // tile lists
     block_exclusive_scan(blk_total, blk_base, nullptr, nb, s_wsum, s_wmax, t2, m2);  // Gaussian-major pair ids
     if (threadIdx.x == 0) {
@@ -100,7 +107,8 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
         counters[0] = total;
         counters[1] = gmax;
         counters[2] = 0;
-        counters[3] = t2;   // == total (both count the same pairs)
+        (void)t2;           // == total (both count the same pairs)
+        counters[3] = s_dense;
     }
 }
 
@@ -112,13 +120,12 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
                                                                const uint32_t* __restrict__ rect,
                                                                const uint32_t* __restrict__ tile_start,
                                                                uint32_t* __restrict__ tile_fill,
-                                                               uint32_t* __restrict__ tile_flags,
                                                                uint32_t* __restrict__ counters,
                                                                uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                const uint32_t* __restrict__ blk_base,
                                                                uint32_t* __restrict__ pair_off,
                                                                int G, int T, int tiles_x, int lds) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases, [T] footprint areas
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases
     __shared__ uint32_t s_wtot[4];
     uint32_t* s_cnt = s_bin;
     uint32_t* s_base = s_bin + T;
@@ -150,32 +157,25 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     }
     const uint64_t key = any ? (((uint64_t)__float_as_uint(rec[rg * kRec + 6]) << 32) | (uint32_t)g) : 0ull;
     const size_t tb = (size_t)r * T;
-    const uint32_t area = any ? disc_area_capped(rec[rg * kRec + 0], rec[rg * kRec + 1], rec[rg * kRec + 7]) : 0u;
     if (!lds) {
         if (any)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     const size_t t = tb + ty * tiles_x + tx;
                     pairs[tile_start[t] + atomicAdd(&tile_fill[t], 1u)] = key;
-                    atomicAdd(&tile_flags[t], area);
                 }
         return;
     }
-    uint32_t* s_area = s_bin + 2 * T;
-    for (int t = threadIdx.x; t < T; t += kBlock) { s_cnt[t] = 0; s_area[t] = 0; }
+    for (int t = threadIdx.x; t < T; t += kBlock) s_cnt[t] = 0;
     __syncthreads();
     if (any)
         for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
-                atomicAdd(&s_cnt[ty * tiles_x + tx], 1u);
-                atomicAdd(&s_area[ty * tiles_x + tx], area);
-            }
+            for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1u);
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += kBlock) {
         const uint32_t c = s_cnt[t];
         if (c) {
             s_base[t] = tile_start[tb + t] + atomicAdd(&tile_fill[tb + t], c);
-            atomicAdd(&tile_flags[tb + t], s_area[t]);
             s_cnt[t] = 0;
         }
     }
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint3
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-hipError_t launch_tile_scan(const SpfState& st, int RT, int nb, hipStream_t stream) {
+hipError_t launch_tile_scan(const SpfState& st, int RT, int nb, uint32_t dense_thr, hipStream_t stream) {
     spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.tile_flags,
-                                                         st.counters, RT,
+                                                         dense_thr, st.counters, RT,
                                                          st.blk_total, st.blk_base, nb);
     return hipGetLastError();
 }
@@ -271,9 +271,8 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
                             hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
-    spf_bin_pairs_kernel<<<grid, kBlock, lds ? 3 * sizeof(uint32_t) * T : 0, stream>>>(
-        st.rec, st.rect, st.tile_start, st.tile_fill, st.tile_flags, st.counters, st.pairs, capacity, st.blk_base,
-        st.pair_off,
+    spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
+        st.rec, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
         d.G, T, tiles_x, lds);
     return hipGetLastError();
 }

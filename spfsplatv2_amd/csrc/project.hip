@@ -170,8 +170,9 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
     const Sym3 Sg0 = cov3d(R, sx, sy, sz);
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
     const int T = tiles_x * tiles_y;
+    uint32_t* s_area = s_hist + T;      // footprint load per tile (see tile_flags in the header)
     if (lds_hist) {
-        for (int t = threadIdx.x; t < T; t += kBlock) s_hist[t] = 0;
+        for (int t = threadIdx.x; t < 2 * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
     }
 
@@ -262,8 +263,13 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
             rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
             rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
             uint32_t* __restrict__ cnt = lds_hist ? s_hist : st.tile_count + (size_t)r * T;
+            uint32_t* __restrict__ are = lds_hist ? s_area : st.tile_flags + (size_t)r * T;
+            const uint32_t area = disc_area_capped(pr.px, pr.py, cull_r2);
             for (int ty = y0; ty < y1; ++ty)
-                for (int tx = x0; tx < x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+                for (int tx = x0; tx < x1; ++tx) {
+                    atomicAdd(&cnt[ty * tiles_x + tx], 1u);
+                    atomicAdd(&are[ty * tiles_x + tx], area);
+                }
         }
         // pairs produced by this block for this render (feeds the Gaussian-major pair numbering)
         const uint32_t wsum = wave_sum_u32(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u);
@@ -273,11 +279,14 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
             st.blk_total[(size_t)r * gridDim.x + blockIdx.x] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
         if (lds_hist) {
             uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
+            uint32_t* __restrict__ gare = st.tile_flags + (size_t)r * T;
             for (int t = threadIdx.x; t < T; t += kBlock) {
                 const uint32_t c = s_hist[t];
                 if (c) {
                     atomicAdd(&gcnt[t], c);
+                    atomicAdd(&gare[t], s_area[t]);
                     s_hist[t] = 0;
+                    s_area[t] = 0;
                 }
             }
         }
@@ -574,7 +583,7 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
     const int T = tiles_x * tiles_y;
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
-    const size_t sm = lds ? sizeof(uint32_t) * T : 0;
+    const size_t sm = lds ? 2 * sizeof(uint32_t) * T : 0;
     switch (deg) {
         case -1: spf_project_fwd_kernel<-1><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
         case 0: spf_project_fwd_kernel<0><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;

@@ -764,44 +764,47 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_lists_kernel(
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
-static uint32_t dense_threshold() {
+uint32_t dense_threshold() {
     static const uint32_t v = getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA;
     return v;
 }
 
+// Every tile is rendered by exactly one of the two kernels (decided per tile from tile_flags / list length);
+// `dense_hint` (number of dense tiles, or SPF_UNKNOWN) only lets the host skip a launch that would find no tile.
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
-                             uint64_t capacity, int T, int tiles_x, hipStream_t stream) {
+                             uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    // every tile is rendered by exactly one of the two kernels (tile_flags bit 0, set while binning)
-    spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, st.tile_flags,
-                                                             st.counters, capacity, in.bg, out.image, out.depth,
-                                                             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T,
-                                                             tiles_x, RT, dense_threshold());
-    spf_render_fwd_rows_kernel<<<grid, kBlock, 0, stream>>>(st.rec, st.pairs, st.tile_start, st.tile_flags,
-                                                            st.counters, capacity, in.bg, out.image, out.depth,
-                                                            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T,
-                                                            tiles_x, RT, dense_threshold());
+    if (dense_hint != (uint32_t)RT)
+        spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    if (dense_hint != 0u)
+        spf_render_fwd_rows_kernel<<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
     return hipGetLastError();
 }
 
 template <bool DG>
 static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                                int tiles_x, int RT, int grid, hipStream_t stream) {
-    spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
-        st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-        g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
-    spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
-        st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-        g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+                                int tiles_x, int RT, int grid, uint32_t dense_hint, hipStream_t stream) {
+    if (dense_hint != (uint32_t)RT)
+        spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    if (dense_hint != 0u)
+        spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                             int tiles_x, hipStream_t stream) {
+                             int tiles_x, uint32_t dense_hint, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, stream);
-    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, stream);
+    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, stream);
+    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, stream);
     return hipGetLastError();
 }
 

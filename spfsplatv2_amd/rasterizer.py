@@ -94,19 +94,19 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         # exact mode: one 16-byte read-back per BATCH (the reference syncs twice per view,
         # cuda_splatting.py:108-109, plus once inside its rasterizer)
         host = counters.cpu()
-        D, max_tile = int(host[0]), int(host[1])
+        D, max_tile, dense = int(host[0]), int(host[1]), int(host[3])
         capacity = D
-        _stats.update(num_pairs=D, max_tile_list=max_tile)
+        _stats.update(num_pairs=D, max_tile_list=max_tile, dense_tiles=dense, tiles=R * T)
     else:
-        capacity, max_tile = int(max_pairs), 0
+        capacity, max_tile, dense = int(max_pairs), 0, 0xFFFFFFFF
     pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
     st.pairs = _ptr(pairs)
     out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
-                                             capacity, max_tile, stream),
+                                             capacity, max_tile, dense, stream),
                "spf_raster_forward_render")
     return ((image, depth, alpha, radii.view(S, V, G)),
-            (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib))
+            (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
 
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
@@ -122,7 +122,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
-    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode = geom
+    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense = geom
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
@@ -151,7 +151,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(gpair), _ptr(vpartial),
                        _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
                        _ptr(d_view), _ptr(d_m2d))
-    _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity,
+    _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity, dense,
                                        _stream_ptr(dev)), "spf_raster_backward")
     return d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d
 
@@ -161,11 +161,12 @@ class _RasterizeBatch(torch.autograd.Function):
     def forward(ctx, means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                 view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs):
         ctx.set_materialize_grads(False)
-        outs, state = _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
-                                    tanfov, bg, view_scale, H, W, sh_degree, scale_modifier, max_pairs)
+        outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix,
+                                           projmatrix, tanfov, bg, view_scale, H, W, sh_degree, scale_modifier,
+                                           max_pairs)
         S, G, _ = means3D.shape
         ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
-                    float(scale_modifier), max_pairs is not None)
+                    float(scale_modifier), max_pairs is not None, dense)
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
@@ -207,10 +208,10 @@ class _DecoderRender(torch.autograd.Function):
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
         _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
-        outs, state = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg,
-                                    vscale, H, W, sh_degree, 1.0, max_pairs)
+        outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
+                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs)
         G = means3D.shape[1]
-        ctx.geom = (S, V, G, 0 if shs is None else shs.shape[2], sh_degree, H, W, 1.0, max_pairs is not None)
+        ctx.geom = (S, V, G, 0 if shs is None else shs.shape[2], sh_degree, H, W, 1.0, max_pairs is not None, dense)
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
                               *state, near)
