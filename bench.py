@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-free", action="store_true", help="fixed pair-buffer capacity, no per-step read-back")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one whole step (decoder fwd + loss + bwd) in a HIP graph and replay it "
+                         "(implies --sync-free)")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -160,21 +163,41 @@ def main():
     torch.cuda.synchronize(dev)
     D_total = spf.last_forward_stats()["num_pairs"]
     log(f"first step done: D={D_total}, max tile list={spf.last_forward_stats()['max_tile_list']}")
-    if args.sync_free:
+    if args.sync_free or args.graph:
         max_pairs = int(D_total * 1.25) + 1024
+    run = step
+    eager_survey = None
+    if args.graph:
+        # per-stage survey and dominant-kernel timing need eager launches (events are recorded at launch time,
+        # a replayed graph launches nothing from the host)
+        _lib.stage_timing_enable(True)
+        for _ in range(max(args.warmup, 3)):
+            step()
+        torch.cuda.synchronize(dev)
+        eager_survey = {k: (v[0] / v[1], 1) for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
+        _lib.stage_timing_enable(False)
+        for t in leaves.values():
+            t.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        run = graph.replay
+        log("step captured in a HIP graph")
     # warm-up doubles as the per-stage survey (HIP events around every stage); the timed region then keeps
     # events only around the dominant kernel, so the headline number is not diluted by 14 event records/step
     _lib.stage_timing_enable(True)
     for _ in range(max(args.warmup, 1)):
-        step()
+        run()
     torch.cuda.synchronize(dev)
     survey = {k: v for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
+    if eager_survey is not None:
+        survey = {k: (v[0] * max(args.warmup, 1), max(args.warmup, 1)) for k, v in eager_survey.items()}
     dom = max(survey, key=lambda k: survey[k][0])
     _lib.stage_timing_enable([dom])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     barrier()
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
@@ -189,7 +212,7 @@ def main():
         P = h * w
         renders = world * S * V
         value = renders * P * args.steps / dt / 1e6
-        dom_ms = stages[dom][0] / max(stages[dom][1], 1)
+        dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1]
         dom_bytes = stage_bytes(dom, S, V, G, K, P, D_total)
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
@@ -211,7 +234,8 @@ def main():
                                    "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
-                       "s_mult": args.s_mult, "pair_buffer": "capacity" if args.sync_free else "exact",
+                       "s_mult": args.s_mult, "pair_buffer": "capacity" if (args.sync_free or args.graph) else "exact",
+                       "launch": "hip-graph replay" if args.graph else "eager",
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},
             "roofline": {"bound": "hbm", "kernel": _lib.stage_kernel_name(dom), "achieved": round(achieved, 2),

@@ -79,6 +79,8 @@ typedef struct SpfState {
     float* rec;            /* [R*G,12]  screen-space record: xy, conic(3), opacity, rgb, depth, cull r^2, flags */
     int32_t* radii;        /* [R*G]     pixel radius, 0 = culled (also an output) */
     uint32_t* rect;        /* [R*G]     packed tile rect: xmin | ymin<<8 | xmax<<16 | ymax<<24 */
+    float* zkey;           /* [R*G]     view-space depth again, compact (the binning pass reads 8 B per Gaussian
+                                        instead of pulling the 48-byte record through the cache) */
     uint32_t* tile_count;  /* [R*T]     Gaussians per tile */
     uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D */
     uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */

@@ -29,7 +29,7 @@ def _ptr_struct(name, fields):
 
 SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
                                       "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale"])
-SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "tile_count", "tile_start", "tile_fill",
+SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
                                     "n_contrib"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])

@@ -143,8 +143,8 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!st || !st->rec || !st->radii || !st->rect || !st->tile_count || !st->tile_start || !st->tile_fill ||
-        !st->tile_flags || !st->counters || !st->blk_total || !st->blk_base)
+    if (!st || !st->rec || !st->radii || !st->rect || !st->zkey || !st->tile_count || !st->tile_start ||
+        !st->tile_fill || !st->tile_flags || !st->counters || !st->blk_total || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
@@ -169,7 +169,8 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     if (rc) return rc;
     rc = check_inputs(d, in);
     if (rc) return rc;
-    if (!st || !st->rec || !st->rect || !st->tile_start || !st->tile_fill || !st->tile_flags || !st->counters ||
+    if (!st || !st->rec || !st->rect || !st->zkey || !st->tile_start || !st->tile_fill || !st->tile_flags ||
+        !st->counters ||
         !st->final_T || !st->n_contrib || !st->pair_off || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_render is null");
     if (capacity > 0 && !st->pairs) return fail(SPF_E_INVALID, "pairs is null but capacity > 0");

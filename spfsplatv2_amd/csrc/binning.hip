@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
 // Three phases per block, all tile bookkeeping in LDS: (1) count the block's pairs per tile, (2) reserve one
 // contiguous range per touched tile with ONE global atomic, (3) hand out slots inside the range with LDS
 // atomics and write the keys.  lds = 0 (more than kMaxLdsTiles tiles): one global atomic per pair.
-__global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __restrict__ rec,
+__global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __restrict__ zkey,
                                                                const uint32_t* __restrict__ rect,
                                                                const uint32_t* __restrict__ tile_start,
                                                                uint32_t* __restrict__ tile_fill,
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
         if (live) pair_off[rg] = off;
     }
-    const uint64_t key = any ? (((uint64_t)__float_as_uint(rec[rg * kRec + 6]) << 32) | (uint32_t)g) : 0ull;
+    const uint64_t key = any ? (((uint64_t)__float_as_uint(zkey[rg]) << 32) | (uint32_t)g) : 0ull;
     const size_t tb = (size_t)r * T;
     if (!lds) {
         if (any)
@@ -272,7 +272,7 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
-        st.rec, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
+        st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
         d.G, T, tiles_x, lds);
     return hipGetLastError();
 }

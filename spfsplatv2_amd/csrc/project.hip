@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
         if (live && !ok) {
             st.radii[rg] = 0;
             st.rect[rg] = 0;
+            st.zkey[rg] = 0.f;
             rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
             rec[1] = make_float4(0.f, 0.f, 0.f, -1.f);
             rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
 
             st.radii[rg] = (int)radius;
             st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+            st.zkey[rg] = pr.tz;
             rec[0] = make_float4(pr.px, pr.py, cA, cB);
             rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
             rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
@@ -435,10 +437,6 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
             if (DEG < 0) {
                 dcol[0] += gcol[0]; dcol[1] += gcol[1]; dcol[2] += gcol[2];
             } else {
-                const int clampmask = __float_as_int(reinterpret_cast<const float4*>(st.rec + rg * kRec)[2].w);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    if (clampmask & (1 << ch)) gcol[ch] = 0.f;
                 float vdir[3];
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
@@ -448,6 +446,19 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
                 float basis[NB], dbx[NB], dby[NB], dbz[NB];
                 sh_basis<(DEG < 0 ? 0 : DEG), true>(x, y, z, basis, dbx, dby, dbz);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                {   // colours clamped at 0 in the forward pass no gradient: re-evaluate the colour exactly as the
+                    // forward kernel does (same expression order) instead of re-reading its 48-byte record
+                    float col[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        col[0] += basis[k] * sh[3 * k];
+                        col[1] += basis[k] * sh[3 * k + 1];
+                        col[2] += basis[k] * sh[3 * k + 2];
+                    }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)
+                        if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
+                }
                 float dd[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {

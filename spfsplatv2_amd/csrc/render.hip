@@ -294,21 +294,28 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         if (!wave_done) {
             int w = 0;
             uint32_t m = done ? 0u : s_pm[0][tid];
-            while (true) {
-                while (__ballot(m == 0u && w < nw - 1)) {        // lanes whose word is exhausted fetch the next
+            // next candidate of this lane (-1: none left); lanes whose word is exhausted fetch the next word
+            auto next = [&]() -> int {
+                while (__ballot(m == 0u && w < nw - 1)) {
                     if (m == 0u && w < nw - 1) {
                         ++w;
                         m = s_pm[w][tid];
                     }
                 }
-                if (__ballot(m != 0u) == 0) break;
-                const bool act = m != 0u;
-                const int bit = act ? __builtin_ctz(m) : 0;
+                const bool has = m != 0u;
+                const int bit = has ? __builtin_ctz(m) : 0;
                 m &= m - 1u;
-                const int j = w * 32 + bit;
-                const float4 p0 = s_p0[j];
-                const float4 p1 = s_p1[j];
-                const float4 p2 = s_p2[j];
+                return has ? w * 32 + bit : -1;
+            };
+            // software pipeline: the LDS gathers of candidate i+1 are in flight while candidate i is composited
+            int jn = next();
+            float4 q0 = s_p0[max(jn, 0)], q1 = s_p1[max(jn, 0)], q2 = s_p2[max(jn, 0)];
+            while (__ballot(jn >= 0)) {
+                const int j = jn;
+                const bool act = j >= 0 && !done;
+                const float4 p0 = q0, p1 = q1, p2 = q2;
+                jn = next();
+                q0 = s_p0[max(jn, 0)]; q1 = s_p1[max(jn, 0)]; q2 = s_p2[max(jn, 0)];
                 const float dx = p0.x - fx, dy = p0.y - fy;
                 const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
                 const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
@@ -691,21 +698,27 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_lists_kernel(
             };
             int w = 0;
             uint32_t m = load_word(0);
-            while (true) {
+            auto next = [&]() -> int {
                 while (__ballot(m == 0u && w < nw - 1)) {
                     if (m == 0u && w < nw - 1) {
                         ++w;
                         m = load_word(w);
                     }
                 }
-                if (__ballot(m != 0u) == 0) break;
-                const bool act = m != 0u;
-                const int bit = act ? __builtin_ctz(m) : 0;
+                const bool has = m != 0u;
+                const int bit = has ? __builtin_ctz(m) : 0;
                 m &= m - 1u;
-                const int j = w * 32 + bit;
-                const float4 p0 = s_p0[j];
-                const float4 p1 = s_p1[j];
-                const float4 p2 = s_p2[j];
+                return has ? w * 32 + bit : -1;
+            };
+            // software pipeline: gathers of candidate i+1 are in flight while candidate i is replayed
+            int jn = next();
+            float4 q0 = s_p0[max(jn, 0)], q1 = s_p1[max(jn, 0)], q2 = s_p2[max(jn, 0)];
+            while (__ballot(jn >= 0)) {
+                const int j = jn;
+                const bool act = j >= 0;
+                const float4 p0 = q0, p1 = q1, p2 = q2;
+                jn = next();
+                q0 = s_p0[max(jn, 0)]; q1 = s_p1[max(jn, 0)]; q2 = s_p2[max(jn, 0)];
                 const float dx = p0.x - fx, dy = p0.y - fy;
                 const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
                 const float Gv = __expf(power);

@@ -72,7 +72,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
     rec = torch.empty((R * G, _REC), **f32)
     radii = torch.empty((R * G,), **i32)
-    rect = torch.empty((R * G,), **i32)
+    rect = torch.empty((2 * R * G,), **i32)        # packed tile rect | depth key (float bits)
     nblk = lib.spf_raster_view_partial_blocks(G)
     pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
     tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | tile_flags | counters
@@ -110,7 +110,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
-    return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect), _ptr(tiles[:RT]), _ptr(tiles[RT:2 * RT + 1]),
+    return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
+                         _ptr(tiles[RT:2 * RT + 1]),
                          _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:4 * RT + 1]),
                          _ptr(tiles[4 * RT + 1:]), _ptr(pairs),
                          _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
@@ -126,7 +127,9 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
-    if capacity_mode and int(tiles[4 * R * T + 1 + 2]) != 0:
+    # (a device->host read is illegal while a HIP graph is being captured: graph users check the flag themselves
+    # with `pair_buffer_overflowed` after a replay)
+    if capacity_mode and not torch.cuda.is_current_stream_capturing() and int(tiles[4 * R * T + 1 + 2]) != 0:
         raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
                             f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)

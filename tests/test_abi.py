@@ -25,7 +25,7 @@ def test_struct_sizes_match_header():
     from spfsplatv2_amd import _lib
     assert C.sizeof(_lib.SpfDims) == 32
     assert C.sizeof(_lib.SpfInputs) == 11 * 8
-    assert C.sizeof(_lib.SpfState) == 14 * 8
+    assert C.sizeof(_lib.SpfState) == 15 * 8
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
     assert C.sizeof(_lib.SpfGrads) == 13 * 8
 
