@@ -20,7 +20,8 @@
  *                           (cuda_splatting.py:66-74), get_fov (src/geometry/projection.py:269-283),
  *                           get_projection_matrix (cuda_splatting.py:15-42), extrinsics.inverse() and the
  *                           transposes (cuda_splatting.py:84-91), and its autograd backward to the poses.
- *   spf_rope2d              `rope_2d(tokens, positions, base, fwd)`
+ *   spf_rope2d              `rope_2d(tokens, positions, base, fwd)` (and VGGT's RotaryPositionEmbedding2D,
+ *                           src/model/encoder/backbone/vggt/layers/rope.py:62-188, same rotation out of place)
  *                           src/model/encoder/backbone/croco/curope/curope.cpp:49-65 and
  *                           curope/kernels.cu:84-108 (in place, forward and backward).
  *
@@ -54,6 +55,8 @@ extern "C" {
 typedef struct SpfDims {
     int32_t S, V, G, K, sh_degree, H, W;
     float scale_modifier;
+    int32_t sh_layout;   /* 0: shs / dL_dshs are [S,G,K,3] (what the reference hands its rasterizer,
+                            cuda_splatting.py:79); 1: [S,G,3,K] (the encoder's native layout: no transposed copy) */
 } SpfDims;
 
 /* Inputs (all float32, contiguous, row-major). */
@@ -62,7 +65,7 @@ typedef struct SpfInputs {
     const float* scales;     /* [S,G,3] */
     const float* rotations;  /* [S,G,4] quaternion (r,x,y,z), used as given (not normalised) */
     const float* opacities;  /* [S,G]   */
-    const float* shs;        /* [S,G,K,3] or NULL when colors is set */
+    const float* shs;        /* [S,G,K,3] ([S,G,3,K] with sh_layout 1) or NULL when colors is set */
     const float* colors;     /* [S,G,3]  or NULL when shs is set (colors_precomp) */
     const float* viewmatrix; /* [S,V,4,4] world->view, row-vector convention (p_view = [p,1] @ M) */
     const float* projmatrix; /* [S,V,4,4] perspective only, row-vector convention */
@@ -116,7 +119,7 @@ typedef struct SpfGrads {
     float* dL_dscales;        /* [S,G,3]   (NULL when enable_cov_grad is false) */
     float* dL_drotations;     /* [S,G,4]   (NULL when enable_cov_grad is false) */
     float* dL_dopacities;     /* [S,G]   */
-    float* dL_dshs;           /* [S,G,K,3] (NULL when enable_sh_grad is false) */
+    float* dL_dshs;           /* same layout as shs (NULL when enable_sh_grad is false) */
     float* dL_dcolors;        /* [S,G,3]   */
     float* dL_dviewmatrix;    /* [S,V,4,4] */
     float* dL_dmeans2D;       /* [R,G,3]   NDC-scaled screen-space gradient (xy, 0) */
@@ -165,11 +168,13 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
                         const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
 
-/* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n) for the
- * two outer dims, stride(H) == D and stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.
- * positions[B,N,2] int64 contiguous (y, x).  fwd = +F0 for forward, -F0 for backward. */
+/* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n, stride_h) and
+ * stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.  positions[B / pos_div, N, 2] int64 contiguous
+ * (y, x): batch item b uses positions[b / pos_div] (pos_div = 1 for the CroCo layout; a head-major [B,H,N,D] tensor
+ * is passed as B*H batches of one head with pos_div = H).  fwd = +F0 for forward, -F0 for backward. */
 int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
-               int64_t stride_b, int64_t stride_n, int32_t dtype, float base, float fwd, void* stream);
+               int64_t stride_b, int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base,
+               float fwd, void* stream);
 
 /* Per-stage device timing with HIP events recorded on the launch stream around every kernel
  * stage.  spf_stage_timing_enable(mask) clears the log and starts recording the stages whose bit

@@ -20,7 +20,7 @@ STAGE_COUNT = len(STAGE_NAMES)
 class SpfDims(C.Structure):
     _fields_ = [("S", C.c_int32), ("V", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("sh_degree", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("scale_modifier", C.c_float)]
+                ("scale_modifier", C.c_float), ("sh_layout", C.c_int32)]
 
 
 def _ptr_struct(name, fields):
@@ -59,7 +59,8 @@ SYMBOLS = {
     "spf_raster_backward": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
                                       C.POINTER(SpfGrads), C.c_uint64, C.c_uint32, C.c_void_p]),
     "spf_rope2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                             C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p]),
+                             C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                             C.c_void_p]),
     "spf_stage_timing_enable": (C.c_int, [C.c_int32]),
     "spf_stage_times_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "spf_stage_kernel_name": (C.c_char_p, [C.c_int32]),

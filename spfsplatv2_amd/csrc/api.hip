@@ -19,7 +19,8 @@ hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, 
                              hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
-hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int, float, float, hipStream_t);
+hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float, float,
+                         hipStream_t);
 }  // namespace spf
 
 namespace {
@@ -223,16 +224,19 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
 }
 
 int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D, int64_t stride_b,
-               int64_t stride_n, int32_t dtype, float base, float fwd, void* stream_) {
+               int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base, float fwd,
+               void* stream_) {
     if (!tokens || !positions) return fail(SPF_E_INVALID, "tokens / positions is null");
     if (B < 0 || N < 0 || H < 0 || D <= 0) return fail(SPF_E_INVALID, "negative size");
     if (D % 4 != 0) return fail(SPF_E_INVALID, "token dim must be multiple of 4");
     if (D > 256) return fail(SPF_E_INVALID, "token dim > 256 is not supported");
     if (dtype < 0 || dtype > 2) return fail(SPF_E_INVALID, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    if (pos_div < 1) return fail(SPF_E_INVALID, "pos_div must be >= 1");
     if ((size_t)B * N * H == 0) return SPF_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageScope t(SPF_STAGE_ROPE, stream);
-    SPF_HIP(spf::launch_rope2d(tokens, positions, B, N, H, D, stride_b, stride_n, dtype, base, fwd, stream));
+    SPF_HIP(spf::launch_rope2d(tokens, positions, B, N, H, D, stride_b, stride_n, stride_h, pos_div, dtype, base, fwd,
+                               stream));
     return SPF_OK;
 }
 

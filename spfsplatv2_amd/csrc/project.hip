@@ -234,12 +234,13 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
                 sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
                                                      nullptr, nullptr);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;   // [K,3] or [3,K]
                 col[0] = col[1] = col[2] = 0.f;
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
-                    col[0] += basis[k] * sh[3 * k];
-                    col[1] += basis[k] * sh[3 * k + 1];
-                    col[2] += basis[k] * sh[3 * k + 2];
+                    col[0] += basis[k] * sh[sk * k];
+                    col[1] += basis[k] * sh[sk * k + sc];
+                    col[2] += basis[k] * sh[sk * k + 2 * sc];
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -446,14 +447,15 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
                 float basis[NB], dbx[NB], dby[NB], dbz[NB];
                 sh_basis<(DEG < 0 ? 0 : DEG), true>(x, y, z, basis, dbx, dby, dbz);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;   // [K,3] or [3,K]
                 {   // colours clamped at 0 in the forward pass no gradient: re-evaluate the colour exactly as the
                     // forward kernel does (same expression order) instead of re-reading its 48-byte record
                     float col[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < NB; ++k) {
-                        col[0] += basis[k] * sh[3 * k];
-                        col[1] += basis[k] * sh[3 * k + 1];
-                        col[2] += basis[k] * sh[3 * k + 2];
+                        col[0] += basis[k] * sh[sk * k];
+                        col[1] += basis[k] * sh[sk * k + sc];
+                        col[2] += basis[k] * sh[sk * k + 2 * sc];
                     }
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
                     dsh[k][1] += basis[k] * gcol[1];
                     dsh[k][2] += basis[k] * gcol[2];
                     if (DEG > 0) {
-                        const float w = sh[3 * k] * gcol[0] + sh[3 * k + 1] * gcol[1] + sh[3 * k + 2] * gcol[2];
+                        const float w = sh[sk * k] * gcol[0] + sh[sk * k + sc] * gcol[1] + sh[sk * k + 2 * sc] * gcol[2];
                         dd[0] += dbx[k] * w; dd[1] += dby[k] * w; dd[2] += dbz[k] * w;
                     }
                 }
@@ -522,9 +524,10 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
         }
     } else if (gr.dL_dshs) {
         float* __restrict__ o = gr.dL_dshs + sg * (size_t)d.K * 3;
+        const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { o[3 * k] = dsh[k][0]; o[3 * k + 1] = dsh[k][1]; o[3 * k + 2] = dsh[k][2]; }
-        for (int k = NB; k < d.K; ++k) { o[3 * k] = 0.f; o[3 * k + 1] = 0.f; o[3 * k + 2] = 0.f; }
+        for (int k = 0; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
+        for (int k = NB; k < d.K; ++k) { o[sk * k] = 0.f; o[sk * k + sc] = 0.f; o[sk * k + 2 * sc] = 0.f; }
     }
     if (gr.dL_dscales && gr.dL_drotations) {
         // Sigma = Rm diag(s^2) Rm^T.  G = symmetric gradient matrix with G_ij = dL/dSigma_ij (full partials).

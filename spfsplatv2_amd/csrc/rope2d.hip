@@ -70,8 +70,8 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(flo
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ tokens,
                                                                 const int64_t* __restrict__ pos, int N, int H, int D,
-                                                                int64_t stride_b, int64_t stride_n, RopeFreq f,
-                                                                size_t total) {
+                                                                int64_t stride_b, int64_t stride_n, int64_t stride_h, int pos_div,
+                                                                RopeFreq f, size_t total) {
     using V = Vec4<T>;
     const size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (item >= total) return;
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ 
     const int h = rem / per_head, e = rem - h * per_head;
     const int x = e / q4n, q0 = (e - x * q4n) * 4;
     const size_t b = token / N, n = token - b * N;
-    const float p = (float)pos[token * 2 + x];
-    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * D + x * 2 * Q + q0;
+    const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
+    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q0;
     typename V::type uv = *reinterpret_cast<const typename V::type*>(up);
     typename V::type vv = *reinterpret_cast<const typename V::type*>(up + Q);
     float u[4], v[4], uo[4], vo[4];
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict__ tokens,
                                                                    const int64_t* __restrict__ pos, int N, int H,
-                                                                   int D, int64_t stride_b, int64_t stride_n,
-                                                                   RopeFreq f, size_t total) {
+                                                                   int D, int64_t stride_b, int64_t stride_n, int64_t stride_h,
+                                                                   int pos_div, RopeFreq f, size_t total) {
     const size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (item >= total) return;
     const int Q = D >> 2, per_head = 2 * Q;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict
     const int h = rem / per_head, e = rem - h * per_head;
     const int x = e / Q, q = e - x * Q;
     const size_t b = token / N, n = token - b * N;
-    const float p = (float)pos[token * 2 + x];
-    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * D + x * 2 * Q + q;
+    const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
+    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q;
     const float u = to_f<T>(up[0]), v = to_f<T>(up[Q]);
     float s, c;
     sincosf(p * f.inv[q], &s, &c);
@@ -126,32 +126,32 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict
 
 template <typename T>
 static hipError_t launch_rope_t(void* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
-                                const RopeFreq& f, hipStream_t stream) {
+                                int64_t sh, int pos_div, const RopeFreq& f, hipStream_t stream) {
     const int Q = D / 4;
     const size_t align = 4 * sizeof(T);
     const bool vec = (Q % 4 == 0) && (reinterpret_cast<uintptr_t>(tokens) % align == 0) && (sb % 4 == 0) &&
-                     (sn % 4 == 0);
+                     (sn % 4 == 0) && (sh % 4 == 0);
     if (vec) {
         const size_t total = (size_t)B * N * H * (D / 8);
         spf_rope2d_vec_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            static_cast<T*>(tokens), pos, N, H, D, sb, sn, f, total);
+            static_cast<T*>(tokens), pos, N, H, D, sb, sn, sh, pos_div, f, total);
     } else {
         const size_t total = (size_t)B * N * H * 2 * Q;
         spf_rope2d_scalar_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            static_cast<T*>(tokens), pos, N, H, D, sb, sn, f, total);
+            static_cast<T*>(tokens), pos, N, H, D, sb, sn, sh, pos_div, f, total);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_rope2d(void* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
-                         int dtype, float base, float fwd, hipStream_t stream) {
+                         int64_t sh, int pos_div, int dtype, float base, float fwd, hipStream_t stream) {
     RopeFreq f;
     const int Q = D / 4;
     for (int q = 0; q < 64; ++q) f.inv[q] = q < Q ? fwd / powf(base, q / float(Q)) : 0.f;
     switch (dtype) {
-        case 0: return launch_rope_t<float>(tokens, pos, B, N, H, D, sb, sn, f, stream);
-        case 1: return launch_rope_t<__half>(tokens, pos, B, N, H, D, sb, sn, f, stream);
-        default: return launch_rope_t<__hip_bfloat16>(tokens, pos, B, N, H, D, sb, sn, f, stream);
+        case 0: return launch_rope_t<float>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        case 1: return launch_rope_t<__half>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        default: return launch_rope_t<__hip_bfloat16>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
     }
 }
 

@@ -111,11 +111,13 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     h, w = image_shape
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
-    shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()   # [b,g,d_sh,3]
+    # SH stays in the encoder's [b,g,3,d_sh] layout: the kernels index it directly (no transposed copy as at
+    # cuda_splatting.py:79); colours-only mode takes the DC coefficient as the colour (cuda_splatting.py:132)
     color, depth, alpha, _radii = render_batch(
         extrinsics, intrinsics, near, far, gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
-        shs if use_sh else None, None if use_sh else shs[:, :, 0, :], background_color, h, w, degree,
-        scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs)
+        gaussian_sh_coefficients if use_sh else None, None if use_sh else gaussian_sh_coefficients[..., 0],
+        background_color, h, w, degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs,
+        sh_layout="g3k")
     return color, depth, alpha
 
 

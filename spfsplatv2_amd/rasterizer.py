@@ -56,15 +56,15 @@ def _stream_ptr(device) -> C.c_void_p:
 
 
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
-                  view_scale, H, W, sh_degree, scale_modifier, max_pairs):
+                  view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0):
     """Launch the forward chain.  Returns (outputs, saved state tensors)."""
     lib = _lib.load()
     S, G, _ = means3D.shape
     V = viewmatrix.shape[1]
     R = S * V
     dev = means3D.device
-    K = 0 if shs is None else shs.shape[2]
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier))
+    K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout))
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
     i32 = dict(dtype=torch.int32, device=dev)
@@ -123,7 +123,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
-    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense = geom
+    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense, sh_layout = geom
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
@@ -132,7 +132,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     if capacity_mode and not torch.cuda.is_current_stream_capturing() and int(tiles[4 * R * T + 1 + 2]) != 0:
         raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
                             f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier)
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout))
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
@@ -169,7 +169,7 @@ class _RasterizeBatch(torch.autograd.Function):
                                            max_pairs)
         S, G, _ = means3D.shape
         ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
-                    float(scale_modifier), max_pairs is not None, dense)
+                    float(scale_modifier), max_pairs is not None, dense, 0)
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
@@ -198,7 +198,7 @@ class _DecoderRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
-                H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs):
+                H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         S, V = extrinsics.shape[:2]
@@ -212,9 +212,10 @@ class _DecoderRender(torch.autograd.Function):
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
         _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
-                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs)
+                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout)
         G = means3D.shape[1]
-        ctx.geom = (S, V, G, 0 if shs is None else shs.shape[2], sh_degree, H, W, 1.0, max_pairs is not None, dense)
+        K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
+        ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, max_pairs is not None, dense, int(sh_layout))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
                               *state, near)
@@ -240,7 +241,7 @@ class _DecoderRender(torch.autograd.Function):
             _lib.check(lib.spf_camera_backward(C.byref(cam), _ptr(d_view), _ptr(d_ext), _stream_ptr(view.device)),
                        "spf_camera_backward")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
@@ -265,11 +266,13 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
                  shs: Optional[Tensor], colors_precomp: Optional[Tensor], bg: Tensor,
                  image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
-                 enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs: Optional[int] = None):
+                 enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs: Optional[int] = None,
+                 sh_layout: str = "gk3"):
     """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
 
     extrinsics [S,V,4,4] camera-to-world, intrinsics [S,V,3,3] normalised, near/far [S,V]; Gaussians as in
-    ``rasterize_batch``.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units), alpha [S,V,1,H,W],
+    ``rasterize_batch``; ``sh_layout="g3k"`` takes ``shs`` as [S,G,3,K] -- the encoder's native layout
+    (``Gaussians.harmonics``), so the transposed copy at cuda_splatting.py:79 never happens.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units), alpha [S,V,1,H,W],
     radii [S,V,G]."""
     if (shs is None) == (colors_precomp is None):
         raise RuntimeError("provide exactly one of shs / colors_precomp")
@@ -283,11 +286,14 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     scales = _f32c(scales, "scales", (S, G, 3))
     rotations = _f32c(rotations, "rotations", (S, G, 4))
     opacities = _f32c(opacities.reshape(S, G), "opacities", (S, G))
+    if sh_layout not in ("gk3", "g3k"):
+        raise RuntimeError(f"sh_layout must be 'gk3' or 'g3k', got {sh_layout!r}")
+    native = sh_layout == "g3k"
     if shs is not None:
-        K = shs.shape[2]
+        K = shs.shape[3 if native else 2]
         if K < (min(sh_degree, 3) + 1) ** 2:
             raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
-        shs = _f32c(shs, "shs", (S, G, K, 3))
+        shs = _f32c(shs, "shs", (S, G, 3, K) if native else (S, G, K, 3))
     else:
         colors_precomp = _f32c(colors_precomp, "colors_precomp", (S, G, 3))
     if bg.dim() == 1:
@@ -295,7 +301,7 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     bg = _f32c(bg, "bg", (S, V, 3))
     return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
-                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs)
+                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0)
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,

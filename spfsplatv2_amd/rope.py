@@ -52,11 +52,33 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
         raise RuntimeError("token dim must be multiple of 4")
     if tokens.dtype not in _DTYPES:
         raise RuntimeError(f"rope_2d: unsupported dtype {tokens.dtype}")
+    _launch(tokens, positions, B, N, H, D, tokens.stride(0), tokens.stride(1), D, 1, base, fwd)
+
+
+def _launch(tokens, positions, B, N, H, D, sb, sn, sh, pos_div, base, fwd) -> None:
     lib = _lib.load()
     stream = C.c_void_p(torch.cuda.current_stream(tokens.device).cuda_stream)
-    _lib.check(lib.spf_rope2d(C.c_void_p(tokens.data_ptr()), C.c_void_p(positions.data_ptr()), B, N, H, D,
-                              tokens.stride(0), tokens.stride(1), _DTYPES[tokens.dtype], float(base), float(fwd),
-                              stream), "spf_rope2d")
+    _lib.check(lib.spf_rope2d(C.c_void_p(tokens.data_ptr()), C.c_void_p(positions.data_ptr()), B, N, H, D, sb, sn, sh,
+                              pos_div, _DTYPES[tokens.dtype], float(base), float(fwd), stream), "spf_rope2d")
+
+
+def rope_2d_head_major(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """In-place RoPE-2D on a CONTIGUOUS head-major tensor [B,H,N,D] (VGGT's layout): every (batch, head) slab is
+    one batch item of one head that shares batch b's positions."""
+    if tokens.dim() != 4 or not tokens.is_contiguous():
+        raise RuntimeError("tokens must be a contiguous [B,H,N,D] tensor")
+    if positions.dim() != 3 or positions.shape[-1] != 2 or positions.shape[0] != tokens.shape[0] or \
+            positions.shape[1] != tokens.shape[2]:
+        raise RuntimeError("Positions must have shape (batch_size, n_tokens, 2)")
+    if not tokens.is_cuda or not positions.is_cuda:
+        raise RuntimeError("rope_2d: tensors are on the CPU; this build only runs on a HIP device (no CPU fallback)")
+    B, H, N, D = tokens.shape
+    if D % 4 != 0:
+        raise RuntimeError("token dim must be multiple of 4")
+    if tokens.dtype not in _DTYPES:
+        raise RuntimeError(f"rope_2d: unsupported dtype {tokens.dtype}")
+    positions = positions.to(torch.int64).contiguous()
+    _launch(tokens, positions, B * H, N, 1, D, N * D, D, D, H, base, fwd)
 
 
 class cuRoPE2D_func(torch.autograd.Function):
@@ -92,3 +114,38 @@ class cuRoPE2D(torch.nn.Module):
 
 
 RoPE2D = cuRoPE2D
+
+
+class _RoPE2DHeadMajor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, positions, base):
+        out = tokens.contiguous().clone()
+        rope_2d_head_major(out, positions, base, 1.0)
+        ctx.save_for_backward(positions)
+        ctx.base = base
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        g = grad.contiguous().clone()
+        rope_2d_head_major(g, ctx.saved_tensors[0], ctx.base, -1.0)
+        return g, None, None
+
+
+class RotaryPositionEmbedding2D(torch.nn.Module):
+    """Drop-in for VGGT's ``RotaryPositionEmbedding2D``
+    (/root/reference/src/model/encoder/backbone/vggt/layers/rope.py:62-188): out-of-place, tokens [B,H,N,D],
+    positions [B,N,2] (y, x).  Same rotation as curope (first half of D by y, second by x, pairs (t[q], t[q+D/4]),
+    angle = pos / frequency^(q/(D/4))); the reference's version costs two embedding gathers, two concatenations
+    and a host sync (``int(positions.max())``, rope.py:174) per call -- here it is one kernel.  ``scaling_factor`` is
+    accepted and unused, as in the reference."""
+
+    def __init__(self, frequency: float = 100.0, scaling_factor: float = 1.0):
+        super().__init__()
+        self.base_frequency = frequency
+        self.scaling_factor = scaling_factor
+
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        assert tokens.size(-1) % 2 == 0, "Feature dimension must be even"
+        assert positions.ndim == 3 and positions.shape[-1] == 2, "Positions must have shape (batch_size, n_tokens, 2)"
+        return _RoPE2DHeadMajor.apply(tokens, positions, float(self.base_frequency))

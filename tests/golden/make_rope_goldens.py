@@ -77,7 +77,18 @@ def main():
             entry["roundtrip_cpp_maxerr"] = float((t - tok.transpose(1, 2)).abs().max())
             print(name, "max|fallback - cpp| =", (out_py.transpose(1, 2) - entry["out_cpp_BNHD"]).abs().max().item())
         cases[name] = entry
-    torch.save({"cases": cases, "has_cpp": cpp is not None}, HERE / "rope_goldens.pt")
+    # VGGT's RotaryPositionEmbedding2D (vggt/layers/rope.py:62-188): out of place, head-major [B,H,N,D]
+    spec = importlib.util.spec_from_file_location("ref_vggt_rope", REF.parent / "vggt" / "layers" / "rope.py")
+    vm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vm)
+    vggt = {}
+    for name, (B, H, hh, ww, D) in {"vggt_2x4_37x64": (2, 4, 6, 6, 64), "vggt_1x16_50x128": (1, 16, 5, 10, 128)}.items():
+        pos = vm.PositionGetter()(B, hh, ww, torch.device("cpu")) + 1          # VGGT offsets patch positions by 1 ...
+        pos = torch.cat([torch.zeros(B, 1, 2, dtype=pos.dtype), pos], dim=1)     # ... and gives special tokens (0, 0)
+        tok = torch.randn(B, H, pos.shape[1], D, generator=gen)
+        out = vm.RotaryPositionEmbedding2D(frequency=100.0)(tok, pos)
+        vggt[name] = {"tokens_BHND": tok, "positions": pos, "frequency": 100.0, "out_BHND": out}
+    torch.save({"cases": cases, "has_cpp": cpp is not None, "vggt": vggt}, HERE / "rope_goldens.pt")
     print("wrote", HERE / "rope_goldens.pt", "cpp:", cpp is not None)
 
 

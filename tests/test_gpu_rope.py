@@ -77,3 +77,19 @@ def test_error_behaviour(hip_lib):
         spf.rope_2d(t, torch.zeros(2, 4, 4, dtype=torch.int64, device="cuda")[..., :2], 100.0, 1.0)
     with pytest.raises(RuntimeError, match="multiple of 4"):
         spf.rope_2d(torch.zeros(2, 4, 3, 6, device="cuda"), p, 100.0, 1.0)
+
+
+def test_vggt_rotary_embedding_dropin(hip_lib, goldens):
+    """RotaryPositionEmbedding2D (vggt/layers/rope.py:62-188): out of place, head-major, vs the reference's output."""
+    import spfsplatv2_amd as spf
+    for name, c in goldens["vggt"].items():
+        tok = c["tokens_BHND"].cuda().requires_grad_(True)
+        out = spf.RotaryPositionEmbedding2D(frequency=c["frequency"])(tok, c["positions"].cuda())
+        assert out is not tok and out.shape == tok.shape
+        assert float((out.detach().cpu() - c["out_BHND"]).abs().max()) <= TOL, name
+        assert torch.equal(tok.detach().cpu(), c["tokens_BHND"])                 # input untouched
+        w = torch.randn(tok.shape, generator=torch.Generator().manual_seed(4))
+        (out * w.cuda()).sum().backward()
+        B, H, N, D = tok.shape
+        want = util.rope_oracle(w.transpose(1, 2).contiguous(), c["positions"], c["frequency"], -1.0).transpose(1, 2)
+        assert float((tok.grad.cpu() - want).abs().max()) <= TOL, name

@@ -46,3 +46,11 @@ def test_oracle_inverse_and_strides():
     zero = util.rope_oracle(view, torch.zeros_like(pos), 100.0, 1.0)
     assert torch.equal(zero, view.contiguous())
     assert float((fwd.pow(2).sum(-1) - view.pow(2).sum(-1)).abs().max()) < 1e-4
+
+
+def test_oracle_matches_vggt_reference_rope(goldens):
+    """VGGT's RotaryPositionEmbedding2D (vggt/layers/rope.py:62-188) is the same rotation, out of place."""
+    for name, c in goldens["vggt"].items():
+        tok = c["tokens_BHND"].transpose(1, 2).contiguous()
+        got = util.rope_oracle(tok, c["positions"], c["frequency"], 1.0).transpose(1, 2)
+        assert float((got - c["out_BHND"]).abs().max()) <= 1e-5, name
