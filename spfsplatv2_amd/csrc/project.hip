@@ -144,10 +144,47 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* __res
     }
 }
 
+// SH coefficient block of one Gaussian: K coefficients per channel, stored [K,3] (layout 0) or [3,K] (layout 1).
+// Coefficients are consumed four at a time through three 16-byte loads (any layout) when K % 4 == 0; otherwise
+// one by one.  v[i][c] = coefficient 4*k4+i of channel c.
+template <bool NATIVE>
+__device__ __forceinline__ void sh_load4(const float* __restrict__ sh, int K, int k4, float v[4][3]) {
+    if (NATIVE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 t = *reinterpret_cast<const float4*>(sh + c * K + 4 * k4);
+            v[0][c] = t.x; v[1][c] = t.y; v[2][c] = t.z; v[3][c] = t.w;
+        }
+    } else {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(sh + 12 * k4);
+        const float4 a = p[0], b = p[1], c = p[2];
+        v[0][0] = a.x; v[0][1] = a.y; v[0][2] = a.z; v[1][0] = a.w;
+        v[1][1] = b.x; v[1][2] = b.y; v[2][0] = b.z; v[2][1] = b.w;
+        v[2][2] = c.x; v[3][0] = c.y; v[3][1] = c.z; v[3][2] = c.w;
+    }
+}
+template <bool NATIVE>
+__device__ __forceinline__ void sh_store4(float* __restrict__ sh, int K, int k4, const float v[4][3]) {
+    if (NATIVE) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(sh + c * K + 4 * k4) = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+    } else {
+        float4* __restrict__ p = reinterpret_cast<float4*>(sh + 12 * k4);
+        p[0] = make_float4(v[0][0], v[0][1], v[0][2], v[1][0]);
+        p[1] = make_float4(v[1][1], v[1][2], v[2][0], v[2][1]);
+        p[2] = make_float4(v[2][2], v[3][0], v[3][1], v[3][2]);
+    }
+}
+template <bool NATIVE>
+__device__ __forceinline__ float sh_at(const float* __restrict__ sh, int K, int k, int c) {
+    return NATIVE ? sh[c * K + k] : sh[3 * k + c];
+}
+
 // ------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(G/256), S), block = 256.  DEG = -1: colours given (colors_precomp).
 // ------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // Per-tile counts are first accumulated in an LDS histogram of the block's render (T counters) and
@@ -234,13 +271,26 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
                 sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
                                                      nullptr, nullptr);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
-                const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;   // [K,3] or [3,K]
                 col[0] = col[1] = col[2] = 0.f;
+                if (NB % 4 == 0 && d.K % 4 == 0) {
 #pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    col[0] += basis[k] * sh[sk * k];
-                    col[1] += basis[k] * sh[sk * k + sc];
-                    col[2] += basis[k] * sh[sk * k + 2 * sc];
+                    for (int k4 = 0; k4 < NB / 4; ++k4) {
+                        float v[4][3];
+                        sh_load4<NATIVE>(sh, d.K, k4, v);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            col[0] += basis[4 * k4 + i] * v[i][0];
+                            col[1] += basis[4 * k4 + i] * v[i][1];
+                            col[2] += basis[4 * k4 + i] * v[i][2];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        col[0] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 0);
+                        col[1] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 1);
+                        col[2] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 2);
+                    }
                 }
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -301,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
 // Backward.  Same decomposition; per-view viewmatrix partials are reduced per block into
 // vpartial[r][block][12] (no float atomics -> deterministic), summed by spf_view_reduce_kernel.
 // ------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk) {
     const int g = blockIdx.x * kBlock + threadIdx.x;
@@ -447,31 +497,47 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
                 float basis[NB], dbx[NB], dby[NB], dbz[NB];
                 sh_basis<(DEG < 0 ? 0 : DEG), true>(x, y, z, basis, dbx, dby, dbz);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
-                const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;   // [K,3] or [3,K]
-                {   // colours clamped at 0 in the forward pass no gradient: re-evaluate the colour exactly as the
-                    // forward kernel does (same expression order) instead of re-reading its 48-byte record
-                    float col[3] = {0.f, 0.f, 0.f};
+                // One pass over the coefficient block: re-evaluate the colour exactly as the forward kernel does
+                // (colours clamped at 0 pass no gradient; cheaper than re-reading the 48-byte record) and collect
+                // s_k = sh_k . dL/dcolour for the direction gradient.
+                float col[3] = {0.f, 0.f, 0.f};
+                float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};  // sum_k dbasis_k sh_k[c]
+                if (NB % 4 == 0 && d.K % 4 == 0) {
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        col[0] += basis[k] * sh[sk * k];
-                        col[1] += basis[k] * sh[sk * k + sc];
-                        col[2] += basis[k] * sh[sk * k + 2 * sc];
+                    for (int k4 = 0; k4 < NB / 4; ++k4) {
+                        float v[4][3];
+                        sh_load4<NATIVE>(sh, d.K, k4, v);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const int k = 4 * k4 + i;
+                                col[c] += basis[k] * v[i][c];
+                                if (DEG > 0) { Dx[c] += dbx[k] * v[i][c]; Dy[c] += dby[k] * v[i][c]; Dz[c] += dbz[k] * v[i][c]; }
+                            }
                     }
+                } else {
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch)
-                        if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
+                    for (int k = 0; k < NB; ++k)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float v = sh_at<NATIVE>(sh, d.K, k, c);
+                            col[c] += basis[k] * v;
+                            if (DEG > 0) { Dx[c] += dbx[k] * v; Dy[c] += dby[k] * v; Dz[c] += dbz[k] * v; }
+                        }
                 }
-                float dd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     dsh[k][0] += basis[k] * gcol[0];
                     dsh[k][1] += basis[k] * gcol[1];
                     dsh[k][2] += basis[k] * gcol[2];
-                    if (DEG > 0) {
-                        const float w = sh[sk * k] * gcol[0] + sh[sk * k + sc] * gcol[1] + sh[sk * k + 2 * sc] * gcol[2];
-                        dd[0] += dbx[k] * w; dd[1] += dby[k] * w; dd[2] += dbz[k] * w;
-                    }
                 }
+                const float dd[3] = {Dx[0] * gcol[0] + Dx[1] * gcol[1] + Dx[2] * gcol[2],
+                                     Dy[0] * gcol[0] + Dy[1] * gcol[1] + Dy[2] * gcol[2],
+                                     Dz[0] * gcol[0] + Dz[1] * gcol[1] + Dz[2] * gcol[2]};
                 if (DEG > 0) {
                     const float dot = dd[0] * x + dd[1] * y + dd[2] * z;
                     float dv[3] = {(dd[0] - x * dot) * inv, (dd[1] - y * dot) * inv, (dd[2] - z * dot) * inv};
@@ -524,9 +590,14 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
         }
     } else if (gr.dL_dshs) {
         float* __restrict__ o = gr.dL_dshs + sg * (size_t)d.K * 3;
-        const int sk = d.sh_layout ? 1 : 3, sc = d.sh_layout ? d.K : 1;
+        const int sk = NATIVE ? 1 : 3, sc = NATIVE ? d.K : 1;
+        if (NB % 4 == 0 && d.K % 4 == 0) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
+            for (int k4 = 0; k4 < NB / 4; ++k4) sh_store4<NATIVE>(o, d.K, k4, &dsh[4 * k4]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
+        }
         for (int k = NB; k < d.K; ++k) { o[sk * k] = 0.f; o[sk * k + sc] = 0.f; o[sk * k + 2 * sc] = 0.f; }
     }
     if (gr.dL_dscales && gr.dL_drotations) {
@@ -591,34 +662,47 @@ __global__ void spf_view_reduce_kernel(const float* __restrict__ vpartial, float
 }
 
 // ---- host-side launchers (called from api.hip) ---------------------------------------------
+template <int DEG, bool NATIVE>
+static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDims& d, const SpfInputs& in,
+                          const SpfState& st, int tiles_x, int tiles_y, int lds) {
+    spf_project_fwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds);
+}
+template <int DEG, bool NATIVE>
+static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
+                          const SpfGrads& g, int nblk) {
+    spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), 0, stream>>>(d, in, st, g, nblk);
+}
+#define SPF_DISPATCH_DEG(FN, ...)                                        \
+    switch (deg * 2 + (native ? 1 : 0)) {                                \
+        case -2: case -1: FN<-1, false>(__VA_ARGS__); break;             \
+        case 0: FN<0, false>(__VA_ARGS__); break;                        \
+        case 1: FN<0, true>(__VA_ARGS__); break;                         \
+        case 2: FN<1, false>(__VA_ARGS__); break;                        \
+        case 3: FN<1, true>(__VA_ARGS__); break;                         \
+        case 4: FN<2, false>(__VA_ARGS__); break;                        \
+        case 5: FN<2, true>(__VA_ARGS__); break;                         \
+        case 6: FN<3, false>(__VA_ARGS__); break;                        \
+        default: FN<3, true>(__VA_ARGS__); break;                        \
+    }
+
 hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, int tiles_x, int tiles_y,
                               hipStream_t stream) {
-    dim3 grid((d.G + kBlock - 1) / kBlock, d.S), block(kBlock);
+    dim3 grid((d.G + kBlock - 1) / kBlock, d.S);
     const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
     const size_t sm = lds ? 2 * sizeof(uint32_t) * T : 0;
-    switch (deg) {
-        case -1: spf_project_fwd_kernel<-1><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
-        case 0: spf_project_fwd_kernel<0><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
-        case 1: spf_project_fwd_kernel<1><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
-        case 2: spf_project_fwd_kernel<2><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
-        default: spf_project_fwd_kernel<3><<<grid, block, sm, stream>>>(d, in, st, tiles_x, tiles_y, lds); break;
-    }
+    SPF_DISPATCH_DEG(project_fwd_t, grid, sm, stream, d, in, st, tiles_x, tiles_y, lds)
     return hipGetLastError();
 }
 
 hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
                               int nblk, hipStream_t stream) {
-    dim3 grid(nblk, d.S), block(kBlock);
+    dim3 grid(nblk, d.S);
     const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
-    switch (deg) {
-        case -1: spf_project_bwd_kernel<-1><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
-        case 0: spf_project_bwd_kernel<0><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
-        case 1: spf_project_bwd_kernel<1><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
-        case 2: spf_project_bwd_kernel<2><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
-        default: spf_project_bwd_kernel<3><<<grid, block, 0, stream>>>(d, in, st, g, nblk); break;
-    }
+    const bool native = d.sh_layout != 0;
+    SPF_DISPATCH_DEG(project_bwd_t, grid, stream, d, in, st, g, nblk)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (g.dL_dviewmatrix) {
@@ -627,5 +711,6 @@ hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     }
     return e;
 }
+#undef SPF_DISPATCH_DEG
 
 }  // namespace spf
