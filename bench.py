@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-free", action="store_true", help="fixed pair-buffer capacity, no per-step read-back")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
+                         "single-GPU box together with --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--graph", action="store_true",
                     help="capture one whole step (decoder fwd + loss + bwd) in a HIP graph and replay it "
                          "(implies --sync-free)")
@@ -116,10 +120,15 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
