@@ -268,8 +268,12 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                 with torch.no_grad():
                     rel = 2e-4
                     near_alpha = ((alpha - ALPHA_MIN).abs() < rel * ALPHA_MIN) & (power <= 0)
-                    near_pow = power.abs() < 1e-6
-                    near_T = valid & ((incl - T_MIN).abs() < 1e-2 * T_MIN) & ~stopped
+                    # power > 0 (skipped) vs <= 0 can only flip where the three terms cancel to rounding level
+                    mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) \
+                        + (con[None, :, 1] * dx * dy).abs()
+                    near_pow = power.abs() <= 1e-5 * mag
+                    # a float32 running product over <= a few thousand factors drifts by ~1e-5..1e-4 relative
+                    near_T = valid & ((incl - T_MIN).abs() < 1e-3 * T_MIN) & ~stopped
                     frag = (near_alpha | near_pow | near_T).any(dim=1)
             else:
                 frag = torch.zeros(n_pix, dtype=torch.bool)
@@ -301,15 +305,38 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
                  projmatrix, tanfovx, tanfovy, H, W, sh_degree, scale_modifier)
     out = composite(pr, bg, H, W, want_fragile=want_fragile)
     if want_fragile:
-        # Gaussians whose integer footprint is decided by a rounding knife-edge taint their tiles.
+        # Tile membership decided by a rounding knife-edge (footprint radius within 1e-4 of an integer, or a rect
+        # bound within ~1e-3 px of a tile border): only the tiles whose membership would actually change are
+        # tainted, i.e. the difference between the largest and the smallest plausible rect.
         with torch.no_grad():
-            frac = pr.radius_raw - torch.floor(pr.radius_raw)
-            edge = (pr.radii > 0) & ((frac < 1e-4) | (frac > 1 - 1e-4))
             fr = out[3].clone()
-            for g in torch.nonzero(edge).flatten().tolist():
-                x0, y0 = pr.rect_min[g].tolist()
-                x1, y1 = pr.rect_max[g].tolist()
-                fr[max(0, y0 - 1) * TILE:(y1 + 1) * TILE, max(0, x0 - 1) * TILE:(x1 + 1) * TILE] = True
+            gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+            px, py = pr.xy[:, 0].double(), pr.xy[:, 1].double()
+            raw = pr.radius_raw.double()
+            eps = 1e-3 * (1.0 + px.abs().clamp(max=1e6) * 1e-4)
+
+            def rect(pxx, pyy, rad):
+                x0 = torch.trunc((pxx - rad) / TILE).clamp(0, gx); y0 = torch.trunc((pyy - rad) / TILE).clamp(0, gy)
+                x1 = torch.trunc((pxx + rad + TILE - 1) / TILE).clamp(0, gx)
+                y1 = torch.trunc((pyy + rad + TILE - 1) / TILE).clamp(0, gy)
+                return x0, y0, x1, y1
+
+            r_lo, r_hi = torch.ceil(raw * (1 - 1e-5) - 1e-4), torch.ceil(raw * (1 + 1e-5) + 1e-4)
+            # union box: smallest mins / largest maxes; intersection box: the opposite
+            ux0, uy0, _, _ = rect(px - eps, py - eps, r_hi)
+            _, _, ux1, uy1 = rect(px + eps, py + eps, r_hi)
+            ix0, iy0, _, _ = rect(px + eps, py + eps, r_lo)
+            _, _, ix1, iy1 = rect(px - eps, py - eps, r_lo)
+            vis = (pr.radii > 0) | ((ux1 > ux0) & (uy1 > uy0) & (pr.depth.detach() > NEAR_CULL))
+            amb = vis & ((ux0 != ix0) | (uy0 != iy0) | (ux1 != ix1) | (uy1 != iy1))
+            for g in torch.nonzero(amb).flatten().tolist():
+                a0, b0, a1, b1 = int(ux0[g]), int(uy0[g]), int(ux1[g]), int(uy1[g])
+                c0, d0, c1, d1 = int(ix0[g]), int(iy0[g]), int(ix1[g]), int(iy1[g])
+                box = torch.zeros(gy, gx, dtype=torch.bool)
+                box[b0:b1, a0:a1] = True
+                if c1 > c0 and d1 > d0:
+                    box[d0:d1, c0:c1] = False
+                fr |= box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W]
         return out[0], out[1], out[2], pr.radii, fr
     return out[0], out[1], out[2], pr.radii
 

@@ -55,6 +55,19 @@ def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _on_device_of_first_arg(fn):
+    """HIP launches go to the CURRENT device: make the tensors' device current for the duration of the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(first, *a, **kw):
+        t = first[0] if isinstance(first, (tuple, list)) else first
+        with torch.cuda.device(t.device):
+            return fn(first, *a, **kw)
+    return wrapped
+
+
+@_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                   view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0):
     """Launch the forward chain.  Returns (outputs, saved state tensors)."""
@@ -118,6 +131,7 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(final_T), _ptr(n_contrib))
 
 
+@_on_device_of_first_arg
 def _backward_impl(inputs, state, geom, grads_out, want):
     """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
     lib = _lib.load()
@@ -210,7 +224,8 @@ class _DecoderRender(torch.autograd.Function):
         vscale = torch.empty((S, V), **f32) if scale_invariant else None
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
-        _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
+        with torch.cuda.device(dev):
+            _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
                                            bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout)
         G = means3D.shape[1]
@@ -238,8 +253,9 @@ class _DecoderRender(torch.autograd.Function):
             d_ext = torch.empty_like(view)
             cam = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(view), None, None, None,
                                  view.shape[0] * view.shape[1], 1 if scale_invariant else 0)
-            _lib.check(lib.spf_camera_backward(C.byref(cam), _ptr(d_view), _ptr(d_ext), _stream_ptr(view.device)),
-                       "spf_camera_backward")
+            with torch.cuda.device(view.device):
+                _lib.check(lib.spf_camera_backward(C.byref(cam), _ptr(d_view), _ptr(d_ext),
+                                                   _stream_ptr(view.device)), "spf_camera_backward")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
                 None, None, None, None, None, None, None, None)
 
@@ -258,7 +274,8 @@ def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Te
     tanfov, vscale = torch.empty((S, V, 2), **f32), torch.empty((S, V), **f32)
     cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                          _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
-    _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(extrinsics.device)), "spf_camera_forward")
+    with torch.cuda.device(extrinsics.device):
+        _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(extrinsics.device)), "spf_camera_forward")
     return view, proj, tanfov, vscale
 
 

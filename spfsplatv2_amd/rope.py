@@ -57,9 +57,10 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
 
 def _launch(tokens, positions, B, N, H, D, sb, sn, sh, pos_div, base, fwd) -> None:
     lib = _lib.load()
-    stream = C.c_void_p(torch.cuda.current_stream(tokens.device).cuda_stream)
-    _lib.check(lib.spf_rope2d(C.c_void_p(tokens.data_ptr()), C.c_void_p(positions.data_ptr()), B, N, H, D, sb, sn, sh,
-                              pos_div, _DTYPES[tokens.dtype], float(base), float(fwd), stream), "spf_rope2d")
+    with torch.cuda.device(tokens.device):      # HIP launches go to the current device
+        stream = C.c_void_p(torch.cuda.current_stream(tokens.device).cuda_stream)
+        _lib.check(lib.spf_rope2d(C.c_void_p(tokens.data_ptr()), C.c_void_p(positions.data_ptr()), B, N, H, D, sb, sn,
+                                  sh, pos_div, _DTYPES[tokens.dtype], float(base), float(fwd), stream), "spf_rope2d")
 
 
 def rope_2d_head_major(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
