@@ -306,14 +306,14 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
     out = composite(pr, bg, H, W, want_fragile=want_fragile)
     if want_fragile:
         # Tile membership decided by a rounding knife-edge (footprint radius within 1e-4 of an integer, or a rect
-        # bound within ~1e-3 px of a tile border): only the tiles whose membership would actually change are
+        # bound within ~1e-4 px of a tile border): only the tiles whose membership would actually change are
         # tainted, i.e. the difference between the largest and the smallest plausible rect.
         with torch.no_grad():
             fr = out[3].clone()
             gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
             px, py = pr.xy[:, 0].double(), pr.xy[:, 1].double()
             raw = pr.radius_raw.double()
-            eps = 1e-3 * (1.0 + px.abs().clamp(max=1e6) * 1e-4)
+            eps = 1e-4 + 2e-6 * px.abs().clamp(max=1e6)     # float32 pixel centres are good to ~1e-6 relative
 
             def rect(pxx, pyy, rad):
                 x0 = torch.trunc((pxx - rad) / TILE).clamp(0, gx); y0 = torch.trunc((pyy - rad) / TILE).clamp(0, gy)
@@ -336,7 +336,14 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
                 box[b0:b1, a0:a1] = True
                 if c1 > c0 and d1 > d0:
                     box[d0:d1, c0:c1] = False
-                fr |= box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W]
+                # ... and inside those tiles only the pixels the Gaussian can reach (its 3-sigma box, padded)
+                reach = torch.zeros(H, W, dtype=torch.bool)
+                rr = float(r_hi[g]) + 2.0
+                y0p, y1p = max(0, int(py[g] - rr)), min(H, int(py[g] + rr) + 2)
+                x0p, x1p = max(0, int(px[g] - rr)), min(W, int(px[g] + rr) + 2)
+                if y1p > y0p and x1p > x0p:
+                    reach[y0p:y1p, x0p:x1p] = True
+                fr |= box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W] & reach
         return out[0], out[1], out[2], pr.radii, fr
     return out[0], out[1], out[2], pr.radii
 
