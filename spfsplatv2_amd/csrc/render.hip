@@ -561,19 +561,20 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 //            and writes the pair's 48-byte record.
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPool = 2048;   // (w, u) slots per round: 16 KB
+constexpr int kPool = 1536;    // (w, u) slots per round: 12 KB
+constexpr int kRoundL = 192;  // candidate entries per round (6 mask words); LDS total ~31 KB -> 5 blocks per CU
 
 template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock) void spf_render_bwd_lists_kernel(
+__global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
     float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr) {
-    __shared__ float4 s_p0[kStage];                 // x, y, A, B
-    __shared__ float4 s_p1[kStage];                 // C, opacity, cull r^2, depth
-    __shared__ float4 s_p2[kStage];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
-    __shared__ uint32_t s_pm[kStage / 32][kBlock];  // [32-entry word][pixel]: candidate bits
+    __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
+    __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
+    __shared__ float4 s_p2[kRoundL];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
+    __shared__ uint32_t s_pm[kRoundL / 32][kBlock];  // [32-entry word][pixel]: candidate bits
     __shared__ float2 s_pool[kPool];                // (w, u) slots of this round's entries
     __shared__ float4 s_gI[kBlock];                 // per pixel: dL/dC (rgb), dL/ddepth
     __shared__ uint32_t s_w[4];                     // per-wave scratch (max / scan totals)
@@ -641,8 +642,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_lists_kernel(
     while (hi > 0) {
         // ---- candidates of this round: thread i <-> entry hi-1-i; slot demand; prefix sum ----
 #pragma unroll
-        for (int w = 0; w < kStage / 32; ++w) s_pm[w][tid] = 0u;
-        const bool have = (uint32_t)tid < hi;
+        for (int w = 0; w < kRoundL / 32; ++w) s_pm[w][tid] = 0u;
+        const bool have = tid < kRoundL && (uint32_t)tid < hi;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a;
         uint32_t gid = 0;
         int xl = 0, yl = 0, bw = 0, bh = 0;
