@@ -226,7 +226,8 @@ def main():
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "pmc_summary.json"
-        if prof.exists():
+        default_workload = (args.config == "C2" and S == 8 and V == 4 and args.s_mult == 1.0 and not args.allreduce)
+        if prof.exists() and default_workload:      # the PMC passes were collected on exactly this workload
             try:
                 traffic = json.loads(prof.read_text()).get(_lib.stage_kernel_name(dom), {}).get("hbm_bytes_per_launch")
             except Exception:

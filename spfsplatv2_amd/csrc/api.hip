@@ -150,8 +150,12 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
-    SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * (size_t)RT, stream));
-    SPF_HIP(hipMemsetAsync(st->tile_flags, 0, sizeof(uint32_t) * (size_t)RT, stream));
+    if (st->tile_flags == st->tile_count + RT) {   // adjacent (the Python binding lays them out so): one fill
+        SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * 2 * (size_t)RT, stream));
+    } else {
+        SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * (size_t)RT, stream));
+        SPF_HIP(hipMemsetAsync(st->tile_flags, 0, sizeof(uint32_t) * (size_t)RT, stream));
+    }
     {
         StageScope t(SPF_STAGE_PROJECT, stream);
         SPF_HIP(spf::launch_project_fwd(*d, *in, *st, tiles_x, tiles_y, stream));

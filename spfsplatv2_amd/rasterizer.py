@@ -88,7 +88,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     rect = torch.empty((2 * R * G,), **i32)        # packed tile rect | depth key (float bits)
     nblk = lib.spf_raster_view_partial_blocks(G)
     pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
-    tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_start (+1) | tile_fill | tile_flags | counters
+    tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_flags | tile_start (+1) | tile_fill | counters
     counters = tiles[4 * R * T + 1:]
     final_T = torch.empty((R * P,), **f32)
     n_contrib = torch.empty((R * P,), **i32)
@@ -124,8 +124,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
-                         _ptr(tiles[RT:2 * RT + 1]),
-                         _ptr(tiles[2 * RT + 1:3 * RT + 1]), _ptr(tiles[3 * RT + 1:4 * RT + 1]),
+                         _ptr(tiles[2 * RT:3 * RT + 1]),
+                         _ptr(tiles[3 * RT + 1:4 * RT + 1]), _ptr(tiles[RT:2 * RT]),
                          _ptr(tiles[4 * RT + 1:]), _ptr(pairs),
                          _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib))
