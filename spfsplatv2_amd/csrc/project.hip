@@ -309,6 +309,22 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
             else cull_r2 = 3.0e38f;
             if (!(cull_r2 == cull_r2)) cull_r2 = 3.0e38f;
 
+            // Shrink the tile rect to the tiles that hold a pixel CENTRE inside the cull disc: a tile dropped here
+            // could only have held pixels whose alpha is < 1/255, i.e. pairs that contribute nothing (the 3-sigma
+            // rect above stays what `radii` reports).
+            {
+                const DiscBox db = disc_box(pr.px, pr.py, cull_r2);
+                if (!db.any) {
+                    x1 = x0; y1 = y0;
+                } else {
+                    const float it = 1.0f / kTile;
+                    x0 = max(x0, (int)fminf((float)tiles_x, fmaxf(0.f, floorf(db.xlo * it))));
+                    y0 = max(y0, (int)fminf((float)tiles_y, fmaxf(0.f, floorf(db.ylo * it))));
+                    x1 = min(x1, (int)fminf((float)tiles_x, fmaxf(0.f, floorf(db.xhi * it) + 1.f)));
+                    y1 = min(y1, (int)fminf((float)tiles_y, fmaxf(0.f, floorf(db.yhi * it) + 1.f)));
+                    if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
+                }
+            }
             st.radii[rg] = (int)radius;
             st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
             st.zkey[rg] = pr.tz;

@@ -9,7 +9,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("G,expect_min_list", [(9000, 2049), (40000, 8193), (70000, 16385)])
+@pytest.mark.parametrize("G,expect_min_list", [(12000, 2049), (50000, 8193), (110000, 16385)])
 def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list):
     """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and the global-memory
     fallback above 16384 entries."""
