@@ -20,6 +20,7 @@
  *                           (cuda_splatting.py:66-74), get_fov (src/geometry/projection.py:269-283),
  *                           get_projection_matrix (cuda_splatting.py:15-42), extrinsics.inverse() and the
  *                           transposes (cuda_splatting.py:84-91), and its autograd backward to the poses.
+ *   spf_adapter_*           UnifiedGaussianAdapter.forward (src/model/encoder/common/gaussian_adapter.py:122-150)
  *   spf_rope2d              `rope_2d(tokens, positions, base, fwd)` (and VGGT's RotaryPositionEmbedding2D,
  *                           src/model/encoder/backbone/vggt/layers/rope.py:62-188, same rotation out of place)
  *                           src/model/encoder/backbone/croco/curope/curope.cpp:49-65 and
@@ -167,6 +168,15 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
 /* Backward of both stages.  `capacity` = number of 12-float records g->gpair can hold (>= D). */
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
                         const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
+
+/* Fused Gaussian adapter (UnifiedGaussianAdapter.forward, src/model/encoder/common/gaussian_adapter.py:122-150):
+ * raw[N, 7+3K] network channels -> scales[N,3] = min(0.001*softplus, 0.3), rotations[N,4] = q/(|q|+eps),
+ * harmonics[N,3,K] = raw[7:] * sh_mask[K]; and its backward (any upstream gradient may be NULL = zero). */
+int spf_adapter_forward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps, float* scales,
+                        float* rotations, float* harmonics, void* stream);
+int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps,
+                         const float* dL_dscales, const float* dL_drotations, const float* dL_dharmonics,
+                         float* dL_draw, void* stream);
 
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n, stride_h) and
  * stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.  positions[B / pos_div, N, 2] int64 contiguous

@@ -17,6 +17,9 @@ hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, 
                              uint32_t, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
                              hipStream_t);
+hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
+hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
+                              float*, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
 hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float, float,
@@ -224,6 +227,27 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         StageScope t(SPF_STAGE_PROJECT_BWD, stream);
         SPF_HIP(spf::launch_project_bwd(*d, *in, *st, *g, spf_raster_view_partial_blocks(d->G), stream));
     }
+    return SPF_OK;
+}
+
+int spf_adapter_forward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps, float* scales,
+                        float* rotations, float* harmonics, void* stream_) {
+    if (!raw || !sh_mask || !scales || !rotations || !harmonics) return fail(SPF_E_INVALID, "adapter: null pointer");
+    if (N < 0 || K < 1) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K >= 1");
+    if (N == 0) return SPF_OK;
+    SPF_HIP(spf::launch_adapter_fwd(raw, N, K, sh_mask, eps, scales, rotations, harmonics,
+                                    static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps,
+                         const float* dL_dscales, const float* dL_drotations, const float* dL_dharmonics,
+                         float* dL_draw, void* stream_) {
+    if (!raw || !sh_mask || !dL_draw) return fail(SPF_E_INVALID, "adapter: null pointer");
+    if (N < 0 || K < 1) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K >= 1");
+    if (N == 0) return SPF_OK;
+    SPF_HIP(spf::launch_adapter_bwd(raw, N, K, sh_mask, eps, dL_dscales, dL_drotations, dL_dharmonics, dL_draw,
+                                    static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 
