@@ -17,71 +17,10 @@ namespace spf {
 // ---- scan of tile counts: single block, n = R*T is small (<= a few 10^5) --------------------
 constexpr int kScanThreads = 1024;
 
-// Exclusive scan of in[0..n) by one 1024-thread block; returns (total, max) to every thread.
-__device__ __forceinline__ void block_exclusive_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                     uint32_t* __restrict__ zero_fill, int n, uint32_t* s_wsum,
-                                                     uint32_t* s_wmax, uint32_t& total, uint32_t& gmax) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + kScanThreads - 1) / kScanThreads;
-    const int b = tid * chunk, e = min(n, b + chunk);
-    uint32_t sum = 0, mx = 0;
-    constexpr int kRegs = 16;          // the common case keeps the thread's chunk in registers: one load latency
-    uint32_t v[kRegs];
-    const bool in_regs = chunk <= kRegs;
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) v[k] = (b + k < e) ? in[b + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) {
-            sum += v[k];
-            mx = max(mx, v[k]);
-        }
-    } else {
-        for (int i = b; i < e; ++i) {
-            const uint32_t c = in[i];
-            sum += c;
-            mx = max(mx, c);
-        }
-    }
-    uint32_t inc = sum;   // inclusive scan of per-thread sums inside the wave
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
-        if (lane >= o) inc += y;
-    }
-    mx = wave_max_u32(mx);
-    __syncthreads();      // previous use of the scratch is over
-    if (lane == kWave - 1) s_wsum[wave] = inc;
-    if (lane == 0) s_wmax[wave] = mx;
-    __syncthreads();
-    uint32_t woff = 0;
-    total = 0;
-    gmax = 0;
-    for (int w = 0; w < kScanThreads / kWave; ++w) {
-        const uint32_t x = s_wsum[w];
-        if (w < wave) woff += x;
-        total += x;
-        gmax = max(gmax, s_wmax[w]);
-    }
-    uint32_t run = woff + inc - sum;  // exclusive prefix of this thread's chunk
-    if (in_regs) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k)
-            if (b + k < e) {
-                out[b + k] = run;
-                if (zero_fill) zero_fill[b + k] = 0;
-                run += v[k];
-            }
-    } else {
-        for (int i = b; i < e; ++i) {
-            const uint32_t c = in[i];
-            out[i] = run;
-            if (zero_fill) zero_fill[i] = 0;
-            run += c;
-        }
-    }
-}
-
+// One 1024-thread block: exclusive scan of the per-tile counts (-> tile_start, zeroed tile_fill, D, longest list,
+// number of dense tiles) and of the per-block pair totals (-> blk_base), BOTH in one pass: every thread first issues
+// all the loads of its two chunks (one global-memory latency), the two running sums travel through the same wave
+// scans and the same pair of barriers.
 __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
                                                                      uint32_t* __restrict__ start,
                                                                      uint32_t* __restrict__ fill,
@@ -90,25 +29,81 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
                                                                      uint32_t* __restrict__ counters, int n,
                                                                      const uint32_t* __restrict__ blk_total,
                                                                      uint32_t* __restrict__ blk_base, int nb) {
-    __shared__ uint32_t s_wsum[kScanThreads / kWave];
-    __shared__ uint32_t s_wmax[kScanThreads / kWave];
-    uint32_t total, gmax, t2, m2;
-    __shared__ uint32_t s_dense;
-    if (threadIdx.x == 0) s_dense = 0;
+    __shared__ uint32_t s_a[kScanThreads / kWave], s_b[kScanThreads / kWave], s_mx[kScanThreads / kWave],
+        s_dn[kScanThreads / kWave];
+    constexpr int kRegs = 16;   // chunks up to 16 live in registers (n, nb <= 16384); longer ones are re-read
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ca = (n + kScanThreads - 1) / kScanThreads, cb = (nb + kScanThreads - 1) / kScanThreads;
+    const int a0 = tid * ca, a1 = min(n, a0 + ca), b0 = tid * cb, b1 = min(nb, b0 + cb);
+    const bool ra = ca <= kRegs, rb = cb <= kRegs;
+    uint32_t va[kRegs], vf[kRegs], vb[kRegs];
+#pragma unroll
+    for (int k = 0; k < kRegs; ++k) {
+        va[k] = (ra && a0 + k < a1) ? count[a0 + k] : 0u;
+        vf[k] = (ra && a0 + k < a1) ? flags[a0 + k] : 0u;
+        vb[k] = (rb && b0 + k < b1) ? blk_total[b0 + k] : 0u;
+    }
+    uint32_t sa = 0, sb = 0, mx = 0, dn = 0;
+    if (ra) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) {
+            sa += va[k];
+            mx = max(mx, va[k]);
+            dn += (a0 + k < a1 && tile_is_dense(vf[k], va[k], dense_thr)) ? 1u : 0u;
+        }
+    } else {
+        for (int i = a0; i < a1; ++i) {
+            const uint32_t c = count[i];
+            sa += c;
+            mx = max(mx, c);
+            dn += tile_is_dense(flags[i], c, dense_thr) ? 1u : 0u;
+        }
+    }
+    if (rb) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k) sb += vb[k];
+    } else {
+        for (int i = b0; i < b1; ++i) sb += blk_total[i];
+    }
+    uint32_t ia = sa, ib = sb;   // inclusive scans of the per-thread sums inside the wave
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t ya = (uint32_t)__shfl_up((int)ia, o, kWave), yb = (uint32_t)__shfl_up((int)ib, o, kWave);
+        if (lane >= o) { ia += ya; ib += yb; }
+    }
+    mx = wave_max_u32(mx);
+    dn = wave_sum_u32(dn);
+    if (lane == kWave - 1) { s_a[wave] = ia; s_b[wave] = ib; }
+    if (lane == 0) { s_mx[wave] = mx; s_dn[wave] = dn; }
     __syncthreads();
-    uint32_t nd = 0;                                                               // tiles the rows kernels take
-    for (int i = threadIdx.x; i < n; i += kScanThreads) nd += tile_is_dense(flags[i], count[i], dense_thr) ? 1u : 0u;
-    nd = wave_sum_u32(nd);
-    if ((threadIdx.x & 63) == 0 && nd) atomicAdd(&s_dense, nd);
-    block_exclusive_scan(count, start, fill, n, s_wsum, s_wmax, total, gmax);       // tile lists
-    block_exclusive_scan(blk_total, blk_base, nullptr, nb, s_wsum, s_wmax, t2, m2);  // Gaussian-major pair ids
-    if (threadIdx.x == 0) {
+    uint32_t oa = 0, ob = 0, total = 0, gmax = 0, dense = 0;
+    for (int w = 0; w < kScanThreads / kWave; ++w) {
+        if (w < wave) { oa += s_a[w]; ob += s_b[w]; }
+        total += s_a[w];
+        gmax = max(gmax, s_mx[w]);
+        dense += s_dn[w];
+    }
+    uint32_t runa = oa + ia - sa, runb = ob + ib - sb;   // exclusive prefixes of this thread's chunks
+    if (ra) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k)
+            if (a0 + k < a1) { start[a0 + k] = runa; fill[a0 + k] = 0u; runa += va[k]; }
+    } else {
+        for (int i = a0; i < a1; ++i) { const uint32_t c = count[i]; start[i] = runa; fill[i] = 0u; runa += c; }
+    }
+    if (rb) {
+#pragma unroll
+        for (int k = 0; k < kRegs; ++k)
+            if (b0 + k < b1) { blk_base[b0 + k] = runb; runb += vb[k]; }
+    } else {
+        for (int i = b0; i < b1; ++i) { const uint32_t c = blk_total[i]; blk_base[i] = runb; runb += c; }
+    }
+    if (tid == 0) {
         start[n] = total;
-        counters[0] = total;
-        counters[1] = gmax;
-        counters[2] = 0;
-        (void)t2;           // == total (both count the same pairs)
-        counters[3] = s_dense;
+        counters[0] = total;     // D
+        counters[1] = gmax;      // longest tile list
+        counters[2] = 0;         // overflow flag (set by the binning kernel)
+        counters[3] = dense;     // tiles the dense "rows" render kernels take
     }
 }
 
