@@ -98,7 +98,8 @@ typedef struct SpfState {
     uint32_t* blk_total;   /* [R*nblk]  pairs per block of 256 Gaussians, nblk = spf_raster_view_partial_blocks(G) */
     uint32_t* blk_base;    /* [R*nblk]  exclusive scan of blk_total */
     float* final_T;        /* [R*P]     transmittance left after the last contributor */
-    uint32_t* n_contrib;   /* [R*P]     1 + list position of the last contributor (0 = none) */
+    uint32_t* n_contrib;   /* [R*P,2]   per pixel: (1 + list position of the last contributor (0 = none),
+                                        number of contributors -- the backward balances its lanes with it) */
 } SpfState;
 
 typedef struct SpfOutputs {

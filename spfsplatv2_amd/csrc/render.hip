@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     asm volatile("" : "+v"(fx), "+v"(fy));   // keep the converted coordinates live (no per-iteration v_cvt)
 
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
+    uint32_t last = 0, hits = 0;
     bool done = !c.inside;
     bool row_done = false;
     bool wave_done = __ballot(!done) == 0;
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
                     C0 = fmaf(p2.x, w, C0); C1 = fmaf(p2.y, w, C1); C2 = fmaf(p2.z, w, C2); Dp = fmaf(p2.w, w, Dp);
                     Tr = take ? test_T : Tr;
                     last = take ? base + (uint32_t)j + 1u : last;
+                    hits += take ? 1u : 0u;
                 }
                 // per-row / per-wave early termination from one ballot per 32 entries
                 const uint64_t alive = __ballot(!done);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
         depth_out[(size_t)c.r * P + pix] = Dp;
         alpha_out[(size_t)c.r * P + pix] = 1.0f - Tr;
         final_T[(size_t)c.r * P + pix] = Tr;
-        n_contrib[(size_t)c.r * P + pix] = last;
+        reinterpret_cast<uint2*>(n_contrib)[(size_t)c.r * P + pix] = make_uint2(last, hits);
     }
 }
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     asm volatile("" : "+v"(fx), "+v"(fy));
 
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
+    uint32_t last = 0, hits = 0;
     bool done = !inside;
     bool wave_done = __ballot(!done) == 0;
 
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 C0 = fmaf(p2.x, wgt, C0); C1 = fmaf(p2.y, wgt, C1); C2 = fmaf(p2.z, wgt, C2); Dp = fmaf(p1.w, wgt, Dp);
                 Tr = take ? test_T : Tr;
                 last = take ? base + (uint32_t)j + 1u : last;
+                hits += take ? 1u : 0u;
                 if (stop) { done = true; m = 0u; w = nw - 1; }
             }
             wave_done = __ballot(!done) == 0;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         depth_out[(size_t)r * P + pix] = Dp;
         alpha_out[(size_t)r * P + pix] = 1.0f - Tr;
         final_T[(size_t)r * P + pix] = Tr;
-        n_contrib[(size_t)r * P + pix] = last;
+        reinterpret_cast<uint2*>(n_contrib)[(size_t)r * P + pix] = make_uint2(last, hits);
     }
 }
 
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     uint32_t ncon = 0;
     if (inside) {
         T_final = final_T[(size_t)r * P + pix];
-        ncon = n_contrib[(size_t)r * P + pix];
+        ncon = n_contrib[2 * ((size_t)r * P + pix)];
         if (dL_dimage) {
             const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
             gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     __shared__ float2 s_pool[kPool];                // (w, u) slots of this round's entries
     __shared__ float4 s_gI[kBlock];                 // per pixel: dL/dC (rgb), dL/ddepth
     __shared__ uint32_t s_w[4];                     // per-wave scratch (max / scan totals)
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_wacc[4];                  // per-wave scratch (accepted-entry counts)
 
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return;
@@ -586,17 +588,50 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = tx * kTile, Y0 = ty * kTile;
-    const int lx = tid & 15, ly = tid >> 4;
-    const int px = X0 + lx, py = Y0 + ly;
-    const bool inside = px < W && py < H;
     const uint32_t beg = tile_start[(size_t)r * T + tile];
     const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
     if (n == 0) return;
     if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    const size_t P = (size_t)H * W;
+    // ---- lane <-> pixel assignment: pixels sorted by their number of contributors (recorded by the forward).
+    // A wave of the pixel-private replay runs as long as its busiest pixel, so pixels of similar load share a wave
+    // (counting sort over 256 pixels in LDS; ties keep pixel order).
+    int mypix;
+    {
+        uint32_t* s_cnt = &s_pm[0][0];          // 256 bins (reused before the rounds start)
+        uint32_t* s_perm = &s_pm[1][0];
+        const int qx = X0 + (tid & 15), qy = Y0 + (tid >> 4);
+        uint32_t h = 0;
+        if (qx < W && qy < H) h = min(n_contrib[2 * ((size_t)r * P + (size_t)qy * W + qx) + 1], 255u);
+        s_cnt[tid] = 0u;
+        __syncthreads();
+        const uint32_t rank_in_bin = atomicAdd(&s_cnt[255u - h], 1u);     // descending load
+        __syncthreads();
+        uint32_t inc = s_cnt[tid];              // exclusive scan of the 256 bins: wave scan + 4 wave totals
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
+            if (lane >= o) inc += y;
+        }
+        if (lane == kWave - 1) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t off = inc - s_cnt[tid];
+        for (int w = 0; w < wave; ++w) off += s_w[w];
+        __syncthreads();
+        s_cnt[tid] = off;                       // bin start
+        __syncthreads();
+        s_perm[s_cnt[255u - h] + rank_in_bin] = (uint32_t)tid;
+        __syncthreads();
+        mypix = (int)s_perm[tid];
+        __syncthreads();
+    }
+    const int lx = mypix & 15, ly = mypix >> 4;
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < W && py < H;
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
-    const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
+    const size_t pix = (size_t)py * W + px;
     auto pair_slot = [&](uint32_t gid) -> uint32_t {
         const size_t rg = (size_t)r * G + gid;
         const uint32_t rc = rect[rg];
@@ -608,7 +643,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     uint32_t ncon = 0;
     if (inside) {
         T_final = final_T[(size_t)r * P + pix];
-        ncon = n_contrib[(size_t)r * P + pix];
+        ncon = n_contrib[2 * ((size_t)r * P + pix)];
         if (dL_dimage) {
             const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
             gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
@@ -616,7 +651,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + pix];
         if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
     }
-    s_gI[tid] = make_float4(gI0, gI1, gI2, gD);
+    s_gI[mypix] = make_float4(gI0, gI1, gI2, gD);
     const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
 
@@ -666,22 +701,26 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
             const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
             if (lane >= o) inc += y;
         }
-        __syncthreads();                       // previous round is completely over (s_w, s_pool, s_p* reusable)
+        // (the barrier that closed the previous round makes s_w / s_wacc / s_pool / s_p* reusable here)
         if (lane == kWave - 1) s_w[wave] = inc;
         __syncthreads();
         uint32_t off = inc - size;
         for (int w = 0; w < wave; ++w) off += s_w[w];
-        const bool acc = have && off + size <= (uint32_t)kPool;      // a prefix of the threads
-        const int cnt = __syncthreads_count(acc);                    // >= 1: one entry needs at most 256 slots
-        if (tid == cnt - 1) s_total = off + size;
+        // accepted = a prefix of the threads: thread t is in iff the slot demand of threads 0..t fits the pool; the
+        // per-wave counts travel with the staging barrier below (no __syncthreads_count round trip)
+        const bool acc = have && off + size <= (uint32_t)kPool;
+        const uint64_t accb = __ballot(acc);
+        if (lane == 0) s_wacc[wave] = (uint32_t)__popcll(accb);
         if (acc) {
             s_p0[tid] = a;
             s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
                                     __int_as_float(xl | (yl << 4) | (max(bw - 1, 0) << 8) | ((int)off << 12)));
         }
+#pragma unroll
+        for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
         __syncthreads();
-        for (uint32_t k = tid; k < s_total; k += kBlock) s_pool[k] = make_float2(0.f, 0.f);
+        const int cnt = (int)(s_wacc[0] + s_wacc[1] + s_wacc[2] + s_wacc[3]);   // >= 1: one entry needs <= 256 slots
         // ---- phase A ----
         if (acc) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
         __syncthreads();
@@ -692,7 +731,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
             const uint32_t jmin = ncon < hi ? hi - ncon : 0u;
             auto load_word = [&](int w) -> uint32_t {
                 const uint32_t wb = 32u * (uint32_t)w;
-                uint32_t m = s_pm[w][tid];
+                uint32_t m = s_pm[w][mypix];
                 if (jmin >= wb + 32u) m = 0u;
                 else if (jmin > wb) m &= ~((1u << (jmin - wb)) - 1u);
                 return m;
@@ -774,6 +813,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
             out[2] = make_float4(c2, cd, 0.f, 0.f);
         }
         hi -= (uint32_t)cnt;
+        __syncthreads();                         // round over: LDS scratch may be reused
     }
 }
 
@@ -806,7 +846,8 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
     if (dense_hint != (uint32_t)RT)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
+            dense_threshold());
     if (dense_hint != 0u)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,

@@ -91,7 +91,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_flags | tile_start (+1) | tile_fill | counters
     counters = tiles[4 * R * T + 1:]
     final_T = torch.empty((R * P,), **f32)
-    n_contrib = torch.empty((R * P,), **i32)
+    n_contrib = torch.empty((2 * R * P,), **i32)
     image = torch.empty((S, V, 3, H, W), **f32)
     depth = torch.empty((S, V, 1, H, W), **f32)
     alpha = torch.empty((S, V, 1, H, W), **f32)
