@@ -117,6 +117,33 @@ class cuRoPE2D(torch.nn.Module):
 RoPE2D = cuRoPE2D
 
 
+class PositionGetter:
+    """Producer of the ``positions`` operand: the (y, x) patch-grid coordinates of an h x w token grid, int64,
+    contiguous, one private copy per call (croco/blocks.py:207-219; consumed by PatchEmbedDust3R.forward,
+    croco/patch_embed.py:19-29).  Grids are cached per (h, w, device)."""
+
+    def __init__(self):
+        self.cache_positions = {}
+
+    def __call__(self, b: int, h: int, w: int, device) -> torch.Tensor:
+        key = (h, w, str(device))
+        grid = self.cache_positions.get(key)
+        if grid is None:
+            n = torch.arange(h * w, dtype=torch.int64, device=device)
+            grid = torch.stack((n // w, n % w), dim=-1)                      # row-major: y slow, x fast
+            self.cache_positions[key] = grid
+        return grid.unsqueeze(0).repeat(b, 1, 1)
+
+
+def append_token_position(pos: torch.Tensor) -> torch.Tensor:
+    """Position of one extra (intrinsics / pose) token appended after the patch tokens: (first token's y + last token's
+    y + 1, first token's x) -- i.e. one row below the grid, column 0 (backbone_masked_croco.py:163-172, 192-201).
+    ``pos`` [..., N, 2] -> [..., N+1, 2]."""
+    extra = pos[..., 0:1, :].clone()
+    extra[..., 0] += pos[..., -1:, 0] + 1
+    return torch.cat((pos, extra), dim=-2)
+
+
 class _RoPE2DHeadMajor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, positions, base):
