@@ -120,6 +120,7 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    builder = rank == 0 if args.one_device else local_rank == 0
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -130,6 +131,13 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    # the in-tree library normally travels with the tree; (re)build it if it is missing or stale (one rank per
+    # node compiles, the others wait) -- a no-op when the sources' digest matches
+    from spfsplatv2_amd import build as _build
+    if builder:
+        _build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
 

@@ -7,9 +7,11 @@ PyTorch fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "_C" / "libspfsplat_hip.so"
+# SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
+LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
 ABI_VERSION = 1
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",

@@ -563,6 +563,25 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 //            and writes the pair's 48-byte record.
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
+#ifdef SPF_ABLATE
+// profiling build only (SPF_HIPCC_EXTRA=-DSPF_ABLATE): cut the kernel short at run time to time its parts
+static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-threshold argument
+#define ABLATE(n) ((int)(dense_thr_arg >> 28) == (n))
+#else
+#define ABLATE(n) false
+#endif
+#ifdef SPF_PHASE_CLOCKS
+// profiling build only (SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS): shader-clock cycles per phase, summed over waves
+__device__ unsigned long long g_phase_cycles[8];
+#define PHASE_INIT() long long ph_t = clock64(); const long long ph_w0 = wall_clock64(); unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PHASE_MARK(i) do { const long long t_ = clock64(); ph_acc[i] += (unsigned long long)(t_ - ph_t); ph_t = t_; } while (0)
+#define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&spf::g_phase_cycles[i_], ph_acc[i_]); atomicAdd(&spf::g_phase_cycles[6], (unsigned long long)(wall_clock64() - ph_w0)); atomicAdd(&spf::g_phase_cycles[7], 1ull); } } while (0)
+#else
+#define PHASE_INIT()
+#define PHASE_MARK(i)
+#define PHASE_FLUSH()
+#endif
+
 constexpr int kPool = 1536;    // (w, u) slots per round: 12 KB
 constexpr int kRoundL = 192;  // candidate entries per round (6 mask words); LDS total ~31 KB -> 5 blocks per CU
 
@@ -572,7 +591,8 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
-    float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr) {
+    float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
+    const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;
     __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
     __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
     __shared__ float4 s_p2[kRoundL];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
@@ -592,6 +612,8 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
     if (n == 0) return;
     if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    PHASE_INIT();
+    if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
     // ---- lane <-> pixel assignment: pixels sorted by their number of contributors (recorded by the forward).
     // A wave of the pixel-private replay runs as long as its busiest pixel, so pixels of similar load share a wave
@@ -659,6 +681,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
     if (lane == 0) s_w[wave] = wmax;
     __syncthreads();
     const uint32_t bmax = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+    if (ABLATE(2)) { if (tail == 123.f) gpair[0] = T_final; return; }
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         for (uint32_t idx = bmax + tid; idx < n; idx += kBlock) {
@@ -668,10 +691,12 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         }
     }
     if (bmax == 0) return;
+    PHASE_MARK(0);
+    if (ABLATE(3)) { if (tail == 123.f) gpair[0] = T_final; return; }
 
     float Tr = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f;   // colour/depth behind the current entry
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lD = 0.f;
+    float sB = -tail * T_final;          // running "behind" scalar of the replay (see phase B)
+    const int kconst = lx + ly - 256;    // per-pixel part of the slot index
 
     uint32_t hi = bmax;   // entries [0, hi) are still to be replayed
     while (hi > 0) {
@@ -714,19 +739,25 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         if (acc) {
             s_p0[tid] = a;
             s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
+            // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + ly*bw + lx; the
+            // bracket is >= -255 and travels biased by 256 next to bw-1
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
-                                    __int_as_float(xl | (yl << 4) | (max(bw - 1, 0) << 8) | ((int)off << 12)));
+                                    __int_as_float(max(bw - 1, 0) | (((int)off - yl * bw - xl + 256) << 4)));
         }
 #pragma unroll
         for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
         __syncthreads();
         const int cnt = (int)(s_wacc[0] + s_wacc[1] + s_wacc[2] + s_wacc[3]);   // >= 1: one entry needs <= 256 slots
+        PHASE_MARK(1);
+        if (ABLATE(4)) { hi -= (uint32_t)cnt; __syncthreads(); continue; }
         // ---- phase A ----
         if (acc) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
         __syncthreads();
+        PHASE_MARK(2);
+        if (ABLATE(5)) { hi -= (uint32_t)cnt; __syncthreads(); continue; }
         // ---- phase B: ascending bits = descending list position ----
         const int nw = (cnt + 31) >> 5;
-        if (hi - (uint32_t)cnt < wmax) {
+        if (hi - (uint32_t)cnt < wmax && !ABLATE(7)) {
             // contributors of this pixel are entries < ncon, i.e. thread indices >= hi - ncon
             const uint32_t jmin = ncon < hi ? hi - ncon : 0u;
             auto load_word = [&](int w) -> uint32_t {
@@ -765,28 +796,27 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
                 const bool hit = act && power <= 0.f && alpha >= kAlphaMin;
                 if (hit) {
+                    // With w_j = alpha_j*T_j and cg_j = c_j . dL/dC (+ depth_j * dL/ddepth):
+                    //   dL/dalpha_i = cg_i*T_i - (sum_{j behind i} cg_j*w_j - tail*T_final) / (1 - alpha_i)
+                    // (image = C + T_final*bg and alpha_out = 1 - T_final see alpha_i only through T_final); the
+                    // bracket is ONE running scalar, sB.
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    Tr = Tr * inv1ma;
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    accD = last_alpha * lD + (1.f - last_alpha) * accD;
-                    lc0 = p2.x; lc1 = p2.y; lc2 = p2.z; lD = p1.w;
-                    float dL_dalpha_ = (p2.x - acc0) * gI0 + (p2.y - acc1) * gI1 + (p2.z - acc2) * gI2 +
-                                       (p1.w - accD) * gD;
-                    dL_dalpha_ *= Tr;
-                    last_alpha = alpha;
-                    // image = C + T_final*bg and alpha_out = 1 - T_final see alpha only through T_final
-                    dL_dalpha_ += (T_final * inv1ma) * tail;
+                    Tr = Tr * inv1ma;                                           // T_i: transmittance in front of i
+                    const float cg = fmaf(p2.x, gI0, fmaf(p2.y, gI1, fmaf(p2.z, gI2, p1.w * gD)));
+                    const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));
+                    const float wgt = alpha * Tr;
+                    sB = fmaf(cg, wgt, sB);
                     const int box = __float_as_int(p2.w);
-                    const int k = (box >> 12) + (ly - ((box >> 4) & 15)) * (((box >> 8) & 15) + 1) + (lx - (box & 15));
-                    s_pool[k] = make_float2(alpha * Tr, Gv * dL_dalpha_);
+                    const int k = (int)__builtin_amdgcn_ubfe((uint32_t)box, 4, 11) + (box & 15) * ly + kconst;
+                    s_pool[k] = make_float2(wgt, Gv * dL_dalpha_);
                 }
             }
         }
+        PHASE_MARK(3);
         __syncthreads();
+        PHASE_MARK(4);
         // ---- phase C ----
-        if (acc) {
+        if (acc && !ABLATE(6)) {
             float Su = 0.f, Sux = 0.f, Suy = 0.f, Suxx = 0.f, Suxy = 0.f, Suyy = 0.f;
             float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
             const float2* __restrict__ hp = s_pool + off;
@@ -814,8 +844,28 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         }
         hi -= (uint32_t)cnt;
         __syncthreads();                         // round over: LDS scratch may be reused
+        PHASE_MARK(5);
     }
+    PHASE_FLUSH();
 }
+
+#ifdef SPF_ABLATE
+extern "C" int spf_debug_set_ablate(int v) {
+    spf::g_ablate_host = v & 15;
+    return 0;
+}
+#endif
+#ifdef SPF_PHASE_CLOCKS
+extern "C" int spf_debug_phase_cycles(unsigned long long* out8, int reset) {
+    (void)hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(spf::g_phase_cycles), sizeof(g_phase_cycles)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(spf::g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // ---- launchers ------------------------------------------------------------------------------------
 uint32_t dense_threshold() {
@@ -847,7 +897,11 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
             g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
+#ifdef SPF_ABLATE
+            dense_threshold() | ((uint32_t)g_ablate_host << 28));
+#else
             dense_threshold());
+#endif
     if (dense_hint != 0u)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
