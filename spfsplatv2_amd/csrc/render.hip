@@ -226,6 +226,15 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
 //            list order, gathering each candidate from LDS and compositing it.
 // A pixel outside the disc has alpha < 1/255 for that Gaussian, so the result equals the plain per-pixel loop.
 // ------------------------------------------------------------------------------------------------
+// Exponent of the lists kernels.  They stage the conic pre-multiplied: A' = -0.5*log2(e)*A, B' = -log2(e)*B,
+// C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
+// spelled out so that the forward and the backward replay evaluate it identically (same hit decisions).
+constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
+constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
+__device__ __forceinline__ float lists_power2(float dx, float dy, float A, float B, float C) {
+    return fmaf(dx, fmaf(A, dx, B * dy), (C * dy) * dy);
+}
+
 __device__ __forceinline__ void scatter_footprint(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2,
                                                   int X0, int Y0) {
     const DiscBox b = disc_box(gx, gy, r2);
@@ -284,8 +293,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[tid] = a;
-            s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
+            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
+            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, b.w, b.z);
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, 0.f);
             gx = a.x; gy = a.y; r2 = b.w;
         }
@@ -295,32 +304,24 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         if (!wave_done) {
             int w = 0;
             uint32_t m = done ? 0u : s_pm[0][tid];
-            // next candidate of this lane (-1: none left); lanes whose word is exhausted fetch the next word
-            auto next = [&]() -> int {
+            // next candidate of this lane (has = false: none left; the index stays valid); lanes whose word is
+            // exhausted fetch the next word
+            auto next = [&](bool& has) -> int {
                 while (__ballot(m == 0u && w < nw - 1)) {
                     if (m == 0u && w < nw - 1) {
                         ++w;
                         m = s_pm[w][tid];
                     }
                 }
-                const bool has = m != 0u;
+                has = m != 0u;
                 const int bit = has ? __builtin_ctz(m) : 0;
                 m &= m - 1u;
-                return has ? w * 32 + bit : -1;
+                return w * 32 + bit;
             };
-            // software pipeline: the LDS gathers of candidate i+1 are in flight while candidate i is composited
-            int jn = next();
-            float4 q0 = s_p0[max(jn, 0)], q1 = s_p1[max(jn, 0)], q2 = s_p2[max(jn, 0)];
-            while (__ballot(jn >= 0)) {
-                const int j = jn;
-                const bool act = j >= 0 && !done;
-                const float4 p0 = q0, p1 = q1, p2 = q2;
-                jn = next();
-                q0 = s_p0[max(jn, 0)]; q1 = s_p1[max(jn, 0)]; q2 = s_p2[max(jn, 0)];
-                const float dx = p0.x - fx, dy = p0.y - fy;
-                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
-                const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
-                const bool hit = act && power <= 0.f && alpha >= kAlphaMin;
+            auto composite = [&](bool has, int j, const float4& p0, const float4& p1, const float4& p2) {
+                const float pw = lists_power2(p0.x - fx, p0.y - fy, p0.z, p0.w, p1.x);
+                const float alpha = fminf(kAlphaMax, p1.y * __builtin_amdgcn_exp2f(pw));
+                const bool hit = has && !done && pw <= 0.f && alpha >= kAlphaMin;
                 const float test_T = Tr * (1.f - alpha);
                 const bool stop = hit && test_T < kTMin;
                 const bool take = hit && !stop;
@@ -330,6 +331,21 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 last = take ? base + (uint32_t)j + 1u : last;
                 hits += take ? 1u : 0u;
                 if (stop) { done = true; m = 0u; w = nw - 1; }
+            };
+            // software pipeline, unrolled by two: the LDS gathers of one candidate are in flight while the other is
+            // composited, and the two register sets swap roles instead of being copied
+            bool ha, hb;
+            int ja = next(ha), jb;
+            float4 a0 = s_p0[ja], a1 = s_p1[ja], a2 = s_p2[ja], b0, b1, b2;
+            while (true) {
+                if (!__ballot(ha)) break;
+                jb = next(hb);
+                b0 = s_p0[jb]; b1 = s_p1[jb]; b2 = s_p2[jb];
+                composite(ha, ja, a0, a1, a2);
+                if (!__ballot(hb)) break;
+                ja = next(ha);
+                a0 = s_p0[ja]; a1 = s_p1[ja]; a2 = s_p2[ja];
+                composite(hb, jb, b0, b1, b2);
             }
             wave_done = __ballot(!done) == 0;
         }
@@ -696,7 +712,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
 
     float Tr = T_final;
     float sB = -tail * T_final;          // running "behind" scalar of the replay (see phase B)
-    const int kconst = lx + ly - 256;    // per-pixel part of the slot index
+    const uint32_t kconst = (uint32_t)(lx + ly - 256);   // per-pixel part of the slot index (mod 2^32)
 
     uint32_t hi = bmax;   // entries [0, hi) are still to be replayed
     while (hi > 0) {
@@ -737,8 +753,8 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         const uint64_t accb = __ballot(acc);
         if (lane == 0) s_wacc[wave] = (uint32_t)__popcll(accb);
         if (acc) {
-            s_p0[tid] = a;
-            s_p1[tid] = make_float4(b.x, b.y, b.w, b.z);
+            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
+            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, b.w, b.z);
             // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + ly*bw + lx; the
             // bracket is >= -255 and travels biased by 256 next to bw-1
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
@@ -769,47 +785,52 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
             };
             int w = 0;
             uint32_t m = load_word(0);
-            auto next = [&]() -> int {
+            auto next = [&](bool& has) -> int {      // as in the forward
                 while (__ballot(m == 0u && w < nw - 1)) {
                     if (m == 0u && w < nw - 1) {
                         ++w;
                         m = load_word(w);
                     }
                 }
-                const bool has = m != 0u;
+                has = m != 0u;
                 const int bit = has ? __builtin_ctz(m) : 0;
                 m &= m - 1u;
-                return has ? w * 32 + bit : -1;
+                return w * 32 + bit;
             };
-            // software pipeline: gathers of candidate i+1 are in flight while candidate i is replayed
-            int jn = next();
-            float4 q0 = s_p0[max(jn, 0)], q1 = s_p1[max(jn, 0)], q2 = s_p2[max(jn, 0)];
-            while (__ballot(jn >= 0)) {
-                const int j = jn;
-                const bool act = j >= 0;
-                const float4 p0 = q0, p1 = q1, p2 = q2;
-                jn = next();
-                q0 = s_p0[max(jn, 0)]; q1 = s_p1[max(jn, 0)]; q2 = s_p2[max(jn, 0)];
-                const float dx = p0.x - fx, dy = p0.y - fy;
-                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
-                const float Gv = __expf(power);
+            auto replay = [&](bool has, const float4& p0, const float4& p1, const float4& p2) {
+                const float pw = lists_power2(p0.x - fx, p0.y - fy, p0.z, p0.w, p1.x);
+                const float Gv = __builtin_amdgcn_exp2f(pw);
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
-                const bool hit = act && power <= 0.f && alpha >= kAlphaMin;
-                if (hit) {
+                if (has && pw <= 0.f && alpha >= kAlphaMin) {
                     // With w_j = alpha_j*T_j and cg_j = c_j . dL/dC (+ depth_j * dL/ddepth):
                     //   dL/dalpha_i = cg_i*T_i - (sum_{j behind i} cg_j*w_j - tail*T_final) / (1 - alpha_i)
                     // (image = C + T_final*bg and alpha_out = 1 - T_final see alpha_i only through T_final); the
                     // bracket is ONE running scalar, sB.
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                     Tr = Tr * inv1ma;                                           // T_i: transmittance in front of i
-                    const float cg = fmaf(p2.x, gI0, fmaf(p2.y, gI1, fmaf(p2.z, gI2, p1.w * gD)));
+                    float cg = fmaf(p2.x, gI0, fmaf(p2.y, gI1, p2.z * gI2));
+                    if (DEPTH_GRAD) cg = fmaf(p1.w, gD, cg);
                     const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));
                     const float wgt = alpha * Tr;
                     sB = fmaf(cg, wgt, sB);
-                    const int box = __float_as_int(p2.w);
-                    const int k = (int)__builtin_amdgcn_ubfe((uint32_t)box, 4, 11) + (box & 15) * ly + kconst;
+                    const uint32_t box = __float_as_uint(p2.w);
+                    const uint32_t k = __builtin_amdgcn_ubfe(box, 4, 11) + __umul24(box & 15u, (uint32_t)ly) + kconst;
                     s_pool[k] = make_float2(wgt, Gv * dL_dalpha_);
                 }
+            };
+            // software pipeline unrolled by two (see the forward)
+            bool ha, hb;
+            int ja = next(ha), jb;
+            float4 a0 = s_p0[ja], a1 = s_p1[ja], a2 = s_p2[ja], b0, b1, b2;
+            while (true) {
+                if (!__ballot(ha)) break;
+                jb = next(hb);
+                b0 = s_p0[jb]; b1 = s_p1[jb]; b2 = s_p2[jb];
+                replay(ha, a0, a1, a2);
+                if (!__ballot(hb)) break;
+                ja = next(ha);
+                a0 = s_p0[ja]; a1 = s_p1[ja]; a2 = s_p2[ja];
+                replay(hb, b0, b1, b2);
             }
         }
         PHASE_MARK(3);
