@@ -229,6 +229,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
 // Exponent of the lists kernels.  They stage the conic pre-multiplied: A' = -0.5*log2(e)*A, B' = -log2(e)*B,
 // C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
 // spelled out so that the forward and the backward replay evaluate it identically (same hit decisions).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
 constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
 __device__ __forceinline__ float lists_power2(float dx, float dy, float A, float B, float C) {
@@ -598,11 +600,16 @@ __device__ unsigned long long g_phase_cycles[8];
 #define PHASE_FLUSH()
 #endif
 
-constexpr int kPool = 1536;    // (w, u) slots per round: 12 KB
-constexpr int kRoundL = 192;  // candidate entries per round (6 mask words); LDS total ~31 KB -> 5 blocks per CU
+#ifndef SPF_POOL
+#define SPF_POOL 1536
+#define SPF_ROUNDL 192
+#define SPF_BPC 5
+#endif
+constexpr int kPool = SPF_POOL;    // (w, u) slots per round: 12 KB
+constexpr int kRoundL = SPF_ROUNDL;  // candidate entries per round (6 mask words); LDS total ~31 KB -> 5 blocks per CU
 
 template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
+__global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + pix];
         if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
     }
-    s_gI[mypix] = make_float4(gI0, gI1, gI2, gD);
+    s_gI[mypix] = make_float4(gI0, gI1, gI2, DEPTH_GRAD ? gD : 1.f);   // .w == 1 lets phase C fold sum(u) into a packed fma
     const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
 
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
             s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, b.w, b.z);
             // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + ly*bw + lx; the
-            // bracket is >= -255 and travels biased by 256 next to bw-1
+            // bracket is >= -255 and travels biased by 256 (13 bits) next to bw-1
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
                                     __int_as_float(max(bw - 1, 0) | (((int)off - yl * bw - xl + 256) << 4)));
         }
@@ -814,7 +821,7 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
                     const float wgt = alpha * Tr;
                     sB = fmaf(cg, wgt, sB);
                     const uint32_t box = __float_as_uint(p2.w);
-                    const uint32_t k = __builtin_amdgcn_ubfe(box, 4, 11) + __umul24(box & 15u, (uint32_t)ly) + kconst;
+                    const uint32_t k = __builtin_amdgcn_ubfe(box, 4, 13) + __umul24(box & 15u, (uint32_t)ly) + kconst;
                     s_pool[k] = make_float2(wgt, Gv * dL_dalpha_);
                 }
             };
@@ -836,32 +843,48 @@ __global__ __launch_bounds__(kBlock, 5) void spf_render_bwd_lists_kernel(
         PHASE_MARK(3);
         __syncthreads();
         PHASE_MARK(4);
-        // ---- phase C ----
+        // ---- phase C: packed fp32 (v_pk_fma_f32), six arithmetic instructions per slot ----
         if (acc && !ABLATE(6)) {
-            float Su = 0.f, Sux = 0.f, Suy = 0.f, Suxx = 0.f, Suxy = 0.f, Suyy = 0.f;
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, cd = 0.f;
+            v2f c01 = {0.f, 0.f}, c2s = {0.f, 0.f};      // (dL/dr, dL/dg), (dL/db, sum u)
+            v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};        // (sum u dx, sum u dy), (sum u dx^2, sum u dy^2)
+            float sxy = 0.f, cd = 0.f;
+            // one flat loop over the box (row-major like its slots), software-pipelined: the two LDS reads of slot
+            // i+1 are in flight while slot i is accumulated -- the loop is latency-, not issue-bound
             const float2* __restrict__ hp = s_pool + off;
-            for (int yy = 0; yy < bh; ++yy) {
-                const float dy = a.y - (float)(Y0 + yl + yy);
-                const float4* __restrict__ gp = s_gI + (yl + yy) * kTile + xl;
-                for (int xx = 0; xx < bw; ++xx) {
-                    const float2 h = hp[yy * bw + xx];
-                    const float4 gi = gp[xx];
-                    const float dx = a.x - (float)(X0 + xl + xx);
-                    c0 = fmaf(h.x, gi.x, c0); c1 = fmaf(h.x, gi.y, c1); c2 = fmaf(h.x, gi.z, c2);
-                    if (DEPTH_GRAD) cd = fmaf(h.x, gi.w, cd);
-                    Su += h.y;
-                    Sux = fmaf(h.y, dx, Sux); Suy = fmaf(h.y, dy, Suy);
-                    Suxx = fmaf(h.y * dx, dx, Suxx); Suxy = fmaf(h.y * dx, dy, Suxy);
-                    Suyy = fmaf(h.y * dy, dy, Suyy);
+            const float4* __restrict__ gp = s_gI + yl * kTile + xl;
+            const float dx0 = a.x - (float)(X0 + xl);
+            v2f d = {dx0, a.y - (float)(Y0 + yl)};
+            const int nslot = (int)size;
+            float2 hn = make_float2(0.f, 0.f);
+            float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nslot > 0) { hn = hp[0]; gn = gp[0]; }
+            int xx = 0;
+            for (int i = 0; i < nslot; ++i) {
+                const float2 h = hn;                 // (w, u) of this pixel
+                const float4 gi = gn;                // (dL/dC, dL/ddepth or 1)
+                const v2f dc = d;
+                ++xx; ++gp; d.x -= 1.f;
+                if (xx == bw) { xx = 0; gp += kTile - bw; d.x = dx0; d.y -= 1.f; }
+                if (i + 1 < nslot) { hn = hp[i + 1]; gn = *gp; }
+                const v2f hw = {h.x, h.x}, hu = {h.y, h.y}, hwu = {h.x, h.y};
+                c01 = __builtin_elementwise_fma(hw, v2f{gi.x, gi.y}, c01);
+                if (DEPTH_GRAD) {
+                    c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, 1.f}, c2s);
+                    cd = fmaf(h.x, gi.w, cd);
+                } else {
+                    c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, gi.w}, c2s);   // gi.w == 1
                 }
+                const v2f t = hu * dc;
+                s1 += t;
+                s2 = __builtin_elementwise_fma(t, dc, s2);
+                sxy = fmaf(t.x, dc.y, sxy);
             }
             const float o = b.y;   // [3DGS-grad] dL/dG = opacity * dL/dalpha (the 0.99 clamp is straight-through)
             float4* __restrict__ out = reinterpret_cast<float4*>(gpair + (size_t)pair_slot(gid) * kRec);
-            out[0] = make_float4(-o * (a.z * Sux + a.w * Suy), -o * (b.x * Suy + a.w * Sux), -0.5f * o * Suxx,
-                                 -o * Suxy);
-            out[1] = make_float4(-0.5f * o * Suyy, Su, c0, c1);
-            out[2] = make_float4(c2, cd, 0.f, 0.f);
+            out[0] = make_float4(-o * (a.z * s1.x + a.w * s1.y), -o * (b.x * s1.y + a.w * s1.x), -0.5f * o * s2.x,
+                                 -o * sxy);
+            out[1] = make_float4(-0.5f * o * s2.y, c2s.y, c01.x, c01.y);
+            out[2] = make_float4(c2s.x, cd, 0.f, 0.f);
         }
         hi -= (uint32_t)cnt;
         __syncthreads();                         // round over: LDS scratch may be reused
