@@ -222,6 +222,102 @@ __global__ __launch_bounds__(THREADS) void spf_sort_tiles_lds_kernel(const uint3
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) p[i] = s[i];
 }
 
+// ---- per-tile sort in registers: one wave per tile, E keys per lane -----------------------------------
+// Lists of up to 64*E entries.  Lane l holds elements E*l .. E*l+E-1 (missing ones are +infinity), so the steps of
+// the network with partner distance j < E are compare-exchanges between a lane's own registers, the others are lane
+// exchanges (partner lane = lane ^ mask: DPP / ds_bpermute, no LDS storage, no barrier).  Same all-ascending
+// network as above, fixed size 64*E: keys are unique, so the result is the same permutation the LDS kernel produces.
+__device__ __forceinline__ void cswap_u64(uint64_t& a, uint64_t& b) {
+    const bool sw = a > b;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo;
+    b = hi;
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, kWave);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, kWave);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int E>
+__device__ __forceinline__ void sort_tile_in_wave(uint64_t* __restrict__ p, uint32_t n) {
+    const int lane = threadIdx.x & (kWave - 1);
+    uint64_t r[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const uint32_t e = (uint32_t)(E * lane + s);
+        r[s] = e < n ? p[e] : ~0ull;
+    }
+    // merges that stay inside a lane (k <= E)
+#pragma unroll
+    for (int k = 2; k <= E; k <<= 1) {
+#pragma unroll
+        for (int s = 0; s < E; ++s)
+            if (s < (s ^ (k - 1))) cswap_u64(r[s], r[s ^ (k - 1)]);
+#pragma unroll
+        for (int j = k >> 2; j > 0; j >>= 1)
+#pragma unroll
+            for (int s = 0; s < E; ++s)
+                if (s < (s ^ j)) cswap_u64(r[s], r[s ^ j]);
+    }
+    // merges across lanes (k = 2E .. 64E); a lane keeps the smaller key of a pair iff it is the lower lane
+#pragma unroll
+    for (int k = 2 * E; k <= kWave * E; k <<= 1) {
+        {
+            const int mask = k / E - 1;                       // first step of a merge: partner index = i ^ (k-1)
+            const bool lower = (lane & ((mask + 1) >> 1)) == 0;
+            uint64_t o[E];
+#pragma unroll
+            for (int s = 0; s < E; ++s) o[s] = shfl_xor_u64(r[E - 1 - s], mask);
+#pragma unroll
+            for (int s = 0; s < E; ++s) r[s] = ((o[s] < r[s]) == lower) ? o[s] : r[s];
+        }
+#pragma unroll
+        for (int j = k >> 2; j >= E; j >>= 1) {
+            const int mask = j / E;
+            const bool lower = (lane & mask) == 0;
+#pragma unroll
+            for (int s = 0; s < E; ++s) {
+                const uint64_t o = shfl_xor_u64(r[s], mask);
+                r[s] = ((o < r[s]) == lower) ? o : r[s];
+            }
+        }
+#pragma unroll
+        for (int j = E >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int s = 0; s < E; ++s)
+                if (s < (s ^ j)) cswap_u64(r[s], r[s ^ j]);
+    }
+#pragma unroll
+    for (int s = 0; s < E; ++s) {
+        const uint32_t e = (uint32_t)(E * lane + s);
+        if (e < n) p[e] = r[s];
+    }
+}
+
+// Four tiles per 256-thread block (one per wave).  SMALL: lists of 2..512 entries, keys-per-lane chosen per tile;
+// otherwise one size class (lo, 64*E].
+template <int E, bool SMALL>
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint32_t* __restrict__ tile_start,
+                                                                     const uint32_t* __restrict__ counters,
+                                                                     uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                     uint32_t lo, int RT) {
+    if (counters[0] > capacity) return;
+    const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (tile >= RT) return;
+    const uint32_t b = tile_start[tile];
+    const uint32_t n = tile_start[tile + 1] - b;
+    if (n <= lo || n > (uint32_t)(kWave * E)) return;
+    if (SMALL) {
+        if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
+        else if (n <= 4u * kWave) sort_tile_in_wave<4>(pairs + b, n);
+        else sort_tile_in_wave<8>(pairs + b, n);
+    } else {
+        sort_tile_in_wave<E>(pairs + b, n);
+    }
+}
+
 // Lists longer than the LDS classes: same network straight on global memory, one 1024-thread
 // block per tile (L2-resident; slow but exact -- a correctness fallback for degenerate scenes
 // where one tile holds > 16384 Gaussians).
@@ -272,14 +368,21 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     return hipGetLastError();
 }
 
-// Size classes: (1, 2048], (2048, 8192], (8192, 16384], > 16384 (global fallback).
+// Size classes: (1, 512] (16, 32] x 64 registers: one wave per tile; (2048, 8192], (8192, 16384]: one 1024-thread
+// block per tile in LDS; > 16384: global fallback.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
-    if (mx > 1) {
-        const uint32_t cap = mx <= 512 ? 512 : 2048;
-        spf_sort_tiles_lds_kernel<256><<<RT, 256, cap * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1, cap);
-    }
+    const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
+    if (mx > 1)
+        spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
+                                                                          capacity, 1, RT);
+    if (mx > 512)
+        spf_sort_tiles_wave_kernel<16, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
+                                                                            capacity, 512, RT);
+    if (mx > 1024)
+        spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
+                                                                            capacity, 1024, RT);
     if (mx > 2048)
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {
