@@ -101,7 +101,11 @@ def main():
     ap.add_argument("--s-mult", type=float, default=1.0)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync-free", action="store_true", help="fixed pair-buffer capacity, no per-step read-back")
+    ap.add_argument("--exact", action="store_true",
+                    help="size the pair buffer from a 16-byte device->host read-back in every step (one host sync per "
+                         "step) instead of the default: a PairBudget planned from the first step, verified on the "
+                         "device, checked once after the timed region")
+    ap.add_argument("--sync-free", action="store_true", help="(default now; kept for compatibility)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
                          "single-GPU box together with --one-device)")
@@ -180,8 +184,9 @@ def main():
     torch.cuda.synchronize(dev)
     D_total = spf.last_forward_stats()["num_pairs"]
     log(f"first step done: D={D_total}, max tile list={spf.last_forward_stats()['max_tile_list']}")
-    if args.sync_free or args.graph:
-        max_pairs = int(D_total * 1.25) + 1024
+    if not args.exact or args.graph:
+        max_pairs = spf.plan_pair_budget(slack=1.25, check="deferred")
+        log(f"planned budget: {max_pairs}")
     run = step
     eager_survey = None
     if args.graph:
@@ -220,6 +225,8 @@ def main():
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     stages = _lib.stage_times()
     _lib.stage_timing_enable(False)
+    if max_pairs is not None and spf.last_plan_flags() != 0:
+        raise RuntimeError(f"the planned pair budget did not hold (flags {spf.last_plan_flags()}): results invalid")
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -252,7 +259,8 @@ def main():
                                    "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
-                       "s_mult": args.s_mult, "pair_buffer": "capacity" if (args.sync_free or args.graph) else "exact",
+                       "s_mult": args.s_mult, "pair_buffer": "exact (read-back per step)" if max_pairs is None else
+                                      f"planned from step 0 (x1.25 = {max_pairs.capacity} pairs), verified on device",
                        "launch": "hip-graph replay" if args.graph else "eager",
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},

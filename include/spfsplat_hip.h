@@ -158,11 +158,16 @@ int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float
 int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream);
 
 /* Forward, stage 2: bin (Gaussian, tile) pairs into per-tile lists, depth-sort every list and
- * composite.  `capacity` = number of uint64 entries st->pairs can hold; `max_tile_hint` = host copy
- * of counters[1] (0 = unknown: every sort size class is launched); `dense_tiles_hint` = host copy of counters[3]
- * (SPF_UNKNOWN = unknown: both the sparse and the dense render kernels are launched; each tile is rendered by
- * exactly one of them either way).  If D > capacity nothing is
- * rendered, counters[2] is set to 1 and the images are left untouched. */
+ * composite.  `capacity` = number of uint64 entries st->pairs can hold.  `max_tile_hint` = upper bound of the
+ * longest tile list the caller assumes (exact mode: host copy of counters[1]; 0 = unknown: every sort size class
+ * is launched).  `dense_tiles_hint` = number of dense tiles the caller assumes (exact mode: host copy of
+ * counters[3]; 0 = none, S*V*tiles = all, SPF_UNKNOWN or anything in between: both the sparse and the dense render
+ * kernels are launched; each tile is rendered by exactly one of them either way).
+ * A caller that PLANS the call from an earlier one instead of reading the counters back (no device->host
+ * synchronisation; capturable in a HIP graph) passes its assumptions here and they are checked on the device:
+ * counters[2] = 0 if the plan held, else a bit mask: 1 = D > capacity (nothing was rendered, images untouched),
+ * 2 = a tile list longer than max_tile_hint (left unsorted), 4 = dense_tiles_hint of 0 / all was wrong (some tiles
+ * were not rendered).  With a non-zero flag the outputs of this call and of the matching backward are invalid. */
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
                               uint64_t capacity, uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream);
 

@@ -8,15 +8,15 @@
 
 namespace spf {
 hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&, int, int, hipStream_t);
-hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, hipStream_t);
+hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, uint64_t, hipStream_t);
 hipError_t launch_tile_scan(const SpfState&, int, int, uint32_t, hipStream_t);
 uint32_t dense_threshold();
-hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, hipStream_t);
+hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, hipStream_t);
 hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
                              uint32_t, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
-                             hipStream_t);
+                             uint64_t, hipStream_t);
 hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
@@ -188,7 +188,7 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
     {
         StageScope t(SPF_STAGE_BIN, stream);
-        SPF_HIP(spf::launch_bin_pairs(*d, *st, capacity, T, tiles_x, stream));
+        SPF_HIP(spf::launch_bin_pairs(*d, *st, capacity, T, tiles_x, max_tile_hint, dense_tiles_hint, stream));
     }
     {
         StageScope t(SPF_STAGE_SORT, stream);
@@ -221,11 +221,11 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     (void)capacity;   // every pair record is written exactly once by its tile: no memset of gpair
     {
         StageScope t(SPF_STAGE_RENDER_BWD, stream);
-        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, dense_tiles_hint, stream));
+        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, dense_tiles_hint, capacity, stream));
     }
     {
         StageScope t(SPF_STAGE_PROJECT_BWD, stream);
-        SPF_HIP(spf::launch_project_bwd(*d, *in, *st, *g, spf_raster_view_partial_blocks(d->G), stream));
+        SPF_HIP(spf::launch_project_bwd(*d, *in, *st, *g, spf_raster_view_partial_blocks(d->G), capacity, stream));
     }
     return SPF_OK;
 }

@@ -119,17 +119,26 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
                                                                uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                const uint32_t* __restrict__ blk_base,
                                                                uint32_t* __restrict__ pair_off,
-                                                               int G, int T, int tiles_x, int lds) {
+                                                               int G, int T, int tiles_x, int lds,
+                                                               uint32_t max_tile_hint, uint32_t dense_hint,
+                                                               uint32_t RT) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases
     __shared__ uint32_t s_wtot[4];
     uint32_t* s_cnt = s_bin;
     uint32_t* s_base = s_bin + T;
     const int r = blockIdx.y;
     const int g = blockIdx.x * kBlock + threadIdx.x;
-    if (counters[0] > capacity) {
-        if (r == 0 && g == 0) counters[2] = 1;
-        return;
+    // The host may launch this chain from a PLAN (capacity, longest list, dense-tile census of an earlier call)
+    // instead of reading the counters back; the plan is checked here, on the device.  Flag bits: 1 = pair buffer too
+    // small (nothing is rendered), 2 = a tile list is longer than planned (it was not sorted), 4 = the planned
+    // sparse/dense kernel choice missed tiles (they were not rendered).
+    if (r == 0 && g == 0) {
+        uint32_t flag = counters[0] > capacity ? 1u : 0u;
+        if (max_tile_hint != 0u && counters[1] > max_tile_hint) flag |= 2u;
+        if ((dense_hint == 0u && counters[3] != 0u) || (dense_hint == RT && counters[3] != RT)) flag |= 4u;
+        if (flag) counters[2] = flag;
     }
+    if (counters[0] > capacity) return;
     const bool live = g < G;
     const size_t rg = (size_t)r * G + (live ? g : 0);
     const uint32_t rc = live ? rect[rg] : 0u;
@@ -359,12 +368,12 @@ hipError_t launch_tile_scan(const SpfState& st, int RT, int nb, uint32_t dense_t
 }
 
 hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
-                            hipStream_t stream) {
+                            uint32_t max_tile_hint, uint32_t dense_hint, hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
         st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
-        d.G, T, tiles_x, lds);
+        d.G, T, tiles_x, lds, max_tile_hint, dense_hint, (uint32_t)(d.S * d.V * T));
     return hipGetLastError();
 }
 

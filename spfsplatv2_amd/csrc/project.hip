@@ -367,9 +367,12 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
 // Backward.  Same decomposition; per-view viewmatrix partials are reduced per block into
 // vpartial[r][block][12] (no float atomics -> deterministic), summed by spf_view_reduce_kernel.
 // ------------------------------------------------------------------------------------------
+constexpr int kViewChunk = 64;
+
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
-                                                                  SpfGrads gr, int nblk) {
+                                                                  SpfGrads gr, int nblk, uint64_t capacity) {
+    if (st.counters[0] > capacity) return;   // a planned pair buffer was too small: nothing was rendered, no pair records
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     const bool live = g < d.G;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
 #pragma unroll
     for (int k = 0; k < NB; ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
 
-    __shared__ float s_part[4][12];
+    extern __shared__ float s_part[];        // [min(V, kViewChunk)][4 waves][12]: viewmatrix partials of a chunk of views
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
     for (int v = 0; v < d.V; ++v) {
@@ -412,13 +415,15 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
 #pragma unroll
         for (int k = 0; k < 12; ++k) dV[k] = 0.f;
 
-        const bool vis = live && st.radii[rg] > 0;
+        // a Gaussian without (Gaussian, tile) pairs in this view (culled: rect == 0, or no pixel centre in its
+        // cull disc) received no gradient record -> nothing to chain
+        const uint32_t rc = live ? st.rect[rg] : 0u;
+        const int npair = (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
+        const bool vis = npair > 0;
         if (vis) {
             // sum the screen-space gradient records of this Gaussian's (Gaussian, tile) pairs
             float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
             {
-                const uint32_t rc = st.rect[rg];
-                const int npair = (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
                 const float4* __restrict__ gp =
                     reinterpret_cast<const float4*>(gr.gpair + (size_t)st.pair_off[rg] * kRec);
                 for (int i = 0; i < npair; ++i) {
@@ -582,18 +587,25 @@ __global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfI
 #pragma unroll
             for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
         }
-        // ---- block reduction of the 12 viewmatrix partials for this view ----
+        // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
         if (gr.dL_dviewmatrix) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 const float tot = wave_sum(dV[k]);
-                if (lane == 0) s_part[wave][k] = tot;
+                if (lane == 0) s_part[((v & (kViewChunk - 1)) * 4 + wave) * 12 + k] = tot;
             }
-            __syncthreads();
-            if (threadIdx.x < 12)
-                gr.vpartial[((size_t)r * nblk + blockIdx.x) * 12 + threadIdx.x] =
-                    s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-            __syncthreads();
+            // the four wave totals are combined once per chunk of kViewChunk views (normally: once, after the loop)
+            if (((v + 1) & (kViewChunk - 1)) == 0 || v + 1 == d.V) {
+                const int v0 = v & ~(kViewChunk - 1);
+                __syncthreads();
+                for (int i = threadIdx.x; i < (v + 1 - v0) * 12; i += kBlock) {
+                    const int vi = i / 12, k = i - 12 * vi;
+                    const float* __restrict__ sp = s_part + vi * 48 + k;
+                    gr.vpartial[((size_t)(s * d.V + v0 + vi) * nblk + blockIdx.x) * 12 + k] =
+                        sp[0] + sp[12] + sp[24] + sp[36];
+                }
+                if (v + 1 < d.V) __syncthreads();
+            }
         }
     }
     if (!live) return;
@@ -685,8 +697,9 @@ static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDim
 }
 template <int DEG, bool NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
-                          const SpfGrads& g, int nblk) {
-    spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), 0, stream>>>(d, in, st, g, nblk);
+                          const SpfGrads& g, int nblk, uint64_t capacity) {
+    spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float), stream>>>(d, in, st, g,
+                                                                                                          nblk, capacity);
 }
 #define SPF_DISPATCH_DEG(FN, ...)                                        \
     switch (deg * 2 + (native ? 1 : 0)) {                                \
@@ -714,11 +727,11 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
 }
 
 hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
-                              int nblk, hipStream_t stream) {
+                              int nblk, uint64_t capacity, hipStream_t stream) {
     dim3 grid(nblk, d.S);
     const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
     const bool native = d.sh_layout != 0;
-    SPF_DISPATCH_DEG(project_bwd_t, grid, stream, d, in, st, g, nblk)
+    SPF_DISPATCH_DEG(project_bwd_t, grid, stream, d, in, st, g, nblk, capacity)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (g.dL_dviewmatrix) {

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
     const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off, float* __restrict__ gpair, int G, int H,
-    int W, int T, int tiles_x, int RT, uint32_t dense_thr) {
+    int W, int T, int tiles_x, int RT, uint32_t dense_thr, const uint32_t* __restrict__ counters, uint64_t capacity) {
+    if (counters[0] > capacity) return;      // the forward did not render (pair buffer too small): nothing to replay
     __shared__ float4 s_p0[kStage];
     __shared__ float2 s_p1[kStage];
     __shared__ float4 s_p2[kStage];
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const uint32_t wmax = wave_max_u32(rowmax);
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
-    const uint32_t bmax = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+    const uint32_t bmax = min(n, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));   // (<= n by construction; the clamp only matters for a tile a failed plan left unrendered)
     // Entries behind every pixel's last contributor get a zero record (every pair slot is written exactly once,
     // so the scratch needs no memset).
     {
@@ -614,7 +615,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
-    float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
+    float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr_arg,
+    const uint32_t* __restrict__ counters, uint64_t capacity) {
+    if (counters[0] > capacity) return;      // the forward did not render (pair buffer too small): nothing to replay
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;
     __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
     __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const uint32_t wmax = wave_max_u32(ncon);
     if (lane == 0) s_w[wave] = wmax;
     __syncthreads();
-    const uint32_t bmax = max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3]));
+    const uint32_t bmax = min(n, max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3])));   // (clamp: see the rows kernel)
     if (ABLATE(2)) { if (tail == 123.f) gpair[0] = T_final; return; }
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -936,28 +939,31 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
 
 template <bool DG>
 static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                                int tiles_x, int RT, int grid, uint32_t dense_hint, hipStream_t stream) {
+                                int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity,
+                                hipStream_t stream) {
     if (dense_hint != (uint32_t)RT)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
             g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
 #ifdef SPF_ABLATE
-            dense_threshold() | ((uint32_t)g_ablate_host << 28));
+            dense_threshold() | ((uint32_t)g_ablate_host << 28),
 #else
-            dense_threshold());
+            dense_threshold(),
 #endif
+            st.counters, capacity);
     if (dense_hint != 0u)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters,
+            capacity);
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                             int tiles_x, uint32_t dense_hint, hipStream_t stream) {
+                             int tiles_x, uint32_t dense_hint, uint64_t capacity, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, stream);
-    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, stream);
+    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, stream);
+    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, stream);
     return hipGetLastError();
 }
 

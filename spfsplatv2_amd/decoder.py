@@ -99,7 +99,7 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  background_color: Tensor, gaussian_means: Tensor, gaussian_sh_coefficients: Tensor,
                  gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
                  scale_invariant: bool = True, use_sh: bool = True, enable_cov_grad: bool = False,
-                 enable_sh_grad: bool = False, max_pairs: Optional[int] = None):
+                 enable_sh_grad: bool = False, max_pairs=None):
     """Batched form of ``render_cuda``: b scenes x v views sharing each scene's Gaussians.
 
     extrinsics [b,v,4,4] (camera-to-world), intrinsics [b,v,3,3] (normalised), near/far [b,v],

@@ -23,10 +23,53 @@ from torch import Tensor
 from . import _lib
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward",
-           "last_forward_stats"]
+           "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags"]
 
 _REC = 12
 _stats: dict = {}
+_last_counters: list = [None]      # device counters of the most recent planned (max_pairs=...) forward call
+
+
+class PairBudget(NamedTuple):
+    """A PLAN for the (Gaussian, tile) pair buffer, taken from an earlier call on similar inputs, so that a call
+    needs no device->host read-back (and can be captured in a HIP graph).  The plan is verified on the device:
+    see ``last_plan_flags``.
+
+    capacity       pair-buffer entries to allocate
+    max_tile_list  assumed upper bound of the longest tile list (0 = unknown: all sort size classes are launched)
+    dense_tiles    None = unknown (both render kernels are launched); 0 = no dense tile; -1 = every tile is dense
+    check          "backward": the backward pass reads the flag (one host sync) and raises if the plan failed;
+                   "deferred": the library never reads it -- call ``last_plan_flags()`` when convenient
+    """
+    capacity: int
+    max_tile_list: int = 0
+    dense_tiles: Optional[int] = None
+    check: str = "backward"
+
+
+_SORT_CLASSES = (128, 256, 512, 1024, 2048, 8192, 16384)
+
+
+def plan_pair_budget(stats: Optional[dict] = None, slack: float = 1.25, check: str = "backward") -> PairBudget:
+    """Budget for the next calls from the statistics of an exact-mode call (default: the most recent one, see
+    ``last_forward_stats``): ``slack`` x the pairs it produced, the list-length class its longest list (x slack) falls
+    in, and its sparse/dense tile census when that was one-sided."""
+    st = dict(_stats if stats is None else stats)
+    if "num_pairs" not in st:
+        raise RuntimeError("plan_pair_budget needs the statistics of an exact-mode forward call (max_pairs=None)")
+    want = int(st["max_tile_list"] * slack) + 1
+    max_tile = next((c for c in _SORT_CLASSES if c >= want), 0)
+    dense = 0 if st.get("dense_tiles", 1) == 0 else (-1 if st.get("dense_tiles") == st.get("tiles") else None)
+    return PairBudget(int(st["num_pairs"] * slack) + 1024, max_tile, dense, check)
+
+
+def last_plan_flags() -> int:
+    """Device-side verdict on the plan of the most recent planned forward call (synchronises with the device):
+    0 = the plan held; bit 1 = pair buffer too small, bit 2 = a tile list longer than planned, bit 4 = dense/sparse
+    assumption wrong.  Non-zero: that call's outputs (and its backward's gradients) are invalid -- re-run it in
+    exact mode or with a larger budget."""
+    c = _last_counters[0]
+    return 0 if c is None else int(c[2])
 
 
 def last_forward_stats() -> dict:
@@ -111,7 +154,12 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         capacity = D
         _stats.update(num_pairs=D, max_tile_list=max_tile, dense_tiles=dense, tiles=R * T)
     else:
-        capacity, max_tile, dense = int(max_pairs), 0, 0xFFFFFFFF
+        plan = max_pairs if isinstance(max_pairs, PairBudget) else PairBudget(int(max_pairs))
+        capacity, max_tile = int(plan.capacity), int(plan.max_tile_list)
+        dense = 0xFFFFFFFF if plan.dense_tiles is None else (R * T if plan.dense_tiles < 0 else int(plan.dense_tiles))
+        if 0 < dense < R * T:
+            dense = 0xFFFFFFFF      # only "none" and "all" are assumptions the device can check
+        _last_counters[0] = counters
     pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
     st.pairs = _ptr(pairs)
     out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
@@ -131,6 +179,13 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(final_T), _ptr(n_contrib))
 
 
+def _plan_mode(max_pairs) -> int:
+    """0 = exact mode, 1 = planned and verified in backward, 2 = planned, verification left to the caller."""
+    if max_pairs is None:
+        return 0
+    return 2 if isinstance(max_pairs, PairBudget) and max_pairs.check == "deferred" else 1
+
+
 @_on_device_of_first_arg
 def _backward_impl(inputs, state, geom, grads_out, want):
     """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
@@ -143,9 +198,15 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     T = lib.spf_raster_num_tiles(H, W)
     # (a device->host read is illegal while a HIP graph is being captured: graph users check the flag themselves
     # with `pair_buffer_overflowed` after a replay)
-    if capacity_mode and not torch.cuda.is_current_stream_capturing() and int(tiles[4 * R * T + 1 + 2]) != 0:
-        raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
-                            f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
+    if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
+        flag = int(tiles[4 * R * T + 1 + 2])
+        if flag & 1:
+            raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
+                                f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
+        if flag:
+            raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = a tile list longer "
+                                f"than planned ({int(tiles[4 * R * T + 2])}), 4 = dense-tile assumption wrong); "
+                                "outputs are invalid")
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout))
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
@@ -183,7 +244,7 @@ class _RasterizeBatch(torch.autograd.Function):
                                            max_pairs)
         S, G, _ = means3D.shape
         ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
-                    float(scale_modifier), max_pairs is not None, dense, 0)
+                    float(scale_modifier), _plan_mode(max_pairs), dense, 0)
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
@@ -230,7 +291,7 @@ class _DecoderRender(torch.autograd.Function):
                                            bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout)
         G = means3D.shape[1]
         K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
-        ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, max_pairs is not None, dense, int(sh_layout))
+        ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
                               *state, near)
@@ -283,7 +344,7 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
                  shs: Optional[Tensor], colors_precomp: Optional[Tensor], bg: Tensor,
                  image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
-                 enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs: Optional[int] = None,
+                 enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs=None,
                  sh_layout: str = "gk3"):
     """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
 
@@ -326,7 +387,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
                     viewmatrix: Tensor, projmatrix: Tensor, tanfov: Tensor, bg: Tensor,
                     image_height: int, image_width: int, sh_degree: int, scale_modifier: float = 1.0,
                     enable_cov_grad: bool = True, enable_sh_grad: bool = True,
-                    means2D: Optional[Tensor] = None, max_pairs: Optional[int] = None,
+                    means2D: Optional[Tensor] = None, max_pairs=None,
                     view_scale: Optional[Tensor] = None):
     """Render S scenes x V views.
 
@@ -344,7 +405,9 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     NDC-scaled screen-space gradient of every Gaussian centre (cuda_splatting.py:98-102,130).
 
     ``max_pairs``: None = exact mode (one tiny device->host read per call to size the pair buffer);
-    an integer = sync-free mode with a fixed pair-buffer capacity (overflow raises in backward).
+    an integer or a ``PairBudget`` (see ``plan_pair_budget``) = planned mode, no read-back in the forward pass: the
+    plan is verified on the device and a failed plan raises in backward (``check="backward"``) or is reported by
+    ``last_plan_flags()`` (``check="deferred"``, fully sync-free and graph-capturable).
     """
     if (shs is None) == (colors_precomp is None):
         raise RuntimeError("provide exactly one of shs / colors_precomp")

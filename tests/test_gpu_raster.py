@@ -76,6 +76,44 @@ def test_sync_free_capacity_mode_and_overflow(hip_lib):
         util.run_product(batch, background=bg, scale_invariant=si, max_pairs=max(D // 2, 1))
 
 
+def test_planned_pair_budget_is_verified_on_the_device(hip_lib):
+    """PairBudget: a call planned from an earlier one needs no read-back; the device checks the plan (flag bits
+    1 = capacity, 2 = longest list, 4 = dense/sparse census) and a failed plan is never silent."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd._lib import SpfError
+    kw, bg, si = CASES["k4_multiview"]
+    batch = syn.make_batch(**kw)
+    exact = util.run_product(batch, background=bg, scale_invariant=si)
+    st = exact["stats"]
+    plan = spf.plan_pair_budget(st, slack=1.25, check="deferred")
+    assert plan.capacity >= st["num_pairs"] and plan.max_tile_list >= st["max_tile_list"]
+    planned = util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan)
+    assert spf.last_plan_flags() == 0
+    assert torch.equal(exact["color"], planned["color"]) and torch.equal(exact["depth"], planned["depth"])
+    for n in util.GRAD_NAMES:
+        assert util.rel_linf(planned["grads"][n], exact["grads"][n]) < 1e-5, n     # (LDS float atomics in dense tiles)
+
+    # a list longer than planned: flag 2, reported (deferred) or raised in backward
+    short = plan._replace(max_tile_list=max(st["max_tile_list"] // 2, 1))
+    util.run_product(batch, background=bg, scale_invariant=si, max_pairs=short)
+    assert spf.last_plan_flags() & 2
+    with pytest.raises(SpfError, match="did not hold"):
+        util.run_product(batch, background=bg, scale_invariant=si, max_pairs=short._replace(check="backward"))
+
+    # wrong dense/sparse census: flag 4
+    some_dense = 0 < st["dense_tiles"] < st["tiles"]
+    wrong = plan._replace(dense_tiles=-1 if st["dense_tiles"] == 0 or some_dense else 0)
+    util.run_product(batch, background=bg, scale_invariant=si, max_pairs=wrong)
+    assert spf.last_plan_flags() & 4
+
+    # too few pairs: flag 1
+    util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan._replace(capacity=st["num_pairs"] // 2))
+    assert spf.last_plan_flags() & 1
+    # and a good plan afterwards is clean again
+    util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan)
+    assert spf.last_plan_flags() == 0
+
+
 def test_drop_in_rasterizer_surface(hip_lib):
     """GaussianRasterizationSettings / GaussianRasterizer exactly as the reference calls them
     (cuda_splatting.py:105-138) vs the oracle on the same arguments."""
