@@ -77,7 +77,7 @@ struct StageScope {
 };
 
 const char* kStageKernel[SPF_STAGE_COUNT] = {
-    "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_lds_kernel",
+    "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_wave_kernel",
     "spf_render_fwd_lists_kernel", "spf_render_bwd_lists_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
 
 int check_dims(const SpfDims* d) {

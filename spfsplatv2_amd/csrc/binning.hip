@@ -243,10 +243,74 @@ __device__ __forceinline__ void cswap_u64(uint64_t& a, uint64_t& b) {
     b = hi;
 }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, kWave);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, kWave);
-    return ((uint64_t)hi << 32) | lo;
+// value of lane (l ^ MASK).  Most masks of the network are a DPP pattern (a VALU move inside a row of 16 lanes);
+// only 16 / 31 / 32 / 63 go through ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true);   // every lane has a source
+}
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v) {
+    if constexpr (MASK == 1) return dpp_mov_u32<0xB1>(v);                           // quad_perm [1,0,3,2]
+    else if constexpr (MASK == 2) return dpp_mov_u32<0x4E>(v);                      // quad_perm [2,3,0,1]
+    else if constexpr (MASK == 3) return dpp_mov_u32<0x1B>(v);                      // quad_perm [3,2,1,0]
+    else if constexpr (MASK == 4) return dpp_mov_u32<0x1B>(dpp_mov_u32<0x141>(v));  // (l ^ 7) ^ 3
+    else if constexpr (MASK == 7) return dpp_mov_u32<0x141>(v);                     // row_half_mirror
+    else if constexpr (MASK == 8) return dpp_mov_u32<0x128>(v);                     // row_ror:8
+    else if constexpr (MASK == 15) return dpp_mov_u32<0x140>(v);                    // row_mirror
+    else return (uint32_t)__shfl_xor((int)v, MASK, kWave);
+}
+template <int MASK>
+__device__ __forceinline__ uint64_t lane_xor_u64(uint64_t v) {
+    return ((uint64_t)lane_xor_u32<MASK>((uint32_t)(v >> 32)) << 32) | lane_xor_u32<MASK>((uint32_t)v);
+}
+
+// compare-exchanges between a lane's own keys: partner distance J, or the mirror step of a merge of size K
+template <int E, int J>
+__device__ __forceinline__ void thread_steps_down(uint64_t (&r)[E]) {
+    if constexpr (J >= 1) {
+#pragma unroll
+        for (int s = 0; s < E; ++s)
+            if (s < (s ^ J)) cswap_u64(r[s], r[s ^ J]);
+        thread_steps_down<E, J / 2>(r);
+    }
+}
+template <int E, int K>
+__device__ __forceinline__ void merges_inside(uint64_t (&r)[E]) {
+    if constexpr (K <= E) {
+#pragma unroll
+        for (int s = 0; s < E; ++s)
+            if (s < (s ^ (K - 1))) cswap_u64(r[s], r[s ^ (K - 1)]);
+        thread_steps_down<E, K / 4>(r);
+        merges_inside<E, 2 * K>(r);
+    }
+}
+// exchange with lane (l ^ MASK); a lane keeps the smaller key of a pair iff it is the lower lane.  MIRROR: first step
+// of a merge (partner index = i ^ (k-1)): the partner's keys come in reverse order.
+template <int E, int MASK, bool MIRROR>
+__device__ __forceinline__ void lane_step(uint64_t (&r)[E], int lane) {
+    const bool lower = (lane & (MIRROR ? (MASK + 1) >> 1 : MASK)) == 0;
+    uint64_t o[E];
+#pragma unroll
+    for (int s = 0; s < E; ++s) o[s] = lane_xor_u64<MASK>(r[MIRROR ? E - 1 - s : s]);
+#pragma unroll
+    for (int s = 0; s < E; ++s) r[s] = ((o[s] < r[s]) == lower) ? o[s] : r[s];
+}
+template <int E, int J>
+__device__ __forceinline__ void lane_steps_down(uint64_t (&r)[E], int lane) {
+    if constexpr (J >= E) {
+        lane_step<E, J / E, false>(r, lane);
+        lane_steps_down<E, J / 2>(r, lane);
+    }
+}
+template <int E, int K>
+__device__ __forceinline__ void merges_across(uint64_t (&r)[E], int lane) {
+    if constexpr (K <= kWave * E) {
+        lane_step<E, K / E - 1, true>(r, lane);
+        lane_steps_down<E, K / 4>(r, lane);
+        thread_steps_down<E, E / 2>(r);
+        merges_across<E, 2 * K>(r, lane);
+    }
 }
 
 template <int E>
@@ -258,46 +322,8 @@ __device__ __forceinline__ void sort_tile_in_wave(uint64_t* __restrict__ p, uint
         const uint32_t e = (uint32_t)(E * lane + s);
         r[s] = e < n ? p[e] : ~0ull;
     }
-    // merges that stay inside a lane (k <= E)
-#pragma unroll
-    for (int k = 2; k <= E; k <<= 1) {
-#pragma unroll
-        for (int s = 0; s < E; ++s)
-            if (s < (s ^ (k - 1))) cswap_u64(r[s], r[s ^ (k - 1)]);
-#pragma unroll
-        for (int j = k >> 2; j > 0; j >>= 1)
-#pragma unroll
-            for (int s = 0; s < E; ++s)
-                if (s < (s ^ j)) cswap_u64(r[s], r[s ^ j]);
-    }
-    // merges across lanes (k = 2E .. 64E); a lane keeps the smaller key of a pair iff it is the lower lane
-#pragma unroll
-    for (int k = 2 * E; k <= kWave * E; k <<= 1) {
-        {
-            const int mask = k / E - 1;                       // first step of a merge: partner index = i ^ (k-1)
-            const bool lower = (lane & ((mask + 1) >> 1)) == 0;
-            uint64_t o[E];
-#pragma unroll
-            for (int s = 0; s < E; ++s) o[s] = shfl_xor_u64(r[E - 1 - s], mask);
-#pragma unroll
-            for (int s = 0; s < E; ++s) r[s] = ((o[s] < r[s]) == lower) ? o[s] : r[s];
-        }
-#pragma unroll
-        for (int j = k >> 2; j >= E; j >>= 1) {
-            const int mask = j / E;
-            const bool lower = (lane & mask) == 0;
-#pragma unroll
-            for (int s = 0; s < E; ++s) {
-                const uint64_t o = shfl_xor_u64(r[s], mask);
-                r[s] = ((o < r[s]) == lower) ? o : r[s];
-            }
-        }
-#pragma unroll
-        for (int j = E >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int s = 0; s < E; ++s)
-                if (s < (s ^ j)) cswap_u64(r[s], r[s ^ j]);
-    }
+    merges_inside<E, 2>(r);             // merges of size <= E stay inside a lane
+    merges_across<E, 2 * E>(r, lane);   // sizes 2E .. 64E
 #pragma unroll
     for (int s = 0; s < E; ++s) {
         const uint32_t e = (uint32_t)(E * lane + s);

@@ -234,6 +234,10 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self.enable_sh_grad = cfg.enable_sh_grad
         self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
                              persistent=False)
+        # None: every call sizes its pair buffer from a 16-byte read-back.  A training loop may set a
+        # ``spfsplatv2_amd.plan_pair_budget(...)`` here after one exact call: no call waits for the device any more
+        # (the plan is verified on the device, see rasterizer.PairBudget).
+        self.max_pairs = None
 
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], depth_mode: DepthRenderingMode | None = None) -> DecoderOutput:
@@ -242,7 +246,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             extrinsics, intrinsics, near, far, image_shape, self.background_color,
             gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
             scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
-            enable_sh_grad=self.enable_sh_grad)
+            enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs)
         depth = depth[:, :, 0]
         if self.make_scale_invariant:
             depth = depth * near[:, :, None, None]

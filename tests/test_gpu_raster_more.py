@@ -194,3 +194,20 @@ def test_full_size_gradient_checksum(hip_lib, c2_batch):
     i2, _, _ = _render(b, opac=op)
     i2.sum().backward()
     assert bool(torch.isfinite(op.grad).all()) and float(op.grad.abs().max()) > 0
+
+
+def test_decoder_module_with_a_planned_budget(hip_lib):
+    """DecoderSplattingCUDA: one exact call, then `decoder.max_pairs = plan_pair_budget(...)` -- same pixels, no
+    read-back, the plan verified on the device."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    batch = syn.make_batch("TEST", 2, 3, seed=31, s_mult=3.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.1, 0.2, 0.3],
+                                                    make_scale_invariant=True, enable_cov_grad=True,
+                                                    enable_sh_grad=True)).cuda()
+    g = dec.Gaussians(batch.means, batch.covariances, batch.rotations, batch.scales, batch.harmonics, batch.opacities)
+    exact = d(g, batch.extrinsics, batch.intrinsics, batch.near, batch.far, batch.image_shape)
+    d.max_pairs = spf.plan_pair_budget(check="deferred")
+    planned = d(g, batch.extrinsics, batch.intrinsics, batch.near, batch.far, batch.image_shape)
+    assert spf.last_plan_flags() == 0
+    assert torch.equal(exact.color, planned.color) and torch.equal(exact.depth, planned.depth)
