@@ -216,6 +216,13 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     }
 }
 
+#ifdef SPF_ABLATE
+// profiling build only (SPF_HIPCC_EXTRA=-DSPF_ABLATE): cut the kernel short at run time to time its parts
+static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-threshold argument
+#define ABLATE(n) ((int)(dense_thr_arg >> 28) == (n))
+#else
+#define ABLATE(n) false
+#endif
 // ------------------------------------------------------------------------------------------------
 // Forward for sparse tiles ("lists"): Gaussian-parallel footprint scatter + pixel-parallel private lists.
 //
@@ -254,12 +261,37 @@ __device__ __forceinline__ void scatter_footprint(uint32_t (*s_pm)[kStage], int 
     }
 }
 
+// Lane <-> pixel assignment of the lists backward (the forward keeps the natural order: sorting its pixels by
+// candidate count was measured -- 20 % fewer replay instructions, no time gained).  A wave of the pixel-private loops runs as long as its busiest pixel,
+// so the tile's 256 pixels are put on lanes in descending order of `load` (<= 255): pixels of similar load share a
+// wave.  Counting sort in LDS with two barriers: histogram by LDS atomics (the rank inside a bin is the atomic's
+// return value), then EVERY wave scans all 256 bins for itself (4 bins per lane, DPP prefix sum) -- no cross-wave
+// exchange.  s_cnt must hold 256 zeros (with a barrier since they were written); s_perm: 256 words.  Returns the pixel
+// (0..255, row-major in the tile) of the calling thread.  All 256 threads must call it.
+__device__ __forceinline__ int assign_pixels_by_load(uint32_t load, uint32_t* s_cnt, uint32_t* s_perm) {
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t bin = 255u - min(load, 255u);                        // descending load
+    const uint32_t rank_in_bin = atomicAdd(&s_cnt[bin], 1u);
+    __syncthreads();
+    const uint4 c = reinterpret_cast<const uint4*>(s_cnt)[lane];        // bins 4*lane .. 4*lane+3
+    const uint32_t tot = c.x + c.y + c.z + c.w;
+    const uint32_t excl = wave_iscan_u32(tot) - tot;                    // pixels in bins before 4*lane
+    const uint32_t before = (uint32_t)__shfl((int)excl, (int)(bin >> 2), kWave);
+    const uint4 g = reinterpret_cast<const uint4*>(s_cnt)[bin >> 2];    // the four bins of my group
+    const uint32_t k = bin & 3u;
+    const uint32_t start = before + (k > 0u ? g.x : 0u) + (k > 1u ? g.y : 0u) + (k > 2u ? g.z : 0u);
+    s_perm[start + rank_in_bin] = (uint32_t)tid;
+    __syncthreads();
+    return (int)s_perm[tid];
+}
+
 __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
     const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
-    int T, int tiles_x, int RT, uint32_t dense_thr) {
+    int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
+    const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;   // (the top bits carry the ablation code of profiling builds)
     __shared__ float4 s_p0[kStage];   // x, y, A, B
     __shared__ float4 s_p1[kStage];   // C, opacity, cull r^2, depth
     __shared__ float4 s_p2[kStage];   // r, g, b, -
@@ -292,7 +324,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         const uint32_t idx = base + tid;
         float gx = 0.f, gy = 0.f, r2 = -1.f;
         if (idx < n) {
-            const uint32_t gid = (uint32_t)pairs[beg + idx];
+            uint32_t gid = (uint32_t)pairs[beg + idx];
+            if (ABLATE(10)) gid = (uint32_t)(beg + idx) % (uint32_t)G;       // (profiling: coalesced instead of gathered)
+            if (ABLATE(11)) gid = (uint32_t)tid;                             // (profiling: always the same 12 KB)
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
@@ -301,9 +335,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             gx = a.x; gy = a.y; r2 = b.w;
         }
         __syncthreads();
-        scatter_footprint(s_pm, tid, gx, gy, r2, X0, Y0);
+        if (!ABLATE(8) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) scatter_footprint(s_pm, tid, gx, gy, r2, X0, Y0);
         __syncthreads();
-        if (!wave_done) {
+        if (!wave_done && !ABLATE(8) && !ABLATE(9) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
             int w = 0;
             uint32_t m = done ? 0u : s_pm[0][tid];
             // next candidate of this lane (has = false: none left; the index stays valid); lanes whose word is
@@ -353,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         }
         if (__syncthreads_and(wave_done)) break;
     }
-    if (inside) {
+    if (inside && !(ABLATE(12) && Tr == 123.f)) {
         const float* __restrict__ bg = bg_all + 3 * r;
         const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
         float* __restrict__ img = image + (size_t)r * 3 * P;
@@ -582,13 +616,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 //            and writes the pair's 48-byte record.
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
-#ifdef SPF_ABLATE
-// profiling build only (SPF_HIPCC_EXTRA=-DSPF_ABLATE): cut the kernel short at run time to time its parts
-static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-threshold argument
-#define ABLATE(n) ((int)(dense_thr_arg >> 28) == (n))
-#else
-#define ABLATE(n) false
-#endif
 #ifdef SPF_PHASE_CLOCKS
 // profiling build only (SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS): shader-clock cycles per phase, summed over waves
 __device__ unsigned long long g_phase_cycles[8];
@@ -622,7 +649,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
     __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
     __shared__ float4 s_p2[kRoundL];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
-    __shared__ uint32_t s_pm[kRoundL / 32][kBlock];  // [32-entry word][pixel]: candidate bits
+    __shared__ __attribute__((aligned(16))) uint32_t s_pm[kRoundL / 32][kBlock];  // [32-entry word][pixel]: candidate bits
     __shared__ float2 s_pool[kPool];                // (w, u) slots of this round's entries
     __shared__ float4 s_gI[kBlock];                 // per pixel: dL/dC (rgb), dL/ddepth
     __shared__ uint32_t s_w[4];                     // per-wave scratch (max / scan totals)
@@ -641,37 +668,15 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     PHASE_INIT();
     if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
-    // ---- lane <-> pixel assignment: pixels sorted by their number of contributors (recorded by the forward).
-    // A wave of the pixel-private replay runs as long as its busiest pixel, so pixels of similar load share a wave
-    // (counting sort over 256 pixels in LDS; ties keep pixel order).
+    // ---- lane <-> pixel assignment by the number of contributors the forward recorded ----
     int mypix;
     {
-        uint32_t* s_cnt = &s_pm[0][0];          // 256 bins (reused before the rounds start)
-        uint32_t* s_perm = &s_pm[1][0];
         const int qx = X0 + (tid & 15), qy = Y0 + (tid >> 4);
         uint32_t h = 0;
-        if (qx < W && qy < H) h = min(n_contrib[2 * ((size_t)r * P + (size_t)qy * W + qx) + 1], 255u);
-        s_cnt[tid] = 0u;
+        if (qx < W && qy < H) h = n_contrib[2 * ((size_t)r * P + (size_t)qy * W + qx) + 1];
+        s_pm[0][tid] = 0u;                        // (s_pm is free before the rounds: bins in word 0, order in word 1)
         __syncthreads();
-        const uint32_t rank_in_bin = atomicAdd(&s_cnt[255u - h], 1u);     // descending load
-        __syncthreads();
-        uint32_t inc = s_cnt[tid];              // exclusive scan of the 256 bins: wave scan + 4 wave totals
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
-            if (lane >= o) inc += y;
-        }
-        if (lane == kWave - 1) s_w[wave] = inc;
-        __syncthreads();
-        uint32_t off = inc - s_cnt[tid];
-        for (int w = 0; w < wave; ++w) off += s_w[w];
-        __syncthreads();
-        s_cnt[tid] = off;                       // bin start
-        __syncthreads();
-        s_perm[s_cnt[255u - h] + rank_in_bin] = (uint32_t)tid;
-        __syncthreads();
-        mypix = (int)s_perm[tid];
-        __syncthreads();
+        mypix = assign_pixels_by_load(h, &s_pm[0][0], &s_pm[1][0]);
     }
     const int lx = mypix & 15, ly = mypix >> 4;
     const int px = X0 + lx, py = Y0 + ly;
@@ -929,7 +934,12 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     if (dense_hint != (uint32_t)RT)
         spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT,
+#ifdef SPF_ABLATE
+            dense_threshold() | ((uint32_t)g_ablate_host << 28));
+#else
+            dense_threshold());
+#endif
     if (dense_hint != 0u)
         spf_render_fwd_rows_kernel<<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,

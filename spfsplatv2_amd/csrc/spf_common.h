@@ -62,6 +62,23 @@ __device__ __forceinline__ float wave_sum(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
 }
 
+// Inclusive prefix sum over the 64 lanes (same DPP ladder as above, on integers).
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_scan_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, BANK_MASK, true);
+}
+__device__ __forceinline__ uint32_t wave_iscan_u32(uint32_t x) {
+    uint32_t t = x;
+    t += dpp_scan_u<0x111>(x);
+    t += dpp_scan_u<0x112>(x);
+    t += dpp_scan_u<0x113>(x);
+    t += dpp_scan_u<0x114, 0xf, 0xe>(t);
+    t += dpp_scan_u<0x118, 0xf, 0xc>(t);
+    t += dpp_scan_u<0x142, 0xa>(t);
+    t += dpp_scan_u<0x143, 0xc>(t);
+    return t;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -14,7 +14,11 @@ from spfsplatv2_amd import _lib, synthetic as syn  # noqa: E402
 
 CUTS = {0: "full kernel", 1: "return at entry (launch + tile header)", 2: "return after lane sort + pixel loads",
         3: "return after zeroing the tail records", 4: "rounds: staging only", 5: "rounds: staging + phase A",
-        6: "everything but phase C", 7: "everything but phase B"}
+        6: "everything but phase C", 7: "everything but phase B",
+        8: "FORWARD lists kernel: staging only", 9: "FORWARD lists kernel: staging + phase A",
+        10: "FORWARD: staging only, records read coalesced instead of gathered",
+        11: "FORWARD: staging only, records always from the same 12 KB",
+        12: "FORWARD: staging only (same as 8)"}
 
 
 def main():
@@ -36,13 +40,13 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        _lib.stage_timing_enable(["render_bwd"])
+        _lib.stage_timing_enable(["render_bwd", "render_fwd"])
         for _ in range(20):
             step()
         torch.cuda.synchronize()
-        st = _lib.stage_times()["render_bwd"]
+        st, sf = _lib.stage_times()["render_bwd"], _lib.stage_times()["render_fwd"]
         _lib.stage_timing_enable(False)
-        print(f"cut {cut}: {st[0] / st[1] * 1e3:8.1f} us   {what}")
+        print(f"cut {cut}: bwd {st[0] / st[1] * 1e3:8.1f} us  fwd {sf[0] / sf[1] * 1e3:8.1f} us   {what}")
 
 
 if __name__ == "__main__":
