@@ -18,9 +18,10 @@ namespace spf {
 constexpr int kScanThreads = 1024;
 
 // One 1024-thread block: exclusive scan of the per-tile counts (-> tile_start, zeroed tile_fill, D, longest list,
-// number of dense tiles) and of the per-block pair totals (-> blk_base), BOTH in one pass: every thread first issues
-// all the loads of its two chunks (one global-memory latency), the two running sums travel through the same wave
-// scans and the same pair of barriers.
+// number of dense tiles) and of the per-block pair totals (-> blk_base).  Every wave owns one contiguous segment of
+// each array and walks it 64 elements at a time, so every load and store of a wave is one contiguous 256 bytes (a
+// thread-chunked layout costs 8x the L1 transactions: 24 us instead of 6); pass 1 sums the segments, pass 2 re-reads
+// them (cache hits) and writes the running offsets from a DPP prefix sum per step.
 __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint32_t* __restrict__ count,
                                                                      uint32_t* __restrict__ start,
                                                                      uint32_t* __restrict__ fill,
@@ -29,80 +30,50 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
                                                                      uint32_t* __restrict__ counters, int n,
                                                                      const uint32_t* __restrict__ blk_total,
                                                                      uint32_t* __restrict__ blk_base, int nb) {
-    __shared__ uint32_t s_a[kScanThreads / kWave], s_b[kScanThreads / kWave], s_mx[kScanThreads / kWave],
-        s_dn[kScanThreads / kWave];
-    constexpr int kRegs = 16;   // chunks up to 16 live in registers (n, nb <= 16384); longer ones are re-read
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ca = (n + kScanThreads - 1) / kScanThreads, cb = (nb + kScanThreads - 1) / kScanThreads;
-    const int a0 = tid * ca, a1 = min(n, a0 + ca), b0 = tid * cb, b1 = min(nb, b0 + cb);
-    const bool ra = ca <= kRegs, rb = cb <= kRegs;
-    uint32_t va[kRegs], vf[kRegs], vb[kRegs];
-#pragma unroll
-    for (int k = 0; k < kRegs; ++k) {
-        va[k] = (ra && a0 + k < a1) ? count[a0 + k] : 0u;
-        vf[k] = (ra && a0 + k < a1) ? flags[a0 + k] : 0u;
-        vb[k] = (rb && b0 + k < b1) ? blk_total[b0 + k] : 0u;
-    }
+    constexpr int kWaves = kScanThreads / kWave;
+    __shared__ uint32_t s_a[kWaves], s_b[kWaves], s_mx[kWaves], s_dn[kWaves];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int sega = ((n + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;      // multiples of 64 elements
+    const int segb = ((nb + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;
+    const int a0 = min(n, wave * sega), a1 = min(n, a0 + sega), b0 = min(nb, wave * segb), b1 = min(nb, b0 + segb);
     uint32_t sa = 0, sb = 0, mx = 0, dn = 0;
-    if (ra) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) {
-            sa += va[k];
-            mx = max(mx, va[k]);
-            dn += (a0 + k < a1 && tile_is_dense(vf[k], va[k], dense_thr)) ? 1u : 0u;
-        }
-    } else {
-        for (int i = a0; i < a1; ++i) {
-            const uint32_t c = count[i];
-            sa += c;
-            mx = max(mx, c);
-            dn += tile_is_dense(flags[i], c, dense_thr) ? 1u : 0u;
-        }
+    for (int i = a0 + lane; i < a1; i += kWave) {
+        const uint32_t c = count[i];
+        sa += c;
+        mx = max(mx, c);
+        dn += tile_is_dense(flags[i], c, dense_thr) ? 1u : 0u;
     }
-    if (rb) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k) sb += vb[k];
-    } else {
-        for (int i = b0; i < b1; ++i) sb += blk_total[i];
-    }
-    uint32_t ia = sa, ib = sb;   // inclusive scans of the per-thread sums inside the wave
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t ya = (uint32_t)__shfl_up((int)ia, o, kWave), yb = (uint32_t)__shfl_up((int)ib, o, kWave);
-        if (lane >= o) { ia += ya; ib += yb; }
-    }
-    mx = wave_max_u32(mx);
-    dn = wave_sum_u32(dn);
-    if (lane == kWave - 1) { s_a[wave] = ia; s_b[wave] = ib; }
-    if (lane == 0) { s_mx[wave] = mx; s_dn[wave] = dn; }
+    for (int i = b0 + lane; i < b1; i += kWave) sb += blk_total[i];
+    sa = wave_sum_u32(sa); sb = wave_sum_u32(sb); mx = wave_max_u32(mx); dn = wave_sum_u32(dn);
+    if (lane == 0) { s_a[wave] = sa; s_b[wave] = sb; s_mx[wave] = mx; s_dn[wave] = dn; }
     __syncthreads();
-    uint32_t oa = 0, ob = 0, total = 0, gmax = 0, dense = 0;
-    for (int w = 0; w < kScanThreads / kWave; ++w) {
-        if (w < wave) { oa += s_a[w]; ob += s_b[w]; }
+    uint32_t runa = 0, runb = 0, total = 0, gmax = 0, dense = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        if (w < wave) { runa += s_a[w]; runb += s_b[w]; }
         total += s_a[w];
         gmax = max(gmax, s_mx[w]);
         dense += s_dn[w];
     }
-    uint32_t runa = oa + ia - sa, runb = ob + ib - sb;   // exclusive prefixes of this thread's chunks
-    if (ra) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k)
-            if (a0 + k < a1) { start[a0 + k] = runa; fill[a0 + k] = 0u; runa += va[k]; }
-    } else {
-        for (int i = a0; i < a1; ++i) { const uint32_t c = count[i]; start[i] = runa; fill[i] = 0u; runa += c; }
+    for (int i0 = a0; i0 < a1; i0 += kWave) {
+        const int i = i0 + lane;
+        const uint32_t c = i < a1 ? count[i] : 0u;
+        const uint32_t inc = wave_iscan_u32(c);
+        if (i < a1) { start[i] = runa + inc - c; fill[i] = 0u; }
+        runa += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
     }
-    if (rb) {
-#pragma unroll
-        for (int k = 0; k < kRegs; ++k)
-            if (b0 + k < b1) { blk_base[b0 + k] = runb; runb += vb[k]; }
-    } else {
-        for (int i = b0; i < b1; ++i) { const uint32_t c = blk_total[i]; blk_base[i] = runb; runb += c; }
+    for (int i0 = b0; i0 < b1; i0 += kWave) {
+        const int i = i0 + lane;
+        const uint32_t c = i < b1 ? blk_total[i] : 0u;
+        const uint32_t inc = wave_iscan_u32(c);
+        if (i < b1) blk_base[i] = runb + inc - c;
+        runb += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
     }
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         start[n] = total;
         counters[0] = total;     // D
         counters[1] = gmax;      // longest tile list
-        counters[2] = 0;         // overflow flag (set by the binning kernel)
+        counters[2] = 0;         // plan verdict (set by the binning kernel)
         counters[3] = dense;     // tiles the dense "rows" render kernels take
     }
 }
