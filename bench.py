@@ -106,6 +106,9 @@ def main():
                          "step) instead of the default: a PairBudget planned from the first step, verified on the "
                          "device, checked once after the timed region")
     ap.add_argument("--sync-free", action="store_true", help="(default now; kept for compatibility)")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="photometric MSE through torch.nn.functional.mse_loss (five eager kernels) instead of the "
+                         "fused spfsplatv2_amd.mse_loss (LossMse, loss_mse.py:36-51)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
                          "single-GPU box together with --one-device)")
@@ -168,7 +171,7 @@ def main():
             leaves["extrinsics"], b.intrinsics, b.near, b.far, (h, w), bg, leaves["means"], leaves["harmonics"],
             leaves["opacities"], leaves["rotations"], leaves["scales"], scale_invariant=True,
             enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
-        loss = torch.nn.functional.mse_loss(color, b.target)
+        loss = (torch.nn.functional.mse_loss if args.torch_loss else spf.mse_loss)(color, b.target)
         loss.backward()
         if args.allreduce:
             shard.allreduce_gaussian_grads([leaves[n].grad for n in names[:5]])
@@ -257,6 +260,7 @@ def main():
             "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, SH degree "
                                    f"{int(K ** 0.5) - 1}, {h}x{w}, {S} scenes x {V} views per GPU per step, "
                                    "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
+                       "loss": "torch.nn.functional.mse_loss" if args.torch_loss else "spfsplatv2_amd.mse_loss (fused HIP)",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
                        "s_mult": args.s_mult, "pair_buffer": "exact (read-back per step)" if max_pairs is None else

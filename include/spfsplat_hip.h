@@ -184,6 +184,17 @@ int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh
                          const float* dL_dscales, const float* dL_drotations, const float* dL_dharmonics,
                          float* dL_draw, void* stream);
 
+/* Photometric MSE on the decoder output (LossMse.forward, src/loss/loss_mse.py:36-51):
+ * loss[0] = weight * mean((prediction - image)^2) over n floats, and its backward
+ * dL_dprediction = (2 * weight / n) * dL_dloss[0] * (prediction - image) (dL_dloss is read on the device).
+ * partial: scratch of spf_mse_partial_blocks() floats.  The sum is taken in a fixed order: results are run-to-run
+ * identical.  Tensors 16-byte aligned. */
+int spf_mse_partial_blocks(void);
+int spf_mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial,
+                    float* loss, void* stream);
+int spf_mse_backward(const float* prediction, const float* image, int64_t n, float weight, const float* dL_dloss,
+                     float* dL_dprediction, void* stream);
+
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n, stride_h) and
  * stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.  positions[B / pos_div, N, 2] int64 contiguous
  * (y, x): batch item b uses positions[b / pos_div] (pos_div = 1 for the CroCo layout; a head-major [B,H,N,D] tensor

@@ -20,6 +20,9 @@ hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, 
 hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
+int mse_partial_blocks();
+hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, hipStream_t);
+hipError_t launch_mse_bwd(const float*, const float*, int64_t, float, const float*, float*, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
 hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float, float,
@@ -248,6 +251,31 @@ int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh
     if (N == 0) return SPF_OK;
     SPF_HIP(spf::launch_adapter_bwd(raw, N, K, sh_mask, eps, dL_dscales, dL_drotations, dL_dharmonics, dL_draw,
                                     static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_mse_partial_blocks(void) { return spf::mse_partial_blocks(); }
+
+int spf_mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial,
+                    float* loss, void* stream_) {
+    if (!prediction || !image || !partial || !loss) return fail(SPF_E_INVALID, "mse: null pointer");
+    if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
+    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image)) & 15)
+        return fail(SPF_E_INVALID, "mse: prediction / image must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss,
+                                static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_mse_backward(const float* prediction, const float* image, int64_t n, float weight, const float* dL_dloss,
+                     float* dL_dprediction, void* stream_) {
+    if (!prediction || !image || !dL_dloss || !dL_dprediction) return fail(SPF_E_INVALID, "mse: null pointer");
+    if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
+    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image) |
+         reinterpret_cast<uintptr_t>(dL_dprediction)) & 15)
+        return fail(SPF_E_INVALID, "mse: tensors must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_bwd(prediction, image, n, 2.0f * weight / (float)n, dL_dloss, dL_dprediction,
+                                static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 

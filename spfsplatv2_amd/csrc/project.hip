@@ -184,8 +184,15 @@ __device__ __forceinline__ float sh_at(const float* __restrict__ sh, int K, int 
 // ------------------------------------------------------------------------------------------
 // Forward.  grid = (ceil(G/256), S), block = 256.  DEG = -1: colours given (colors_precomp).
 // ------------------------------------------------------------------------------------------
+// minimum resident blocks per CU asked of the compiler (profiling knobs; 1 = no constraint)
+#ifndef SPF_PBWD_BPC
+#define SPF_PBWD_BPC 1
+#endif
+#ifndef SPF_PFWD_BPC
+#define SPF_PFWD_BPC 1
+#endif
 template <int DEG, bool NATIVE>
-__global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+__global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // Per-tile counts are first accumulated in an LDS histogram of the block's render (T counters) and
     // flushed with one global atomic per touched tile: neighbouring Gaussians of a pixel-aligned scene land
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void spf_project_fwd_kernel(SpfDims d, SpfI
 constexpr int kViewChunk = 64;
 
 template <int DEG, bool NATIVE>
-__global__ __launch_bounds__(kBlock) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+__global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
     if (st.counters[0] > capacity) return;   // a planned pair buffer was too small: nothing was rendered, no pair records
     const int g = blockIdx.x * kBlock + threadIdx.x;

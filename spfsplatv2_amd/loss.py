@@ -1,0 +1,127 @@
+"""Photometric MSE loss on the HIP library: host mirror of the reference's ``LossMse``.
+
+=====================  =========================================================================
+here                   reference (/root/reference/src/loss/)
+=====================  =========================================================================
+``LossMseCfg``         loss_mse.py:13-16
+``LossMseCfgWrapper``  loss_mse.py:18-20
+``Loss``               loss.py:17-40 (the config wrapper convention: one dataclass field = the loss's name)
+``LossMse``            loss_mse.py:36-51: ``weight * ((prediction - image) ** 2).mean()``, 0 before ``apply_after_step``
+``mse_loss``           the same expression as a function (what ``bench.py`` and the tests call)
+=====================  =========================================================================
+
+The reference evaluates the expression with eager PyTorch (four kernels forward, four backward over the rendered
+batch); here it is one pass forward and one backward, and the sum is taken in a fixed order (bit-reproducible).
+No CPU path: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, fields
+from typing import Generic, TypeVar
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+T_cfg = TypeVar("T_cfg")
+T_wrapper = TypeVar("T_wrapper")
+_scratch: dict = {}      # per device: partial sums
+
+
+def _scratch_for(dev: torch.device):
+    key = (dev.type, dev.index)
+    if key not in _scratch:
+        n = _lib.load().spf_mse_partial_blocks()
+        _scratch[key] = torch.empty(n, dtype=torch.float32, device=dev)
+    return _scratch[key]
+
+
+def _check(prediction: Tensor, image: Tensor) -> None:
+    for name, t in (("prediction", prediction), ("image", image)):
+        if not t.is_cuda:
+            raise RuntimeError(f"mse_loss: {name} is on {t.device}; this build only runs on a HIP device (no CPU "
+                               "fallback)")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"mse_loss: {name} must be float32, got {t.dtype}")
+    if prediction.shape != image.shape:
+        raise RuntimeError(f"mse_loss: shapes differ: {tuple(prediction.shape)} vs {tuple(image.shape)}")
+    if prediction.numel() == 0:
+        raise RuntimeError("mse_loss: empty input")
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction: Tensor, image: Tensor, weight: float):
+        _check(prediction, image)
+        p, t = prediction.contiguous(), image.contiguous()
+        lib = _lib.load()
+        dev = p.device
+        partial = _scratch_for(dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.spf_mse_forward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
+                                           float(weight), C.c_void_p(partial.data_ptr()),
+                                           C.c_void_p(loss.data_ptr()), stream),
+                       "spf_mse_forward")
+        ctx.save_for_backward(p, t)
+        ctx.weight = float(weight)
+        ctx.shape = prediction.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        lib = _lib.load()
+        dev = p.device
+        g = g.to(torch.float32).contiguous()
+        gp = torch.empty_like(p)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.spf_mse_backward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(), ctx.weight,
+                                            C.c_void_p(g.data_ptr()), C.c_void_p(gp.data_ptr()), stream),
+                       "spf_mse_backward")
+        gp = gp.view(ctx.shape)
+        gi = -gp if ctx.needs_input_grad[1] else None
+        return gp, gi, None
+
+
+def mse_loss(prediction: Tensor, image: Tensor, weight: float = 1.0) -> Tensor:
+    """``weight * ((prediction - image) ** 2).mean()`` (loss_mse.py:48-51) as one fused pass; 0-dim float32 result."""
+    return _Mse.apply(prediction, image, weight)
+
+
+class Loss(nn.Module, ABC, Generic[T_cfg, T_wrapper]):
+    cfg: T_cfg
+    name: str
+
+    def __init__(self, cfg: T_wrapper) -> None:
+        super().__init__()
+        (field,) = fields(type(cfg))            # the wrapper's single field names the loss (loss.py:24-31)
+        self.cfg = getattr(cfg, field.name)
+        self.name = field.name
+
+    @abstractmethod
+    def forward(self, prediction, batch, gaussians, global_step: int) -> Tensor:
+        ...
+
+
+@dataclass
+class LossMseCfg:
+    weight: float
+    apply_after_step: int
+
+
+@dataclass
+class LossMseCfgWrapper:
+    mse: LossMseCfg
+
+
+class LossMse(Loss[LossMseCfg, LossMseCfgWrapper]):
+    def forward(self, prediction: Tensor, image: Tensor, gaussians, global_step: int) -> Tensor:
+        if global_step < self.cfg.apply_after_step:           # not applied yet (loss_mse.py:44-46)
+            return torch.tensor(0, dtype=torch.float32, device=image.device)
+        return mse_loss(prediction, image, self.cfg.weight)

@@ -1,0 +1,75 @@
+"""Photometric MSE loss: oracle (oracle/loss_ref.py) pinned by vectors captured from the reference's own LossMse
+(tests/golden/make_loss_goldens.py; loss_mse.py:36-51), and the fused HIP op against both.
+Tolerances: loss 2e-6 relative (float32 sum of up to 1.6e5 squares), gradient 1e-7 absolute (values ~1e-5)."""
+from pathlib import Path
+
+import pytest
+import torch
+
+from oracle import loss_ref
+
+GOLD = torch.load(Path(__file__).parent / "golden" / "loss_goldens.pt")
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+@pytest.mark.parametrize("name", list(GOLD))
+def test_oracle_matches_reference_loss(name):
+    g = GOLD[name]
+    loss, grad = loss_ref.mse_loss(g["prediction"], g["image"], g["weight"], g["global_step"], g["apply_after_step"])
+    if float(g["loss"]) == 0.0:
+        assert float(loss) == 0.0 and float(grad.abs().max()) == 0.0
+    else:
+        assert _rel(loss, g["loss"]) < 2e-6
+        assert float((grad.float() - g["grad"]).abs().max()) < 1e-9 + 1e-6 * float(g["grad"].abs().max())
+
+
+def test_loss_module_surface_and_cpu_refusal():
+    from spfsplatv2_amd import loss as L
+    m = L.LossMse(L.LossMseCfgWrapper(L.LossMseCfg(weight=0.5, apply_after_step=3)))
+    assert m.name == "mse" and m.cfg.weight == 0.5 and len(list(m.parameters())) == 0
+    x = torch.rand(1, 1, 3, 4, 4)
+    assert float(m(x, x, None, 0)) == 0.0            # before apply_after_step: a constant 0 (loss_mse.py:44-46)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(x, x, None, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(GOLD))
+def test_hip_loss_matches_reference_vectors(hip_lib, name):
+    from spfsplatv2_amd import loss as L
+    g = GOLD[name]
+    pred = g["prediction"].cuda().requires_grad_(True)
+    img = g["image"].cuda().requires_grad_(True)
+    m = L.LossMse(L.LossMseCfgWrapper(L.LossMseCfg(weight=g["weight"], apply_after_step=g["apply_after_step"])))
+    loss = m(pred, img, None, g["global_step"])
+    if float(g["loss"]) == 0.0:
+        assert float(loss) == 0.0 and not loss.requires_grad
+        return
+    assert loss.shape == () and loss.dtype == torch.float32
+    assert _rel(loss, g["loss"]) < 2e-6
+    (3.0 * loss).backward()                              # upstream scalar is read on the device
+    assert float((pred.grad.cpu() - 3.0 * g["grad"]).abs().max()) < 1e-7
+    assert torch.equal(img.grad, -pred.grad)
+
+
+@pytest.mark.gpu
+def test_hip_loss_is_deterministic_and_takes_views(hip_lib):
+    from spfsplatv2_amd import loss as L
+    gen = torch.Generator().manual_seed(5)
+    a = torch.rand(8, 4, 3, 256, 256, generator=gen).cuda()      # the bench's batch: 6.3 M floats, 1024 partial blocks
+    b = torch.rand(8, 4, 3, 256, 256, generator=gen).cuda()
+    l1, l2 = L.mse_loss(a, b), L.mse_loss(a, b)
+    assert torch.equal(l1, l2)
+    ref, _ = loss_ref.mse_loss(a, b, 1.0)
+    assert _rel(l1, ref) < 2e-6
+    # a non-contiguous prediction (channel-last view) gives the same loss and a gradient of the view's shape
+    av = a.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True)
+    lv = L.mse_loss(av, b, 0.25)
+    assert _rel(lv, 0.25 * ref) < 2e-6
+    lv.backward()
+    assert av.grad.shape == a.shape
+    want = 0.25 * 2.0 / a.numel() * (a - b)
+    assert float((av.grad - want).abs().max()) < 1e-12 + 1e-6 * float(want.abs().max())
