@@ -162,6 +162,7 @@ def main():
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
     leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in names}
     bg = torch.zeros(3, device=dev)
+    one = torch.ones((), device=dev)
     max_pairs = None
 
     def step():
@@ -172,7 +173,7 @@ def main():
             leaves["opacities"], leaves["rotations"], leaves["scales"], scale_invariant=True,
             enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
         loss = (torch.nn.functional.mse_loss if args.torch_loss else spf.mse_loss)(color, b.target)
-        loss.backward()
+        loss.backward(gradient=one)          # (a cached dL/dloss = 1 saves autograd's fill kernel)
         if args.allreduce:
             shard.allreduce_gaussian_grads([leaves[n].grad for n in names[:5]])
         return loss

@@ -302,8 +302,8 @@ __device__ __forceinline__ void sort_tile_in_wave(uint64_t* __restrict__ p, uint
     }
 }
 
-// Four tiles per 256-thread block (one per wave).  SMALL: lists of 2..512 entries, keys-per-lane chosen per tile;
-// otherwise one size class (lo, 64*E].
+// Four tiles per 256-thread block (one per wave).  SMALL: lists of 2..64*E entries, keys-per-lane (2/4/8/16 <= E)
+// chosen per tile; otherwise one size class (lo, 64*E].
 template <int E, bool SMALL>
 __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint32_t* __restrict__ tile_start,
                                                                      const uint32_t* __restrict__ counters,
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint3
     if (SMALL) {
         if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
         else if (n <= 4u * kWave) sort_tile_in_wave<4>(pairs + b, n);
-        else sort_tile_in_wave<8>(pairs + b, n);
+        else if (E <= 8 || n <= 8u * kWave) sort_tile_in_wave<8>(pairs + b, n);
+        else sort_tile_in_wave<16>(pairs + b, n);
     } else {
         sort_tile_in_wave<E>(pairs + b, n);
     }
@@ -374,18 +375,18 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     return hipGetLastError();
 }
 
-// Size classes: (1, 512] (16, 32] x 64 registers: one wave per tile; (2048, 8192], (8192, 16384]: one 1024-thread
+// Size classes: (1, 512] or (1, 1024] and (1024, 2048]: one wave per tile, list in registers; (2048, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: global fallback.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
-    if (mx > 1)
+    if (mx > 1 && mx <= 512)     // (registers sized for 8 keys per lane: one more wave per SIMD than the 16-key build)
         spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                           capacity, 1, RT);
     if (mx > 512)
-        spf_sort_tiles_wave_kernel<16, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
-                                                                            capacity, 512, RT);
+        spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
+                                                                           capacity, 1, RT);
     if (mx > 1024)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                             capacity, 1024, RT);
