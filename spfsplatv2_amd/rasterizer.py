@@ -94,6 +94,26 @@ def _f32c(t: Tensor, name: str, shape: tuple) -> Tensor:
     return t.contiguous()
 
 
+_bg_cache: dict = {}     # id(source) -> (weakref to the source, its version, S, V, expanded copy)
+
+
+def _background(bg: Tensor, S: int, V: int) -> Tensor:
+    """Background colours as a contiguous [S,V,3] tensor.  A single colour [3] is broadcast once and the copy is
+    reused for as long as the caller passes the same, unmodified tensor (a decoder's `background_color` buffer):
+    no per-call expand kernel."""
+    if bg.dim() != 1:
+        return _f32c(bg, "bg", (S, V, 3))
+    import weakref
+    hit = _bg_cache.get(id(bg))
+    if hit is not None and hit[0]() is bg and hit[1:4] == (bg._version, S, V):
+        return hit[4]
+    out = _f32c(bg.expand(S, V, 3), "bg", (S, V, 3))
+    if len(_bg_cache) >= 16:
+        _bg_cache.clear()
+    _bg_cache[id(bg)] = (weakref.ref(bg), bg._version, S, V, out)
+    return out
+
+
 def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -374,9 +394,7 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
         shs = _f32c(shs, "shs", (S, G, 3, K) if native else (S, G, K, 3))
     else:
         colors_precomp = _f32c(colors_precomp, "colors_precomp", (S, G, 3))
-    if bg.dim() == 1:
-        bg = bg.expand(S, V, 3)
-    bg = _f32c(bg, "bg", (S, V, 3))
+    bg = _background(bg, S, V)
     return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
                                 bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0)
@@ -433,9 +451,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     viewmatrix = _f32c(viewmatrix, "viewmatrix", (S, V, 4, 4))
     projmatrix = _f32c(projmatrix, "projmatrix", (S, V, 4, 4))
     tanfov = _f32c(tanfov, "tanfov", (S, V, 2))
-    if bg.dim() == 1:
-        bg = bg.expand(S, V, 3)
-    bg = _f32c(bg, "bg", (S, V, 3))
+    bg = _background(bg, S, V)
     if not (0 <= sh_degree <= 4):
         raise RuntimeError(f"sh_degree {sh_degree} outside 0..4")
     if view_scale is not None:
