@@ -48,7 +48,7 @@ extern "C" {
 
 #define SPF_UNKNOWN 0xffffffffu
 #define SPF_TILE 16          /* square tile edge in pixels */
-#define SPF_DENSE_AREA 20    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
+#define SPF_DENSE_AREA 26    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
 
 /* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.
  * All scenes hold G Gaussians with K SH coefficients per colour channel (stride); the SH basis is

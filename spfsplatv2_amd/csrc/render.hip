@@ -925,13 +925,53 @@ uint32_t dense_threshold() {
     return v;
 }
 
+// When both the sparse and the dense kernel have tiles, they run CONCURRENTLY: the dense one is forked onto an
+// auxiliary stream (event fork / join, capturable in a HIP graph) so that a few long-running dense tiles do not
+// serialise behind -- or in front of -- the sparse kernel's wave of short blocks.  One auxiliary stream per device,
+// created on first use; this is the only state the library keeps besides the stage-timing events.
+struct AuxStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static AuxStream* aux_stream() {
+    static AuxStream aux[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    AuxStream& a = aux[dev];
+    if (!a.s) {
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { a.s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    return &a;
+}
+// Returns the stream the dense kernel should be launched on (the caller's own stream if forking is not possible).
+static hipStream_t fork_dense(hipStream_t stream, AuxStream*& a) {
+    a = getenv("SPF_NO_FORK") ? nullptr : aux_stream();
+    if (!a) return stream;
+    if (hipEventRecord(a->fork, stream) != hipSuccess || hipStreamWaitEvent(a->s, a->fork, 0) != hipSuccess) {
+        a = nullptr;
+        return stream;
+    }
+    return a->s;
+}
+static void join_dense(hipStream_t stream, AuxStream* a) {
+    if (!a) return;
+    (void)hipEventRecord(a->join, a->s);
+    (void)hipStreamWaitEvent(stream, a->join, 0);
+}
+
 // Every tile is rendered by exactly one of the two kernels (decided per tile from tile_flags / list length);
 // `dense_hint` (number of dense tiles, or SPF_UNKNOWN) only lets the host skip a launch that would find no tile.
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
                              uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (dense_hint != (uint32_t)RT)
+    const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
+    AuxStream* a = nullptr;
+    const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
+    if (sparse)
         spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT,
@@ -940,10 +980,11 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
 #else
             dense_threshold());
 #endif
-    if (dense_hint != 0u)
-        spf_render_fwd_rows_kernel<<<grid, kBlock, 0, stream>>>(
+    if (dense)
+        spf_render_fwd_rows_kernel<<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    join_dense(stream, a);
     return hipGetLastError();
 }
 
@@ -951,7 +992,10 @@ template <bool DG>
 static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
                                 int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity,
                                 hipStream_t stream) {
-    if (dense_hint != (uint32_t)RT)
+    const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
+    AuxStream* a = nullptr;
+    const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
+    if (sparse)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
             g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
@@ -961,11 +1005,12 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
             dense_threshold(),
 #endif
             st.counters, capacity);
-    if (dense_hint != 0u)
-        spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, stream>>>(
+    if (dense)
+        spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
             g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters,
             capacity);
+    join_dense(stream, a);
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
