@@ -220,6 +220,7 @@ def main():
         survey = {k: (v[0] * max(args.warmup, 1), max(args.warmup, 1)) for k, v in eager_survey.items()}
     dom = max(survey, key=lambda k: survey[k][0])
     _lib.stage_timing_enable([dom])
+    _lib.stage_timing_sample_every(4)     # events around every 4th launch of the dominant kernel
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -229,6 +230,7 @@ def main():
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
     stages = _lib.stage_times()
     _lib.stage_timing_enable(False)
+    _lib.stage_timing_sample_every(1)
     if max_pairs is not None and spf.last_plan_flags() != 0:
         raise RuntimeError(f"the planned pair budget did not hold (flags {spf.last_plan_flags()}): results invalid")
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

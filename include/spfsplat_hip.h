@@ -222,6 +222,8 @@ enum {
 };
 #define SPF_STAGE_LOG 1024
 int spf_stage_timing_enable(int32_t mask);
+/* Record only every n-th launch of an enabled stage (default 1): an event pair leaves the GPU idle for ~11 us. */
+int spf_stage_timing_sample_every(int32_t n);
 int spf_stage_times_ms(float* total_ms /* host, [SPF_STAGE_COUNT] */,
                        int32_t* count /* host, [SPF_STAGE_COUNT] */);
 const char* spf_stage_kernel_name(int32_t stage);
