@@ -52,13 +52,22 @@ def loss_weights(batch, seed=1234):
     return torch.rand(b, v, h, w, generator=gen), torch.rand(b, v, h, w, generator=gen)
 
 
-def scalar_loss(color, depth_bvhw, alpha_bv1hw, target, wd, wa):
-    """MSE on colour (the reference's loss, loss_mse.py:48-51) + weighted depth and alpha terms."""
-    return ((color - target) ** 2).mean() + 0.01 * (depth_bvhw * wd).mean() + 0.1 * (alpha_bv1hw[:, :, 0] * wa).mean()
+def scalar_loss(color, depth_bvhw, alpha_bv1hw, target, wd, wa, mask=None):
+    """MSE on colour (the reference's loss, loss_mse.py:48-51) + weighted depth and alpha terms.  `mask` [b,v,h,w]
+    (0/1) switches pixels off: used to keep knife-edge pixels, where a branch of the algorithm may legitimately flip
+    between float32 and float64, out of the GRADIENT comparison too (their dL/dpixel is then 0 on both sides)."""
+    if mask is None:
+        return ((color - target) ** 2).mean() + 0.01 * (depth_bvhw * wd).mean() + \
+            0.1 * (alpha_bv1hw[:, :, 0] * wa).mean()
+    m = mask.to(color.dtype)
+    return (((color - target) ** 2) * m[:, :, None]).mean() + 0.01 * (depth_bvhw * wd * m).mean() + \
+        0.1 * (alpha_bv1hw[:, :, 0] * wa * m).mean()
 
 
 def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_invariant=True, want_fragile=True,
-               with_grads=True):
+               with_grads=True, mask_fragile=False):
+    """`mask_fragile`: the loss ignores the pixels the oracle flags as knife-edge; the mask comes back as
+    res["pixel_mask"] for `run_product(..., pixel_mask=...)`."""
     from oracle import glue_ref
     leaves = {n: getattr(batch, n).detach().clone().to(dtype).requires_grad_(with_grads) for n in GRAD_NAMES}
     # the rasterizer consumes float32 inputs: keep the float32 values exactly, evaluate in `dtype`
@@ -71,7 +80,9 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
                fragile=out[4] if want_fragile else None)
     if with_grads:
         wd, wa = loss_weights(batch)
-        loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype))
+        mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else None
+        res["pixel_mask"] = mask
+        loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype), mask)
         loss.backward()
         res["loss"] = float(loss.detach())
         res["grads"] = {n: leaves[n].grad.detach() for n in GRAD_NAMES}
@@ -79,7 +90,7 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
 
 
 def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invariant=True, with_grads=True,
-                max_pairs=None):
+                max_pairs=None, pixel_mask=None):
     import spfsplatv2_amd as spf
     bd = batch.to(device)
     leaves = {n: getattr(bd, n).detach().clone().requires_grad_(with_grads) for n in GRAD_NAMES}
@@ -95,7 +106,8 @@ def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invarian
                stats=spf.last_forward_stats())
     if with_grads:
         wd, wa = loss_weights(batch)
-        loss = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device))
+        loss = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device),
+                           None if pixel_mask is None else pixel_mask.to(device))
         loss.backward()
         res["loss"] = float(loss.detach())
         res["grads"] = {n: leaves[n].grad.detach().cpu() for n in GRAD_NAMES}
