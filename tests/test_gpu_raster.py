@@ -31,19 +31,21 @@ CASES = {
 }
 
 
-def test_parity_vs_oracle_at_full_size(hip_lib):
-    """BASELINE.json configs[1] at FULL size (the bench workload): 65,536 pixel-aligned Gaussians, 256x256.
+@pytest.mark.parametrize("K,s_mult", [(1, 1.0), (16, 2.0)], ids=["c2", "c2_sh3_wider"])
+def test_parity_vs_oracle_at_full_size(hip_lib, K, s_mult):
+    """BASELINE.json configs[1] at FULL size (the bench workload): 65,536 pixel-aligned Gaussians, 256x256 -- and the
+    same scene with SH degree 3 and twice the footprint (BASELINE configs[4]'s coefficient count).
     At this size a few hundred of the 65,536 pixels sit on a knife edge of the algorithm (an alpha within 2e-4 of
     1/255, ...), where float32 and float64 may take different branches: a contribution of up to 1/255 appears or
     not, and so does its gradient.  Those pixels (flagged by the float64 oracle, < 2 %) are excluded from the RGB
     gate as everywhere else AND switched off in the loss of both sides, so that the gradient gate (1e-3 of the
     tensor's scale, over every Gaussian) compares like with like."""
-    batch = syn.make_batch(config="C2", n_scenes=1, n_views=1, seed=8)
+    batch = syn.make_batch(config="C2", n_scenes=1, n_views=1, seed=8, K=K, s_mult=s_mult)
     ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
     prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
     rep = util.compare(prod, ref)
     rep["num_pairs"] = prod["stats"].get("num_pairs")
-    _report("c2_full_size", rep)
+    _report(f"c2_full_size_K{K}", rep)
     assert not rep["fails"], rep
     assert prod["stats"]["num_pairs"] > 60000
 
