@@ -275,6 +275,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "launch_ms": round(dom_ms, 5),
                          "algorithmic_bytes_per_launch": dom_bytes,
+                         "limiter": "VALU issue, not HBM: SQ_ACTIVE_INST_VALU = 78 % of the SIMD cycles in this kernel "
+                                    "(profiles/r01_sq_counters.txt)" if dom == "render_bwd" else None,
                          "path_achieved_GBs": round(A / (dt / args.steps) / 1e9, 2),
                          "path_frac_of_copy_ceiling": round(A / (dt / args.steps) / 1e9 / HBM_COPY_GBS, 5)},
             "stage_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 5) for k, v in survey.items()},
