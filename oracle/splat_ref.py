@@ -67,6 +67,7 @@ class Projected:
     rect_min: Tensor    # [G,2] int64 tile rect (x,y), inclusive
     rect_max: Tensor    # [G,2] int64 tile rect (x,y), exclusive
     radius_raw: Tensor  # [G] 3*sqrt(lambda_max) before ceil (for knife-edge flagging)
+    rgb_raw: Tensor | None = None   # [G,3] SH colour + 0.5 BEFORE the clamp at 0 (for knife-edge flagging)
 
 
 def quat_to_rotmat(q: Tensor) -> Tensor:
@@ -191,10 +192,11 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
         d = v / v.norm(dim=-1, keepdim=True)
         basis = sh_basis(deg, d)                            # [G,K]
         rgb = torch.einsum("gk,gkc->gc", basis, shs[:, :K, :]) + 0.5
+        rgb_raw = rgb.detach()
         rgb = torch.clamp(rgb, min=0.0)                     # gradient masked where clamped
     return Projected(xy=xy, depth=tz, conic=conic, opacity=opacities.reshape(G),
                      rgb=rgb.to(dt), radii=radii, rect_min=rect_min, rect_max=rect_max,
-                     radius_raw=radius_raw)
+                     radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw)
 
 
 def tile_lists(pr: Projected, H: int, W: int):
@@ -329,6 +331,16 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
             _, _, ix1, iy1 = rect(px - eps, py - eps, r_lo)
             vis = (pr.radii > 0) | ((ux1 > ux0) & (uy1 > uy0) & (pr.depth.detach() > NEAR_CULL))
             amb = vis & ((ux0 != ix0) | (uy0 != iy0) | (ux1 != ix1) | (uy1 != iy1))
+            # SH colour within 1e-6 of the clamp at 0 (B#9): whether the channel -- and the gradient of its 3K
+            # coefficients -- is switched off is decided by the last bit; every pixel the Gaussian can reach is tainted
+            if pr.rgb_raw is not None:
+                clampy = (pr.radii > 0) & (pr.rgb_raw.double().abs() < 1e-6).any(dim=-1)
+                for g in torch.nonzero(clampy).flatten().tolist():
+                    rr = float(r_hi[g]) + 2.0
+                    y0p, y1p = max(0, int(py[g] - rr)), min(H, int(py[g] + rr) + 2)
+                    x0p, x1p = max(0, int(px[g] - rr)), min(W, int(px[g] + rr) + 2)
+                    if y1p > y0p and x1p > x0p:
+                        fr[y0p:y1p, x0p:x1p] = True
             for g in torch.nonzero(amb).flatten().tolist():
                 a0, b0, a1, b1 = int(ux0[g]), int(uy0[g]), int(ux1[g]), int(uy1[g])
                 c0, d0, c1, d1 = int(ix0[g]), int(iy0[g]), int(ix1[g]), int(iy1[g])

@@ -83,9 +83,11 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
         mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else None
         res["pixel_mask"] = mask
         loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype), mask)
-        loss.backward()
+        if loss.requires_grad:               # (nothing visible in any view: the loss is a constant)
+            loss.backward()
         res["loss"] = float(loss.detach())
-        res["grads"] = {n: leaves[n].grad.detach() for n in GRAD_NAMES}
+        res["grads"] = {n: (leaves[n].grad.detach() if leaves[n].grad is not None else torch.zeros_like(leaves[n]))
+                        for n in GRAD_NAMES}
     return res
 
 
