@@ -157,6 +157,20 @@ int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float
  * scan.  On return (stream order) st->counters[0] = D and st->counters[1] = longest tile list. */
 int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream);
 
+/* Decoder fast path (the batched DecoderSplattingCUDA.forward, decoder_splatting_cuda.py:41-78): two launches fewer
+ * per step than the calls above.
+ *   spf_decoder_prepare           = spf_camera_forward AND the clearing of `zero_bytes` bytes at `zero` (pass
+ *                                   st->tile_count with tile_flags laid out right behind it: 8*R*T bytes; 16-byte
+ *                                   aligned) in ONE kernel;
+ *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing of those counters;
+ *   spf_camera_backward_partials  = the deterministic sum of g->vpartial [R,nblk,12] (as written by spf_raster_backward
+ *                                   when g->vpartial != NULL; pass g->dL_dviewmatrix = NULL to skip its own reduction)
+ *                                   AND spf_camera_backward, in ONE kernel. */
+int spf_decoder_prepare(const SpfCamera* cam, void* zero, uint64_t zero_bytes, void* stream);
+int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream);
+int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, int32_t nblk, float* dL_dextrinsics,
+                                 void* stream);
+
 /* Forward, stage 2: bin (Gaussian, tile) pairs into per-tile lists, depth-sort every list and
  * composite.  `capacity` = number of uint64 entries st->pairs can hold.  `max_tile_hint` = upper bound of the
  * longest tile list the caller assumes (exact mode: host copy of counters[1]; 0 = unknown: every sort size class

@@ -25,6 +25,8 @@ hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, fl
 hipError_t launch_mse_bwd(const float*, const float*, int64_t, float, const float*, float*, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
+hipError_t launch_camera_fwd_zero(const SpfCamera&, void*, uint64_t, hipStream_t);
+hipError_t launch_camera_bwd_reduce(const SpfCamera&, const float*, int, float*, hipStream_t);
 hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float, float,
                          hipStream_t);
 }  // namespace spf
@@ -148,7 +150,7 @@ int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float
     return SPF_OK;
 }
 
-int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
+static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, bool tiles_cleared, void* stream_) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -159,7 +161,9 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
-    if (st->tile_flags == st->tile_count + RT) {   // adjacent (the Python binding lays them out so): one fill
+    if (tiles_cleared) {
+        // spf_decoder_prepare cleared tile_count | tile_flags together with the camera set-up
+    } else if (st->tile_flags == st->tile_count + RT) {   // adjacent (the Python binding lays them out so): one fill
         SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * 2 * (size_t)RT, stream));
     } else {
         SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * (size_t)RT, stream));
@@ -174,6 +178,32 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
         SPF_HIP(spf::launch_tile_scan(*st, RT, d->S * d->V * spf_raster_view_partial_blocks(d->G),
                                       spf::dense_threshold(), stream));
     }
+    return SPF_OK;
+}
+
+int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
+    return forward_project(d, in, st, false, stream_);
+}
+
+int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
+    return forward_project(d, in, st, true, stream_);
+}
+
+int spf_decoder_prepare(const SpfCamera* cam, void* zero, uint64_t zero_bytes, void* stream_) {
+    int rc = check_camera(cam, true);
+    if (rc) return rc;
+    if (!zero || (reinterpret_cast<uintptr_t>(zero) & 15) || (zero_bytes & 15))
+        return fail(SPF_E_INVALID, "decoder_prepare: the buffer to clear must be 16-byte aligned and sized");
+    SPF_HIP(spf::launch_camera_fwd_zero(*cam, zero, zero_bytes, static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, int32_t nblk, float* dL_dextrinsics,
+                                 void* stream_) {
+    int rc = check_camera(cam, false);
+    if (rc) return rc;
+    if (!vpartial || !dL_dextrinsics || nblk < 1) return fail(SPF_E_INVALID, "camera_backward_partials: bad argument");
+    SPF_HIP(spf::launch_camera_bwd_reduce(*cam, vpartial, nblk, dL_dextrinsics, static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 

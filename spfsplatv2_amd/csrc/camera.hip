@@ -56,9 +56,7 @@ __device__ __forceinline__ void unit_ray(const float* Kinv, float u, float v, fl
     d[0] /= n; d[1] /= n; d[2] /= n;
 }
 
-__global__ void spf_camera_fwd_kernel(SpfCamera c) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.R) return;
+__device__ __forceinline__ void camera_fwd_one(const SpfCamera& c, int r) {
     float nr = c.near[r], fr = c.far[r];
     const float scale = c.scale_invariant ? 1.0f / nr : 1.0f;
     float A[16], B[16];
@@ -105,12 +103,24 @@ __global__ void spf_camera_fwd_kernel(SpfCamera c) {
         for (int j = 0; j < 4; ++j) c.projmatrix[16 * r + 4 * i + j] = P[4 * j + i];
 }
 
+__global__ void spf_camera_fwd_kernel(SpfCamera c) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < c.R) camera_fwd_one(c, r);
+}
+
+// The decoder's first launch: camera set-up AND the clearing of the per-tile counters the projection kernel
+// accumulates into (`zero`, 16-byte aligned, `nvec` uint4) -- one kernel instead of a kernel and a memset node.
+__global__ __launch_bounds__(kBlock) void spf_camera_fwd_zero_kernel(SpfCamera c, uint4* __restrict__ zero,
+                                                                     uint64_t nvec) {
+    const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (uint64_t i = t; i < nvec; i += (uint64_t)gridDim.x * kBlock) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (uint64_t r = t; r < (uint64_t)c.R; r += (uint64_t)gridDim.x * kBlock) camera_fwd_one(c, (int)r);
+}
+
 // dL/dA = -B^T (dL/dB) B^T with B = A^-1 = viewmatrix^T and dL/dB = (dL/dviewmatrix)^T; then undo the
 // translation rescale.
-__global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_dview,
-                                      float* __restrict__ dL_dext) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= c.R) return;
+__device__ __forceinline__ void camera_bwd_one(const SpfCamera& c, int r, const float* dL_dview,
+                                               float* __restrict__ dL_dext) {
     const float scale = c.scale_invariant ? 1.0f / c.near[r] : 1.0f;
     float Bt[16], Gb[16], T1[16];
 #pragma unroll
@@ -118,7 +128,7 @@ __global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Gb[4 * i + j] = dL_dview[16 * r + 4 * j + i];  // dL/dB
+        for (int j = 0; j < 4; ++j) Gb[4 * i + j] = dL_dview[4 * j + i];  // dL/dB
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -140,6 +150,39 @@ __global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_
         }
 }
 
+__global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_dview,
+                                      float* __restrict__ dL_dext) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < c.R) camera_bwd_one(c, r, dL_dview + 16 * r, dL_dext);
+}
+
+// The decoder's last launch: sum the projection backward's per-block viewmatrix partials vpartial[r][0..nblk)[12]
+// (fixed order: deterministic) and chain the result to the pose -- what spf_view_reduce_kernel + the kernel above do
+// in two launches.  grid = R, block = 64.
+__global__ void spf_camera_bwd_reduce_kernel(SpfCamera c, const float* __restrict__ vpartial, int nblk,
+                                             float* __restrict__ dL_dext) {
+    __shared__ float s_dv[16];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int b = lane; b < nblk; b += kWave) {
+        const float* pp = vpartial + ((size_t)r * nblk + b) * 12;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += pp[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+        // partial k < 9: dL/dVm[4i+j] with k = 3i+j (i, j < 3); k = 9+j: dL/dVm[12+j]; the last column gets none
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_dv[4 * i + j] = j < 3 ? acc[i < 3 ? 3 * i + j : 9 + j] : 0.f;
+        camera_bwd_one(c, r, s_dv, dL_dext);
+    }
+}
+
 hipError_t launch_camera_fwd(const SpfCamera& c, hipStream_t stream) {
     spf_camera_fwd_kernel<<<(c.R + 63) / 64, 64, 0, stream>>>(c);
     return hipGetLastError();
@@ -147,6 +190,20 @@ hipError_t launch_camera_fwd(const SpfCamera& c, hipStream_t stream) {
 
 hipError_t launch_camera_bwd(const SpfCamera& c, const float* dL_dview, float* dL_dext, hipStream_t stream) {
     spf_camera_bwd_kernel<<<(c.R + 63) / 64, 64, 0, stream>>>(c, dL_dview, dL_dext);
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_fwd_zero(const SpfCamera& c, void* zero, uint64_t nbytes, hipStream_t stream) {
+    const uint64_t nvec = nbytes / 16;
+    const uint64_t want = ((nvec > (uint64_t)c.R ? nvec : (uint64_t)c.R) + kBlock - 1) / kBlock;
+    const int grid = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+    spf_camera_fwd_zero_kernel<<<grid, kBlock, 0, stream>>>(c, static_cast<uint4*>(zero), nvec);
+    return hipGetLastError();
+}
+
+hipError_t launch_camera_bwd_reduce(const SpfCamera& c, const float* vpartial, int nblk, float* dL_dext,
+                                    hipStream_t stream) {
+    spf_camera_bwd_reduce_kernel<<<c.R, kWave, 0, stream>>>(c, vpartial, nblk, dL_dext);
     return hipGetLastError();
 }
 

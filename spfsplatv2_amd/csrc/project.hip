@@ -595,7 +595,7 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
-        if (gr.dL_dviewmatrix) {
+        if (gr.vpartial) {
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
                 const float tot = wave_sum(dV[k]);

@@ -132,8 +132,10 @@ def _on_device_of_first_arg(fn):
 
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
-                  view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0):
-    """Launch the forward chain.  Returns (outputs, saved state tensors)."""
+                  view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None):
+    """Launch the forward chain.  Returns (outputs, saved state tensors).  `camera` (an SpfCamera whose outputs are
+    viewmatrix / projmatrix / tanfov / view_scale): the decoder fast path -- camera set-up and the clearing of the tile
+    counters are one kernel."""
     lib = _lib.load()
     S, G, _ = means3D.shape
     V = viewmatrix.shape[1]
@@ -164,8 +166,15 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
                          _ptr(view_scale))
     st = _state_struct(rec, radii, rect, tiles, None, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
-    _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
-               "spf_raster_forward_project")
+    if camera is not None and tiles.data_ptr() % 16 == 0 and (R * T) % 2 == 0:
+        _lib.check(lib.spf_decoder_prepare(C.byref(camera), _ptr(tiles), 8 * R * T, stream), "spf_decoder_prepare")
+        _lib.check(lib.spf_raster_forward_project_prepared(C.byref(dims), C.byref(inp), C.byref(st), stream),
+                   "spf_raster_forward_project_prepared")
+    else:
+        if camera is not None:
+            _lib.check(lib.spf_camera_forward(C.byref(camera), stream), "spf_camera_forward")
+        _lib.check(lib.spf_raster_forward_project(C.byref(dims), C.byref(inp), C.byref(st), stream),
+                   "spf_raster_forward_project")
     if max_pairs is None:
         # exact mode: one 16-byte read-back per BATCH (the reference syncs twice per view,
         # cuda_splatting.py:108-109, plus once inside its rasterizer)
@@ -239,7 +248,9 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     d_rot = torch.empty_like(rotations) if want["scales_rot"] else None
     d_shs = torch.empty_like(shs) if (shs is not None and want["shs"]) else None
     d_col = torch.empty_like(colors) if (colors is not None and want["colors"]) else None
-    d_view = torch.empty_like(viewmatrix) if want["view"] else None
+    # want["view"] == "partials": leave the viewmatrix gradient as per-block partial sums (the decoder chains them to
+    # the poses in one kernel, spf_camera_backward_partials); returned in place of d_view
+    d_view = torch.empty_like(viewmatrix) if want["view"] is True else None
     vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
     d_m2d = torch.zeros((R, G, 3), **f32) if want["means2D"] else None
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
@@ -251,7 +262,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
                        _ptr(d_view), _ptr(d_m2d))
     _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity, dense,
                                        _stream_ptr(dev)), "spf_raster_backward")
-    return d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d
+    return d_means, d_scales, d_rot, d_opac, d_shs, d_col, (vpartial if want["view"] == "partials" else d_view), d_m2d
 
 
 class _RasterizeBatch(torch.autograd.Function):
@@ -305,10 +316,8 @@ class _DecoderRender(torch.autograd.Function):
         vscale = torch.empty((S, V), **f32) if scale_invariant else None
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
-        with torch.cuda.device(dev):
-            _lib.check(lib.spf_camera_forward(C.byref(cam), _stream_ptr(dev)), "spf_camera_forward")
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
-                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout)
+                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam)
         G = means3D.shape[1]
         K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
         ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout))
@@ -325,8 +334,8 @@ class _DecoderRender(torch.autograd.Function):
         need = ctx.needs_input_grad
         enable_cov_grad, enable_sh_grad, scale_invariant = ctx.flags
         want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
-                    colors=need[9], view=need[0], means2D=False)
-        d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, _ = _backward_impl(
+                    colors=need[9], view="partials" if need[0] else False, means2D=False)
+        d_means, d_scales, d_rot, d_opac, d_shs, d_col, vpartial, _ = _backward_impl(
             saved[:11], saved[11:19], ctx.geom, (g_image, g_depth, g_alpha), want)
         d_ext = None
         if need[0]:
@@ -335,8 +344,9 @@ class _DecoderRender(torch.autograd.Function):
             cam = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(view), None, None, None,
                                  view.shape[0] * view.shape[1], 1 if scale_invariant else 0)
             with torch.cuda.device(view.device):
-                _lib.check(lib.spf_camera_backward(C.byref(cam), _ptr(d_view), _ptr(d_ext),
-                                                   _stream_ptr(view.device)), "spf_camera_backward")
+                _lib.check(lib.spf_camera_backward_partials(C.byref(cam), _ptr(vpartial), vpartial.shape[1],
+                                                            _ptr(d_ext), _stream_ptr(view.device)),
+                           "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
                 None, None, None, None, None, None, None, None)
 
