@@ -11,15 +11,26 @@ share), i.e. decoder forward (projection, tile binning, depth sort, compositing)
 every Gaussian parameter and to the camera poses.  Renders are independent, so N GPUs shard scene-first with no
 data-path collective (weak scaling: every rank gets its own 8 x 4 batch).
 
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- `python -m torch.distributed.run`
+on 127.0.0.1, one process per GPU, backend nccl (= RCCL) -- and rank 0 prints the line with `n_gpus: N`.
+
+Timing: the `--steps` loop (EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks) is run as
+>= 25 back-to-back TRIALS adding up to >= 1 s of GPU work; `ms_per_step` / `value` are the MEDIAN trial and
+`trials_ms` keeps every trial (a single 10 ms sample was a 2 % lottery).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel's algorithmic HBM bytes / its HIP-event duration over the timed region
+  roofline      dominant kernel's algorithmic HBM bytes / its HIP-event duration over the timed region, plus
+                `valu`: the same kernel's VALU-issue roofline (it is instruction-issue bound, not HBM bound)
   cpu_baseline  the CPU oracle (oracle/splat_ref.py, kind "port") timed on the host cores on a bounded sample
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,6 +44,17 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0           # measured float4 copy ceiling
+CU_COUNT, SIMD_PER_CU, CLOCK_HZ = 256, 4, 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+
+# workload -> (default scenes per GPU, default views per scene); sizes live in spfsplatv2_amd/synthetic.py::CONFIGS
+WORKLOADS = {
+    "C2": (8, 4),        # BASELINE configs[1] at configs[3]'s per-GPU batch: the headline metric
+    "C3": (2, 4),        # 320k Gaussians
+    "C5": (1, 8),        # 500k Gaussians, SH degree 3, 512x512
+    "REF2V": (16, 1),    # what the shipped 2-view model really renders: 131,072 Gaussians (two 256x256 grids), 25 SH
+                         # coefficients per channel (sh_degree 4), batch 16 x 1 target view
+                         # (encoder_spfsplatv2.py:240,296-321; config/experiment/spfsplatv2/re10k.yaml:36-37,48)
+}
 
 
 def stage_bytes(stage: str, S: int, V: int, G: int, K: int, P: int, D_total: int) -> float:
@@ -66,10 +88,11 @@ def log(msg: str) -> None:
 def cpu_baseline(args, batch_cpu) -> dict:
     """CPU oracle, fwd+bwd, same workload, bounded sample (first scene, one view at a time until ~`--cpu-budget`
     seconds are spent).  The oracle's per-tile tensors are small, so more than ~16 threads only adds
-    synchronisation cost: threads = min(host cores, 16), and that is the `cores` reported."""
+    synchronisation cost: threads = min(host cores, 16); `cores` is what was used, `host_cores` what the box has."""
     from tests import util
     from spfsplatv2_amd import synthetic as syn
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
     S, V = batch_cpu.extrinsics.shape[:2]
     h, w = batch_cpu.image_shape
@@ -84,21 +107,25 @@ def cpu_baseline(args, batch_cpu) -> dict:
         spent += time.perf_counter() - t0
         done += 1
         log(f"cpu_baseline: {done} render(s), {spent:.1f} s")
-    return {"value": round(done * h * w / spent / 1e6, 5), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+    return {"value": round(done * h * w / spent / 1e6, 5), "unit": "Mpixels/s", "cores": cores,
+            "host_cores": host_cores, "kind": "port",
             "sample": f"{done} of the step's {S * V} renders, same workload "
                       f"({batch_cpu.means.shape[1]} Gaussians, {h}x{w}), oracle/splat_ref.py fwd+bwd in float32, "
-                      f"{spent:.1f} s on {cores} threads"}
+                      f"{spent:.1f} s on {cores} of the host's {host_cores} cores"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; default: WORLD_SIZE if a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scenes", type=int, default=8, help="scenes per GPU per step")
-    ap.add_argument("--views", type=int, default=4, help="target views per scene")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C5"])
+    ap.add_argument("--scenes", type=int, default=None, help="scenes per GPU per step (default: per --config)")
+    ap.add_argument("--views", type=int, default=None, help="target views per scene (default: per --config)")
+    ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--s-mult", type=float, default=1.0)
+    ap.add_argument("--min-trials", type=int, default=25, help="back-to-back repetitions of the --steps loop")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="GPU work the trials must add up to")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true",
@@ -119,14 +146,69 @@ def main():
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def rank_launch_command(n: int, argv: list[str], port: int) -> list[str]:
+    """The command `--gpus N` runs when no launcher set WORLD_SIZE: one process per GPU on this node, exactly the
+    driver's own form (torch.distributed.run, 127.0.0.1 rendezvous)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def launch_ranks(args, argv: list[str]) -> int:
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks here.  Never falls back to one GPU."""
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.one_device:
+        print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); refusing to report a smaller job "
+              "(--one-device --backend gloo exercises the multi-rank path on one GPU)", file=sys.stderr)
+        return 2
+    if args.one_device and args.backend == "nccl":
+        print("bench.py: --one-device needs --backend gloo (RCCL refuses two ranks on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = rank_launch_command(args.gpus, argv, port)
+    log("no launcher (WORLD_SIZE unset): " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    return subprocess.call(cmd, env=env)
+
+
+def valu_roofline(kernel: str, launch_ms: float, default_workload: bool):
+    """VALU-issue roofline of the dominant kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, so
+    frac = wave-instructions x 4 / (CUs x SIMDs x clock x launch time).  Wave-instructions per launch come from the SQ
+    counter pass committed under profiles/ (SQ_INSTS_VALU, collected on exactly the default workload)."""
+    prof = ROOT / "profiles" / "sq_summary.json"
+    if not (prof.exists() and default_workload):
+        return None
+    try:
+        insts = json.loads(prof.read_text())[kernel]["SQ_INSTS_VALU_per_launch"]
+    except Exception:
+        return None
+    peak = CU_COUNT * SIMD_PER_CU * CLOCK_HZ / 4.0                 # wave-instructions / s the chip can issue
+    ach = insts / (launch_ms * 1e-3)
+    return {"bound": "valu-issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
+            "unit": "G wave-instructions/s", "frac": round(ach / peak, 5), "wave_instructions_per_launch": insts}
+
+
+def main():
+    args = parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
+        # a launcher decides the job size; a line that claims another N than was run would be a lie
         if rank == 0:
-            print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+            print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     builder = rank == 0 if args.one_device else local_rank == 0
     if args.one_device:
         local_rank = 0
@@ -148,7 +230,8 @@ def main():
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
 
-    S, V = args.scenes, args.views
+    S = args.scenes if args.scenes is not None else WORKLOADS[args.config][0]
+    V = args.views if args.views is not None else WORKLOADS[args.config][1]
     from spfsplatv2_amd import shard
     if args.allreduce:      # same scenes everywhere, rank-specific target poses
         batch_cpu = syn.make_batch(args.config, S, V, seed=1000, s_mult=args.s_mult)
@@ -182,6 +265,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    def max_over_ranks(values: list[float]) -> list[float]:
+        if world == 1:
+            return values
+        t = torch.tensor(values, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
 
     log(f"batch resident: {S} scenes x {V} views, G={G}, K={K}, {h}x{w}")
     step()
@@ -219,24 +309,35 @@ def main():
     if eager_survey is not None:
         survey = {k: (v[0] * max(args.warmup, 1), max(args.warmup, 1)) for k, v in eager_survey.items()}
     dom = max(survey, key=lambda k: survey[k][0])
+    _lib.stage_timing_enable(False)
+
+    def trial() -> float:
+        """EXACTLY --steps steps between barrier + synchronize on both sides."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        return time.perf_counter() - t0
+
+    # number of trials: >= --min-trials and >= --min-seconds of GPU work in total, agreed between the ranks from a
+    # first (untimed, discarded) trial
+    est = max_over_ranks([trial()])[0]
+    n_trials = int(min(2000, max(args.min_trials, math.ceil(args.min_seconds / max(est, 1e-6)))))
+    # events around every n-th launch of the dominant kernel only (an event pair leaves the GPU idle for ~11 us):
+    # at most ~1000 samples over the whole timed region (the library keeps 1024 per stage)
     _lib.stage_timing_enable([dom])
-    _lib.stage_timing_sample_every(4)     # events around every 4th launch of the dominant kernel
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {dt:.3f} s")
+    _lib.stage_timing_sample_every(max(4, math.ceil(n_trials * args.steps / 1000)))
+    trials = [trial() for _ in range(n_trials)]
     stages = _lib.stage_times()
     _lib.stage_timing_enable(False)
     _lib.stage_timing_sample_every(1)
     if max_pairs is not None and spf.last_plan_flags() != 0:
         raise RuntimeError(f"the planned pair budget did not hold (flags {spf.last_plan_flags()}): results invalid")
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    trials = max_over_ranks(trials)                       # per trial: the slowest rank
+    dt = sorted(trials)[len(trials) // 2]                 # median trial
+    log(f"timed region: {n_trials} trials x {args.steps} steps = {sum(trials):.3f} s; median trial {dt * 1e3:.3f} ms, "
+        f"min {min(trials) * 1e3:.3f}, max {max(trials) * 1e3:.3f}")
 
     if rank == 0:
         P = h * w
@@ -248,20 +349,22 @@ def main():
         traffic = None
         prof = ROOT / "profiles" / "pmc_summary.json"
         default_workload = (args.config == "C2" and S == 8 and V == 4 and args.s_mult == 1.0 and not args.allreduce)
+        kernel = _lib.stage_kernel_name(dom)
         if prof.exists() and default_workload:      # the PMC passes were collected on exactly this workload
             try:
-                traffic = json.loads(prof.read_text()).get(_lib.stage_kernel_name(dom), {}).get("hbm_bytes_per_launch")
+                traffic = json.loads(prof.read_text()).get(kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         A = total_bytes(S, V, G, K, P, D_total)
+        deg = int(K ** 0.5) - 1
         out = {
             "metric": "Mpixels/s fwd+bwd, 256x256 @ ~65k Gaussians" if args.config == "C2" else
                       f"Mpixels/s fwd+bwd ({args.config})",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, SH degree "
-                                   f"{int(K ** 0.5) - 1}, {h}x{w}, {S} scenes x {V} views per GPU per step, "
+            "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, {K} SH coefficient(s) per "
+                                   f"channel (sh_degree {deg}), {h}x{w}, {S} scenes x {V} views per GPU per step, "
                                    "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
                        "loss": "torch.nn.functional.mse_loss" if args.torch_loss else "spfsplatv2_amd.mse_loss (fused HIP)",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
@@ -271,12 +374,15 @@ def main():
                        "launch": "hip-graph replay" if args.graph else "eager",
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},
-            "roofline": {"bound": "hbm", "kernel": _lib.stage_kernel_name(dom), "achieved": round(achieved, 2),
+            "timing": {"trials": n_trials, "statistic": "median trial; each trial = exactly `steps` steps between "
+                                                        "barrier+synchronize, max over ranks",
+                       "seconds_timed": round(sum(trials), 4)},
+            "trials_ms": [round(t * 1e3, 4) for t in trials],
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "launch_ms": round(dom_ms, 5),
                          "algorithmic_bytes_per_launch": dom_bytes,
-                         "limiter": "VALU issue, not HBM: SQ_ACTIVE_INST_VALU = 78 % of the SIMD cycles in this kernel "
-                                    "(profiles/r01_sq_counters.txt)" if dom == "render_bwd" else None,
+                         "valu": valu_roofline(kernel, dom_ms, default_workload),
                          "path_achieved_GBs": round(A / (dt / args.steps) / 1e9, 2),
                          "path_frac_of_copy_ceiling": round(A / (dt / args.steps) / 1e9 / HBM_COPY_GBS, 5)},
             "stage_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 5) for k, v in survey.items()},

@@ -40,7 +40,13 @@ def allreduce_gaussian_grads(grads: Sequence[torch.Tensor | None], group=None) -
     if not live:
         return
     flat = torch.cat([g.reshape(-1) for g in live])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        # testing configuration only (a CPU backend under device tensors): stage the bucket through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in live:
         n = g.numel()

@@ -123,6 +123,10 @@ CONFIGS = {
     "C2": (65536, (256, 256), (256, 256), 1, 1),
     "C3": (320000, (256, 256), (256, 256), 5, 1),
     "C5": (500000, (512, 512), (512, 512), 2, 16),
+    # what the shipped 2-view model hands its decoder: one Gaussian per context pixel of two 256x256 views, 25 SH
+    # coefficients per channel (/root/reference/src/model/encoder/encoder_spfsplatv2.py:240,296-321;
+    # config/model/encoder/spfsplatv2.yaml:20)
+    "REF2V": (131072, (256, 256), (256, 256), 2, 25),
     # small parity-test scenes (oracle finishes in seconds): up to 2 x 64 x 64 Gaussians
     "TEST": (4096, (64, 64), (64, 64), 2, 1),
     # many Gaussians per tile (exercises the long-list sort classes): up to 2 x 256 x 256 Gaussians
