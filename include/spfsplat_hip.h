@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SPF_ABI_VERSION 1
+#define SPF_ABI_VERSION 2
 
 #define SPF_OK 0
 #define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
@@ -52,12 +52,17 @@ extern "C" {
 
 /* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.
  * All scenes hold G Gaussians with K SH coefficients per colour channel (stride); the SH basis is
- * evaluated up to min(sh_degree, 3).  K == 0 means colours are given directly (colors_precomp). */
+ * evaluated up to min(sh_degree, 3), or min(sh_degree, 4) when sh_band4 is set.  K == 0 means colours are given
+ * directly (colors_precomp). */
 typedef struct SpfDims {
     int32_t S, V, G, K, sh_degree, H, W;
     float scale_modifier;
     int32_t sh_layout;   /* 0: shs / dL_dshs are [S,G,K,3] (what the reference hands its rasterizer,
                             cuda_splatting.py:79); 1: [S,G,3,K] (the encoder's native layout: no transposed copy) */
+    int32_t sh_band4;    /* 0 (default): the reference's d_sh = 25 / sh_degree 4 (config/model/encoder/spfsplatv2.yaml:20,
+                            cuda_splatting.py:77-78,114) is accepted as a stride and evaluated to degree 3 like the
+                            published 3DGS kernels; 1: band 4 (coefficients 16..24) is evaluated too, forward and
+                            backward (the `pose` fork's behaviour is not knowable offline: SURVEY.md 0.6) */
 } SpfDims;
 
 /* Inputs (all float32, contiguous, row-major). */
@@ -91,7 +96,7 @@ typedef struct SpfState {
     uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
                                         area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
                                         "rows" render kernels, the others the sparse "lists" kernels */
-    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: overflow flag 3: number of dense tiles */
+    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: plan verdict (0 = held) 3: number of dense tiles */
     uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
     uint32_t* pair_off;    /* [R*G]     index of the Gaussian's first (Gaussian, tile) pair in Gaussian-major order:
                                         its pair with the k-th tile of its rect (row-major) has index pair_off + k */
@@ -179,9 +184,11 @@ int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, in
  * kernels are launched; each tile is rendered by exactly one of them either way).
  * A caller that PLANS the call from an earlier one instead of reading the counters back (no device->host
  * synchronisation; capturable in a HIP graph) passes its assumptions here and they are checked on the device:
- * counters[2] = 0 if the plan held, else a bit mask: 1 = D > capacity (nothing was rendered, images untouched),
- * 2 = a tile list longer than max_tile_hint (left unsorted), 4 = dense_tiles_hint of 0 / all was wrong (some tiles
- * were not rendered).  With a non-zero flag the outputs of this call and of the matching backward are invalid. */
+ * counters[2] = 0 if the plan held, else a bit mask: 1 = D > capacity, 2 = a tile list longer than max_tile_hint
+ * (it could not be sorted), 4 = dense_tiles_hint of 0 / all was wrong (some tiles have no kernel).  A failed plan is
+ * never silent and never undefined: with a non-zero flag EVERY output of this call (image, depth, alpha) and every
+ * gradient of the matching backward is filled with NaN -- deterministic, and caught by the reference's own
+ * NaN-gradient guard (src/model/model_wrapper.py:1117-1151) even if the caller never reads the flag. */
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
                               uint64_t capacity, uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream);
 

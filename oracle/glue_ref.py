@@ -97,11 +97,15 @@ def orthographic_callsite_args(extrinsics, width, height, near, far, image_shape
     fov_y = (2 * tan_y).atan()
     near = near + dist
     far = far + dist
-    move_back = torch.eye(4).repeat(b, 1, 1)
-    move_back[:, 2, 3] = -dist
-    extrinsics = extrinsics @ move_back
+    # cuda_splatting.py:183-201 builds inverse(extrinsics @ move_back), move_back = translate(0, 0, -dist).  That
+    # equals translate(0, 0, +dist) @ inverse(extrinsics) -- the same matrix without a float32 inverse of a pose whose
+    # translation is ~10^3 units (that inverse is only good to ~1e-7 of the translation: pixel centres would wobble by
+    # ~1e-3 px between one inverse routine and the next).  Pinned against the reference's own call-site vectors
+    # (tests/golden/callsite_render_cuda.pt, `calls_ortho`) like the rest of this file.
+    w2c = torch.linalg.inv(extrinsics).clone()
+    w2c[:, 2, 3] = w2c[:, 2, 3] + dist
     proj = projection_matrix(near, far, fov_x.expand(b), fov_y).transpose(-1, -2)
-    view = torch.linalg.inv(extrinsics).transpose(-1, -2)
+    view = w2c.transpose(-1, -2)
     h, w = image_shape
     return [dict(image_height=h, image_width=w, tanfovx=float(tan_x), tanfovy=float(tan_y[i]), bg=background[i],
                  scale_modifier=1.0, projmatrix=proj[i], sh_degree=degree, means3D=means[i],
@@ -111,11 +115,13 @@ def orthographic_callsite_args(extrinsics, width, height, near, far, image_shape
 
 
 def decoder_forward(means, harmonics, opacities, rotations, scales, extrinsics, intrinsics, near, far, image_shape,
-                    background_color, make_scale_invariant=True, dtype=torch.float32, want_fragile=False):
+                    background_color, make_scale_invariant=True, dtype=torch.float32, want_fragile=False,
+                    band4=False, want_radii_fragile=False):
     """DecoderSplattingCUDA.forward (decoder_splatting_cuda.py:41-78) on the CPU oracle.
 
     [b,g,...] Gaussians, [b,v,...] cameras -> color [b,v,3,h,w], depth [b,v,h,w] (already x near),
-    alpha [b,v,1,h,w], radii [b,v,g] (+ fragile [b,v,h,w]).  Differentiable w.r.t. its float inputs.
+    alpha [b,v,1,h,w], radii [b,v,g] (+ fragile [b,v,h,w]) (+ radii_fragile [b,v,g]).  Differentiable w.r.t. its
+    float inputs.  `band4`: evaluate SH band 4 when d_sh = 25 (see splat_ref.SH_C4).
     """
     b, v = extrinsics.shape[:2]
     rep = lambda t: t[:, None].expand(b, v, *t.shape[1:]).reshape(b * v, *t.shape[1:])   # the `repeat`s
@@ -123,16 +129,19 @@ def decoder_forward(means, harmonics, opacities, rotations, scales, extrinsics, 
     args = callsite_args(extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(-1),
                          far.reshape(-1), image_shape, bg[None].expand(b * v, 3), rep(means), rep(harmonics),
                          rep(opacities), rep(rotations), rep(scales), scale_invariant=make_scale_invariant)
-    cols, deps, alps, rads, frs = [], [], [], [], []
+    cols, deps, alps, rads, frs, rfr = [], [], [], [], [], []
     for a in args:
         c = lambda t: None if t is None else t.to(dtype)
         out = splat_ref.rasterize(c(a["means3D"]), c(a["scales"]), c(a["rotations"]), c(a["opacities"]),
                                   c(a["shs"]), c(a["colors_precomp"]), c(a["viewmatrix"]), c(a["projmatrix"]),
                                   c(a["bg"]), a["tanfovx"], a["tanfovy"], a["image_height"], a["image_width"],
-                                  a["sh_degree"], a["scale_modifier"], want_fragile=want_fragile)
+                                  a["sh_degree"], a["scale_modifier"], want_fragile=want_fragile, band4=band4,
+                                  want_radii_fragile=want_radii_fragile)
         cols.append(out[0]); deps.append(out[1]); alps.append(out[2]); rads.append(out[3])
         if want_fragile:
             frs.append(out[4])
+        if want_radii_fragile:
+            rfr.append(out[-1])
     h, w = image_shape
     color = torch.stack(cols).reshape(b, v, 3, h, w)
     depth = torch.stack(deps).reshape(b, v, h, w)
@@ -140,6 +149,9 @@ def decoder_forward(means, harmonics, opacities, rotations, scales, extrinsics, 
         depth = depth * near.to(dtype)[:, :, None, None]                     # decoder_splatting_cuda.py:72-76
     alpha = torch.stack(alps).reshape(b, v, 1, h, w)
     radii = torch.stack(rads).reshape(b, v, -1)
+    res = (color, depth, alpha, radii)
     if want_fragile:
-        return color, depth, alpha, radii, torch.stack(frs).reshape(b, v, h, w)
-    return color, depth, alpha, radii
+        res += (torch.stack(frs).reshape(b, v, h, w),)
+    if want_radii_fragile:
+        res += (torch.stack(rfr).reshape(b, v, -1),)
+    return res

@@ -46,6 +46,14 @@ SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005,
 SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658,
          0.3731763325901154, -0.4570457994644658, 1.445305721320277,
          -0.5900435899266435)
+# Band 4 (the reference's default d_sh = 25, config/model/encoder/spfsplatv2.yaml:20).  The published 3DGS kernels stop
+# at degree 3; whether the `pose` fork evaluates band 4 is unknowable offline, so it is evaluated only
+# when asked (`band4=True`).  The constants continue the same real-SH family: index n(n+1)+m, same signs -- pinned by
+# tests/golden/sh_basis_goldens.pt, generated from the reference's own table
+# /root/reference/src/misc/sht.py::rsh_cart_4 (which also reproduces bands 0-3 above to 1e-15).
+SH_C4 = (2.5033429417967046, -1.7701307697799304, 0.9461746957575601,
+         -0.6690465435572892, 0.10578554691520431, -0.6690465435572892,
+         0.47308734787878004, -1.7701307697799304, 0.6258357354491761)
 
 NEAR_CULL = 0.2          # B#3
 LOWPASS = 0.3            # B#5
@@ -104,6 +112,11 @@ def sh_basis(deg: int, d: Tensor) -> Tensor:
                 SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy),
                 SH_C3[4] * x * (4 * zz - xx - yy), SH_C3[5] * z * (xx - yy),
                 SH_C3[6] * x * (xx - 3 * yy)]
+    if deg > 3:
+        out += [SH_C4[0] * xy * (xx - yy), SH_C4[1] * yz * (3 * xx - yy), SH_C4[2] * xy * (7 * zz - 1),
+                SH_C4[3] * yz * (7 * zz - 3), SH_C4[4] * (zz * (35 * zz - 30) + 3),
+                SH_C4[5] * xz * (7 * zz - 3), SH_C4[6] * (xx - yy) * (7 * zz - 1),
+                SH_C4[7] * xz * (xx - 3 * yy), SH_C4[8] * (xx * (xx - 3 * yy) - yy * (3 * xx - yy))]
     return torch.stack(out, dim=-1)
 
 
@@ -116,8 +129,16 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
             shs: Tensor | None, colors_precomp: Tensor | None,
             viewmatrix: Tensor, projmatrix: Tensor,
             tanfovx: float, tanfovy: float, H: int, W: int,
-            sh_degree: int, scale_modifier: float = 1.0) -> Projected:
-    """Per-Gaussian preprocess (stage R1)."""
+            sh_degree: int, scale_modifier: float = 1.0, band4: bool = False,
+            frozen: dict | None = None, capture: dict | None = None) -> Projected:
+    """Per-Gaussian preprocess (stage R1).
+
+    `capture` / `frozen` make the three [3DGS-grad] conventions testable: a call with `capture={}` records the
+    constants each convention treats as fixed (clamped Jacobian coordinates, colour clamp mask, and -- in
+    `composite` -- the alpha clamp offset); a call with `frozen=<that dict>` evaluates the plain, fully differentiable
+    function in which those values ARE constants.  The documented meaning of the conventions is then: autograd
+    gradient of the normal call == true (finite-difference) gradient of the frozen function
+    (tests/test_oracle_fd.py)."""
     dt = means3D.dtype
     G = means3D.shape[0]
     Rv, tv = viewmatrix[:3, :3], viewmatrix[3, :3]
@@ -140,8 +161,14 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
     txz, tyz = t[:, 0] / safe_tz, t[:, 1] / safe_tz
     # [3DGS-grad] when clamped, the clamped coordinate is a constant (no gradient to t.x,
     # and none to t.z through the clamp product).
-    tcx = torch.where(txz.abs() <= limx, t[:, 0], (txz.clamp(-limx, limx) * safe_tz).detach())
-    tcy = torch.where(tyz.abs() <= limy, t[:, 1], (tyz.clamp(-limy, limy) * safe_tz).detach())
+    inx, iny = txz.abs() <= limx, tyz.abs() <= limy
+    cx, cy = (txz.clamp(-limx, limx) * safe_tz).detach(), (tyz.clamp(-limy, limy) * safe_tz).detach()
+    if frozen is not None:
+        inx, iny, cx, cy = frozen["jac_clamp"]
+    if capture is not None:
+        capture["jac_clamp"] = (inx, iny, cx, cy)
+    tcx = torch.where(inx, t[:, 0], cx)
+    tcy = torch.where(iny, t[:, 1], cy)
     zero = torch.zeros_like(tz)
     J = torch.stack([
         fx / safe_tz, zero, -fx * tcx / (safe_tz * safe_tz),
@@ -186,14 +213,19 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
     if colors_precomp is not None:
         rgb = colors_precomp
     else:
-        deg = min(sh_degree, 3)     # band 4 coefficients are carried (stride) but not evaluated
+        deg = min(sh_degree, 4 if band4 else 3)     # band 4: carried (stride), evaluated only on request
         K = (deg + 1) ** 2
         v = means3D - camera_position(viewmatrix)
         d = v / v.norm(dim=-1, keepdim=True)
         basis = sh_basis(deg, d)                            # [G,K]
         rgb = torch.einsum("gk,gkc->gc", basis, shs[:, :K, :]) + 0.5
         rgb_raw = rgb.detach()
-        rgb = torch.clamp(rgb, min=0.0)                     # gradient masked where clamped
+        if frozen is not None:
+            rgb = rgb * frozen["rgb_mask"]
+        else:
+            rgb = torch.clamp(rgb, min=0.0)                 # [3DGS-grad] gradient masked where clamped
+        if capture is not None:
+            capture["rgb_mask"] = (rgb_raw >= 0).to(dt)
     return Projected(xy=xy, depth=tz, conic=conic, opacity=opacities.reshape(G),
                      rgb=rgb.to(dt), radii=radii, rect_min=rect_min, rect_max=rect_max,
                      radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw)
@@ -216,10 +248,12 @@ def tile_lists(pr: Projected, H: int, W: int):
             yield tx, ty, ids
 
 
-def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = False):
+def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = False,
+              frozen: dict | None = None, capture: dict | None = None):
     """Tile-wise front-to-back alpha compositing (stage R6).
 
     Returns image[3,H,W], depth[1,H,W], alpha[1,H,W] (+ fragile[H,W] bool if asked).
+    `frozen` / `capture`: see `project` (here: the offset that turns o*exp(power) into min(0.99, .), per tile).
     """
     dt = pr.xy.dtype
     rows_c = [[None] * ((W + TILE - 1) // TILE) for _ in range((H + TILE - 1) // TILE)]
@@ -248,7 +282,12 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
             o = pr.opacity[ids][None, :]
             raw = o * torch.exp(torch.clamp(power, max=0.0))
             # [3DGS-grad] min(0.99, .) is straight-through in the backward pass.
-            alpha = raw + (torch.clamp(raw, max=ALPHA_MAX) - raw).detach()
+            off = (torch.clamp(raw, max=ALPHA_MAX) - raw).detach()
+            if frozen is not None:
+                off = frozen["alpha_clamp"][(tx, ty)]
+            if capture is not None:
+                capture.setdefault("alpha_clamp", {})[(tx, ty)] = off
+            alpha = raw + off
             with torch.no_grad():
                 valid = (power <= 0) & (alpha >= ALPHA_MIN)
             a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
@@ -297,15 +336,17 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
               shs: Tensor | None, colors_precomp: Tensor | None,
               viewmatrix: Tensor, projmatrix: Tensor, bg: Tensor,
               tanfovx: float, tanfovy: float, H: int, W: int,
-              sh_degree: int, scale_modifier: float = 1.0, want_fragile: bool = False):
+              sh_degree: int, scale_modifier: float = 1.0, want_fragile: bool = False, band4: bool = False,
+              frozen: dict | None = None, capture: dict | None = None, want_radii_fragile: bool = False):
     """One (scene, view) render: the semantics of one ``GaussianRasterizer(settings)(...)`` call
     (/root/reference/src/model/decoder/cuda_splatting.py:124-138).
 
     Returns (image[3,H,W], depth[1,H,W], alpha[1,H,W], radii[G] int32[, fragile[H,W]]).
     """
     pr = project(means3D, scales, rotations, opacities, shs, colors_precomp, viewmatrix,
-                 projmatrix, tanfovx, tanfovy, H, W, sh_degree, scale_modifier)
-    out = composite(pr, bg, H, W, want_fragile=want_fragile)
+                 projmatrix, tanfovx, tanfovy, H, W, sh_degree, scale_modifier, band4=band4,
+                 frozen=frozen, capture=capture)
+    out = composite(pr, bg, H, W, want_fragile=want_fragile, frozen=frozen, capture=capture)
     if want_fragile:
         # Tile membership decided by a rounding knife-edge (footprint radius within 1e-4 of an integer, or a rect
         # bound within ~1e-4 px of a tile border): only the tiles whose membership would actually change are
@@ -356,8 +397,35 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
                 if y1p > y0p and x1p > x0p:
                     reach[y0p:y1p, x0p:x1p] = True
                 fr |= box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W] & reach
-        return out[0], out[1], out[2], pr.radii, fr
-    return out[0], out[1], out[2], pr.radii
+        res = (out[0], out[1], out[2], pr.radii, fr)
+    else:
+        res = (out[0], out[1], out[2], pr.radii)
+    return res + (radii_fragile(pr, H, W),) if want_radii_fragile else res
+
+
+def radii_fragile(pr: Projected, H: int, W: int) -> Tensor:
+    """[G] bool: Gaussians whose integer `radii` entry (B#6) is decided by a rounding knife-edge -- 3*sqrt(lambda)
+    within ~1e-5 relative of an integer (the ceil), a tile rect whose area flips between zero and non-zero, or a
+    depth at the near cull.  Everywhere else the product's radii must equal the oracle's exactly."""
+    with torch.no_grad():
+        gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+        px, py = pr.xy[:, 0].double(), pr.xy[:, 1].double()
+        raw = pr.radius_raw.double()
+        tz = pr.depth.detach().double()
+        eps = 1e-4 + 2e-6 * px.abs().clamp(max=1e6)
+        r_lo, r_hi = torch.ceil(raw * (1 - 1e-5) - 1e-4), torch.ceil(raw * (1 + 1e-5) + 1e-4)
+
+        def area(pxl, pxh, pyl, pyh, rad):
+            x0 = torch.trunc((pxl - rad) / TILE).clamp(0, gx); y0 = torch.trunc((pyl - rad) / TILE).clamp(0, gy)
+            x1 = torch.trunc((pxh + rad + TILE - 1) / TILE).clamp(0, gx)
+            y1 = torch.trunc((pyh + rad + TILE - 1) / TILE).clamp(0, gy)
+            return (x1 - x0).clamp(min=0) * (y1 - y0).clamp(min=0)
+
+        big = area(px - eps, px + eps, py - eps, py + eps, r_hi) > 0
+        small = area(px + eps, px - eps, py + eps, py - eps, r_lo) > 0
+        near = (tz - NEAR_CULL).abs() < 1e-5
+        odd = ~(torch.isfinite(px) & torch.isfinite(py) & torch.isfinite(raw))
+        return (((r_lo != r_hi) | (big != small)) & (tz > NEAR_CULL - 1e-5)) | near | odd
 
 
 def num_pairs(pr: Projected) -> int:

@@ -12,7 +12,7 @@ from pathlib import Path
 
 # SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
 LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
                "project_bwd", "rope2d")
@@ -22,7 +22,7 @@ STAGE_COUNT = len(STAGE_NAMES)
 class SpfDims(C.Structure):
     _fields_ = [("S", C.c_int32), ("V", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("sh_degree", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("scale_modifier", C.c_float), ("sh_layout", C.c_int32)]
+                ("scale_modifier", C.c_float), ("sh_layout", C.c_int32), ("sh_band4", C.c_int32)]
 
 
 def _ptr_struct(name, fields):

@@ -90,7 +90,11 @@ class UnifiedGaussianAdapter(nn.Module):
         return 7 + 3 * self.d_sh
 
     def forward(self, means: Tensor, opacities: Tensor, raw_gaussians: Tensor, eps: float = 1e-8,
-                with_covariances: bool = False) -> Gaussians:
+                with_covariances: bool = True) -> Gaussians:
+        """``with_covariances`` (default True, as the reference: gaussian_adapter.py:140-141 always builds them, and
+        encoder_spfsplatv2.py:302, validation_in_3d.py and validate_in_the_wild.py read them).  The render path never
+        does (cuda_splatting.py:136), so a training loop may pass False to skip the 36 bytes per Gaussian: the field is
+        then a zero-stride NaN tensor -- any accidental use is loud, never a silent zero."""
         if raw_gaussians.shape[-1] != self.d_in:
             raise RuntimeError(f"raw_gaussians has {raw_gaussians.shape[-1]} channels, expected {self.d_in}")
         if not raw_gaussians.is_cuda:
@@ -104,6 +108,6 @@ class UnifiedGaussianAdapter(nn.Module):
             from .adapter_cov import build_covariance
             cov = build_covariance(scales, rot)
         else:
-            cov = torch.zeros((), dtype=torch.float32, device=raw.device).expand(*batch, 3, 3)
+            cov = torch.full((), float("nan"), dtype=torch.float32, device=raw.device).expand(*batch, 3, 3)
         return Gaussians(means=means, covariances=cov, scales=scales,
                          rotations=rot.broadcast_to((*scales.shape[:-1], 4)), harmonics=sh, opacities=opacities)

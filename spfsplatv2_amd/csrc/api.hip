@@ -96,6 +96,8 @@ int check_dims(const SpfDims* d) {
         return fail(SPF_E_INVALID, "image larger than 4080 px per side is not supported");
     if (d->sh_degree < 0 || d->sh_degree > 4) return fail(SPF_E_INVALID, "sh_degree %d outside 0..4", d->sh_degree);
     if (d->K < 0) return fail(SPF_E_INVALID, "K must be >= 0");
+    if (d->sh_band4 != 0 && d->sh_band4 != 1) return fail(SPF_E_INVALID, "sh_band4 must be 0 or 1");
+    if (d->sh_layout != 0 && d->sh_layout != 1) return fail(SPF_E_INVALID, "sh_layout must be 0 or 1");
     return SPF_OK;
 }
 
@@ -107,7 +109,8 @@ int check_inputs(const SpfDims* d, const SpfInputs* in) {
     if ((in->shs == nullptr) == (in->colors == nullptr))
         return fail(SPF_E_INVALID, "exactly one of shs / colors must be given");
     if (in->shs) {
-        const int deg = d->sh_degree > 3 ? 3 : d->sh_degree;
+        const int cap = d->sh_band4 ? 4 : 3;
+        const int deg = d->sh_degree > cap ? cap : d->sh_degree;
         if (d->K < (deg + 1) * (deg + 1))
             return fail(SPF_E_INVALID, "K = %d is too small for sh_degree %d", d->K, d->sh_degree);
     }

@@ -393,12 +393,14 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint3
     if (mx > 2048)
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        // the opt-in to 128 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_lds_kernel<1024>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e != hipSuccess) return e;
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 8192, 16384);
     }

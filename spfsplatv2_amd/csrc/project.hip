@@ -94,7 +94,8 @@ __device__ __forceinline__ void project_point(const float p[3], const float* __r
     o.det = o.a * o.c - o.b * o.b;
 }
 
-// SH basis (deg <= 3) for unit direction (x,y,z); optional derivatives.
+// SH basis (deg <= 4) for unit direction (x,y,z); optional derivatives (of the polynomials as written; the caller
+// projects them onto the tangent space of the unit sphere).
 template <int DEG, bool WITH_GRAD>
 __device__ __forceinline__ void sh_basis(float x, float y, float z, float* __restrict__ b,
                                          float* __restrict__ dbx, float* __restrict__ dby,
@@ -140,45 +141,138 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* __res
                 dbx[14] = SH_C3[5] * 2.f * xz; dby[14] = SH_C3[5] * -2.f * yz; dbz[14] = SH_C3[5] * (xx - yy);
                 dbx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); dby[15] = SH_C3[6] * -6.f * xy; dbz[15] = 0.f;
             }
+            if (DEG > 3) {
+                const float z7m1 = 7.f * zz - 1.f, z7m3 = 7.f * zz - 3.f, xmy = xx - yy;
+                b[16] = SH_C4[0] * xy * xmy;
+                b[17] = SH_C4[1] * yz * (3.f * xx - yy);
+                b[18] = SH_C4[2] * xy * z7m1;
+                b[19] = SH_C4[3] * yz * z7m3;
+                b[20] = SH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f);
+                b[21] = SH_C4[5] * xz * z7m3;
+                b[22] = SH_C4[6] * xmy * z7m1;
+                b[23] = SH_C4[7] * xz * (xx - 3.f * yy);
+                b[24] = SH_C4[8] * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+                if (WITH_GRAD) {
+                    dbx[16] = SH_C4[0] * y * (3.f * xx - yy); dby[16] = SH_C4[0] * x * (xx - 3.f * yy); dbz[16] = 0.f;
+                    dbx[17] = SH_C4[1] * 6.f * xy * z; dby[17] = SH_C4[1] * z * (3.f * xx - 3.f * yy);
+                    dbz[17] = SH_C4[1] * y * (3.f * xx - yy);
+                    dbx[18] = SH_C4[2] * y * z7m1; dby[18] = SH_C4[2] * x * z7m1; dbz[18] = SH_C4[2] * 14.f * xy * z;
+                    dbx[19] = 0.f; dby[19] = SH_C4[3] * z * z7m3; dbz[19] = SH_C4[3] * y * (21.f * zz - 3.f);
+                    dbx[20] = 0.f; dby[20] = 0.f; dbz[20] = SH_C4[4] * z * (140.f * zz - 60.f);
+                    dbx[21] = SH_C4[5] * z * z7m3; dby[21] = 0.f; dbz[21] = SH_C4[5] * x * (21.f * zz - 3.f);
+                    dbx[22] = SH_C4[6] * 2.f * x * z7m1; dby[22] = SH_C4[6] * -2.f * y * z7m1;
+                    dbz[22] = SH_C4[6] * 14.f * z * xmy;
+                    dbx[23] = SH_C4[7] * z * (3.f * xx - 3.f * yy); dby[23] = SH_C4[7] * -6.f * xy * z;
+                    dbz[23] = SH_C4[7] * x * (xx - 3.f * yy);
+                    dbx[24] = SH_C4[8] * 4.f * x * (xx - 3.f * yy); dby[24] = SH_C4[8] * 4.f * y * (yy - 3.f * xx);
+                    dbz[24] = 0.f;
+                }
+            }
         }
     }
 }
 
 // SH coefficient block of one Gaussian: K coefficients per channel, stored [K,3] (layout 0) or [3,K] (layout 1).
-// Coefficients are consumed four at a time through three 16-byte loads (any layout) when K % 4 == 0; otherwise
-// one by one.  v[i][c] = coefficient 4*k4+i of channel c.
-template <bool NATIVE>
+// Coefficients are consumed four at a time through three 16-byte accesses (any layout), the remaining NB % 4 one by
+// one.  ALIGNED (K % 4 == 0): the accesses are 16-byte aligned; otherwise (K = 25, the reference's default d_sh) the
+// block of a Gaussian starts at a multiple of 4 bytes only and the same dwordx4 instructions are issued with dword
+// alignment (legal for global memory on gfx9+; a 75-float block read through 4-byte loads costs 4x the instructions
+// and address-coalescer cycles).  v[i][c] = coefficient 4*k4+i of channel c.
+typedef float f4a __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool ALIGNED>
+__device__ __forceinline__ f4a ld4(const float* __restrict__ p) {
+    if (ALIGNED) return *reinterpret_cast<const f4a*>(p);
+    return *reinterpret_cast<const f4u*>(p);
+}
+template <bool ALIGNED>
+__device__ __forceinline__ void st4(float* __restrict__ p, float a, float b, float c, float d) {
+    const f4a v = {a, b, c, d};
+    if (ALIGNED) *reinterpret_cast<f4a*>(p) = v;
+    else *reinterpret_cast<f4u*>(p) = v;
+}
+template <bool NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_load4(const float* __restrict__ sh, int K, int k4, float v[4][3]) {
     if (NATIVE) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float4 t = *reinterpret_cast<const float4*>(sh + c * K + 4 * k4);
+            const f4a t = ld4<ALIGNED>(sh + c * K + 4 * k4);
             v[0][c] = t.x; v[1][c] = t.y; v[2][c] = t.z; v[3][c] = t.w;
         }
     } else {
-        const float4* __restrict__ p = reinterpret_cast<const float4*>(sh + 12 * k4);
-        const float4 a = p[0], b = p[1], c = p[2];
+        const f4a a = ld4<ALIGNED>(sh + 12 * k4), b = ld4<ALIGNED>(sh + 12 * k4 + 4), c = ld4<ALIGNED>(sh + 12 * k4 + 8);
         v[0][0] = a.x; v[0][1] = a.y; v[0][2] = a.z; v[1][0] = a.w;
         v[1][1] = b.x; v[1][2] = b.y; v[2][0] = b.z; v[2][1] = b.w;
         v[2][2] = c.x; v[3][0] = c.y; v[3][1] = c.z; v[3][2] = c.w;
     }
 }
-template <bool NATIVE>
+template <bool NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_store4(float* __restrict__ sh, int K, int k4, const float v[4][3]) {
     if (NATIVE) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            *reinterpret_cast<float4*>(sh + c * K + 4 * k4) = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        for (int c = 0; c < 3; ++c) st4<ALIGNED>(sh + c * K + 4 * k4, v[0][c], v[1][c], v[2][c], v[3][c]);
     } else {
-        float4* __restrict__ p = reinterpret_cast<float4*>(sh + 12 * k4);
-        p[0] = make_float4(v[0][0], v[0][1], v[0][2], v[1][0]);
-        p[1] = make_float4(v[1][1], v[1][2], v[2][0], v[2][1]);
-        p[2] = make_float4(v[2][2], v[3][0], v[3][1], v[3][2]);
+        st4<ALIGNED>(sh + 12 * k4, v[0][0], v[0][1], v[0][2], v[1][0]);
+        st4<ALIGNED>(sh + 12 * k4 + 4, v[1][1], v[1][2], v[2][0], v[2][1]);
+        st4<ALIGNED>(sh + 12 * k4 + 8, v[2][2], v[3][0], v[3][1], v[3][2]);
     }
+}
+// zero n floats at p (dword aligned): the gradient of coefficients that are carried but not evaluated
+__device__ __forceinline__ void zero_floats(float* __restrict__ p, int n) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4) st4<false>(p + i, 0.f, 0.f, 0.f, 0.f);
+    for (; i < n; ++i) p[i] = 0.f;
 }
 template <bool NATIVE>
 __device__ __forceinline__ float sh_at(const float* __restrict__ sh, int K, int k, int c) {
     return NATIVE ? sh[c * K + k] : sh[3 * k + c];
+}
+
+// colour = sum_k basis_k sh_k (forward), optionally with D{x,y,z}[c] = sum_k dbasis_k/d{x,y,z} sh_k[c] (backward)
+template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD>
+__device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const float* basis,
+                                            const float* dbx, const float* dby, const float* dbz, float col[3],
+                                            float Dx[3], float Dy[3], float Dz[3]) {
+    constexpr int NV = NB / 4;
+#pragma unroll
+    for (int k4 = 0; k4 < NV; ++k4) {
+        float v[4][3];
+        sh_load4<NATIVE, ALIGNED>(sh, K, k4, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int k = 4 * k4 + i;
+                col[c] += basis[k] * v[i][c];
+                if (WITH_GRAD) { Dx[c] += dbx[k] * v[i][c]; Dy[c] += dby[k] * v[i][c]; Dz[c] += dbz[k] * v[i][c]; }
+            }
+    }
+#pragma unroll
+    for (int k = 4 * NV; k < NB; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = sh_at<NATIVE>(sh, K, k, c);
+            col[c] += basis[k] * v;
+            if (WITH_GRAD) { Dx[c] += dbx[k] * v; Dy[c] += dby[k] * v; Dz[c] += dbz[k] * v; }
+        }
+}
+// dL/dsh of the NB evaluated coefficients, zeros for the K - NB that are only carried
+template <int NB, bool NATIVE, bool ALIGNED>
+__device__ __forceinline__ void sh_store_grad(float* __restrict__ o, int K, const float (*dsh)[3]) {
+    constexpr int NV = NB / 4;
+#pragma unroll
+    for (int k4 = 0; k4 < NV; ++k4) sh_store4<NATIVE, ALIGNED>(o, K, k4, &dsh[4 * k4]);
+    const int sk = NATIVE ? 1 : 3, sc = NATIVE ? K : 1;
+#pragma unroll
+    for (int k = 4 * NV; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
+    if (K > NB) {
+        if (NATIVE) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) zero_floats(o + c * K + NB, K - NB);
+        } else {
+            zero_floats(o + 3 * NB, 3 * (K - NB));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -279,26 +373,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                                                      nullptr, nullptr);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
                 col[0] = col[1] = col[2] = 0.f;
-                if (NB % 4 == 0 && d.K % 4 == 0) {
-#pragma unroll
-                    for (int k4 = 0; k4 < NB / 4; ++k4) {
-                        float v[4][3];
-                        sh_load4<NATIVE>(sh, d.K, k4, v);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            col[0] += basis[4 * k4 + i] * v[i][0];
-                            col[1] += basis[4 * k4 + i] * v[i][1];
-                            col[2] += basis[4 * k4 + i] * v[i][2];
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        col[0] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 0);
-                        col[1] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 1);
-                        col[2] += basis[k] * sh_at<NATIVE>(sh, d.K, k, 2);
-                    }
-                }
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, basis, nullptr, nullptr, nullptr, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false>(sh, d.K, basis, nullptr, nullptr, nullptr, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -379,11 +455,27 @@ constexpr int kViewChunk = 64;
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
-    if (st.counters[0] > capacity) return;   // a planned pair buffer was too small: nothing was rendered, no pair records
+    (void)capacity;
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     const bool live = g < d.G;
     const size_t sg = (size_t)s * d.G + (live ? g : 0);
+    if (st.counters[2] != 0u) {
+        // the forward's plan did not hold (see render.hip::poison_tile): nothing was rendered and there are no pair
+        // records -- every gradient this kernel owns becomes NaN instead of staying uninitialised
+        const float nan = __builtin_nanf("");
+        if (gr.vpartial)
+            for (int i = threadIdx.x; i < d.V * 12; i += kBlock)
+                gr.vpartial[((size_t)(s * d.V + i / 12) * nblk + blockIdx.x) * 12 + i % 12] = nan;
+        if (!live) return;
+        for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * sg + k] = nan;
+        gr.dL_dopacities[sg] = nan;
+        if (gr.dL_dcolors) for (int k = 0; k < 3; ++k) gr.dL_dcolors[3 * sg + k] = nan;
+        if (gr.dL_dshs) for (int k = 0; k < 3 * d.K; ++k) gr.dL_dshs[sg * (size_t)d.K * 3 + k] = nan;
+        if (gr.dL_dscales) for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * sg + k] = nan;
+        if (gr.dL_drotations) for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * sg + k] = nan;
+        return;
+    }
     float p0[3] = {0.f, 0.f, 0.f};
     float sx = 1.f, sy = 1.f, sz = 1.f, opac = 0.f;
     float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -530,30 +622,8 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
                 // s_k = sh_k . dL/dcolour for the direction gradient.
                 float col[3] = {0.f, 0.f, 0.f};
                 float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};  // sum_k dbasis_k sh_k[c]
-                if (NB % 4 == 0 && d.K % 4 == 0) {
-#pragma unroll
-                    for (int k4 = 0; k4 < NB / 4; ++k4) {
-                        float v[4][3];
-                        sh_load4<NATIVE>(sh, d.K, k4, v);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const int k = 4 * k4 + i;
-                                col[c] += basis[k] * v[i][c];
-                                if (DEG > 0) { Dx[c] += dbx[k] * v[i][c]; Dy[c] += dby[k] * v[i][c]; Dz[c] += dbz[k] * v[i][c]; }
-                            }
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float v = sh_at<NATIVE>(sh, d.K, k, c);
-                            col[c] += basis[k] * v;
-                            if (DEG > 0) { Dx[c] += dbx[k] * v; Dy[c] += dby[k] * v; Dz[c] += dbz[k] * v; }
-                        }
-                }
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, (DEG > 0)>(sh, d.K, basis, dbx, dby, dbz, col, Dx, Dy, Dz);
+                else sh_contract<NB, NATIVE, false, (DEG > 0)>(sh, d.K, basis, dbx, dby, dbz, col, Dx, Dy, Dz);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch)
                     if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
@@ -625,15 +695,8 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
         }
     } else if (gr.dL_dshs) {
         float* __restrict__ o = gr.dL_dshs + sg * (size_t)d.K * 3;
-        const int sk = NATIVE ? 1 : 3, sc = NATIVE ? d.K : 1;
-        if (NB % 4 == 0 && d.K % 4 == 0) {
-#pragma unroll
-            for (int k4 = 0; k4 < NB / 4; ++k4) sh_store4<NATIVE>(o, d.K, k4, &dsh[4 * k4]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
-        }
-        for (int k = NB; k < d.K; ++k) { o[sk * k] = 0.f; o[sk * k + sc] = 0.f; o[sk * k + 2 * sc] = 0.f; }
+        if (d.K % 4 == 0) sh_store_grad<NB, NATIVE, true>(o, d.K, dsh);
+        else sh_store_grad<NB, NATIVE, false>(o, d.K, dsh);
     }
     if (gr.dL_dscales && gr.dL_drotations) {
         // Sigma = Rm diag(s^2) Rm^T.  G = symmetric gradient matrix with G_ij = dL/dSigma_ij (full partials).
@@ -697,6 +760,11 @@ __global__ void spf_view_reduce_kernel(const float* __restrict__ vpartial, float
 }
 
 // ---- host-side launchers (called from api.hip) ---------------------------------------------
+// degree the SH basis is evaluated to: band 4 (d_sh = 25) only on request, see SpfDims.sh_band4
+static inline int sh_eval_degree(const SpfDims& d) {
+    const int cap = d.sh_band4 ? 4 : 3;
+    return d.sh_degree > cap ? cap : d.sh_degree;
+}
 template <int DEG, bool NATIVE>
 static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDims& d, const SpfInputs& in,
                           const SpfState& st, int tiles_x, int tiles_y, int lds) {
@@ -718,13 +786,15 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
         case 4: FN<2, false>(__VA_ARGS__); break;                        \
         case 5: FN<2, true>(__VA_ARGS__); break;                         \
         case 6: FN<3, false>(__VA_ARGS__); break;                        \
-        default: FN<3, true>(__VA_ARGS__); break;                        \
+        case 7: FN<3, true>(__VA_ARGS__); break;                         \
+        case 8: FN<4, false>(__VA_ARGS__); break;                        \
+        default: FN<4, true>(__VA_ARGS__); break;                        \
     }
 
 hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, int tiles_x, int tiles_y,
                               hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S);
-    const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    const int deg = in.colors ? -1 : sh_eval_degree(d);
     const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
     const int lds = T <= kMaxLdsTiles ? 1 : 0;
@@ -736,7 +806,7 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
 hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
                               int nblk, uint64_t capacity, hipStream_t stream) {
     dim3 grid(nblk, d.S);
-    const int deg = in.colors ? -1 : (d.sh_degree > 3 ? 3 : d.sh_degree);
+    const int deg = in.colors ? -1 : sh_eval_degree(d);
     const bool native = d.sh_layout != 0;
     SPF_DISPATCH_DEG(project_bwd_t, grid, stream, d, in, st, g, nblk, capacity)
     hipError_t e = hipGetLastError();

@@ -114,6 +114,27 @@ __device__ __forceinline__ uint32_t block_bits(float gx, float gy, float r2, int
     return bits;
 }
 
+// A PLANNED call (see spf_raster_forward_render) whose plan did not hold -- counters[2] != 0: pair buffer too small, a
+// list too long to have been sorted, or tiles without a kernel -- must not leave uninitialised or half-right pixels
+// behind: every render kernel that runs then fills its tiles' outputs with NaN instead of rendering (both kernels
+// cover every tile, so whichever was launched poisons the whole batch).  The flag also subsumes the memory-safety
+// guard `D > capacity`.
+__device__ __forceinline__ void poison_tile(int RT, int T, int tiles_x, int H, int W, float* __restrict__ image,
+                                            float* __restrict__ depth_out, float* __restrict__ alpha_out) {
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    if (vid >= RT) return;
+    const int r = vid / T, tile = vid - r * T;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int px = tx * kTile + (threadIdx.x & 15), py = ty * kTile + (threadIdx.x >> 4);
+    if (px >= W || py >= H) return;
+    const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
+    const float nan = __builtin_nanf("");
+    float* __restrict__ img = image + (size_t)r * 3 * P;
+    img[pix] = nan; img[P + pix] = nan; img[2 * P + pix] = nan;
+    depth_out[(size_t)r * P + pix] = nan;
+    alpha_out[(size_t)r * P + pix] = nan;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward: front-to-back compositing, one 4x4 pixel block per DPP row (see the header comment).
 // ------------------------------------------------------------------------------------------------
@@ -128,7 +149,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     __shared__ float4 s_p2[kStage];   // r, g, b, depth
     __shared__ uint32_t s_mask[kStage / 32][16];   // [32-entry chunk][4x4 block]
 
-    if (counters[0] > capacity) return;
+    (void)capacity;
+    if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
     BlockCtx c;
     if (!block_ctx(c, RT, T, tiles_x, H, W)) return;
     const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
@@ -297,7 +319,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     __shared__ float4 s_p2[kStage];   // r, g, b, -
     __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
 
-    if (counters[0] > capacity) return;
+    (void)capacity;
+    if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return;
     const int r = vid / T, tile = vid - r * T;
@@ -423,7 +446,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
     const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off, float* __restrict__ gpair, int G, int H,
     int W, int T, int tiles_x, int RT, uint32_t dense_thr, const uint32_t* __restrict__ counters, uint64_t capacity) {
-    if (counters[0] > capacity) return;      // the forward did not render (pair buffer too small): nothing to replay
+    (void)capacity;
+    if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
     __shared__ float4 s_p0[kStage];
     __shared__ float2 s_p1[kStage];
     __shared__ float4 s_p2[kStage];
@@ -644,7 +668,8 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
     float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr_arg,
     const uint32_t* __restrict__ counters, uint64_t capacity) {
-    if (counters[0] > capacity) return;      // the forward did not render (pair buffer too small): nothing to replay
+    (void)capacity;
+    if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;
     __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
     __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
@@ -934,15 +959,20 @@ struct AuxStream {
     hipEvent_t fork = nullptr, join = nullptr;
 };
 static AuxStream* aux_stream() {
-    static AuxStream aux[32];
+    // one auxiliary stream + event pair per (device, calling thread): a thread's launches are ordered on ITS streams,
+    // so two host threads (or two devices) never share -- and never race on -- an event pair
+    static thread_local AuxStream aux[32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     AuxStream& a = aux[dev];
     if (!a.s) {
         if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { a.s = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(a.s);
+            a.s = nullptr;
             return nullptr;
+        }
     }
     return &a;
 }

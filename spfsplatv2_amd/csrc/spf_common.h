@@ -36,6 +36,11 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
                                        -0.4570457994644658f, 0.3731763325901154f,
                                        -0.4570457994644658f, 1.445305721320277f,
                                        -0.5900435899266435f};
+// Band 4 (evaluated only when SpfDims.sh_band4 is set): same real-SH family, index n(n+1)+m; pinned against the
+// reference's own table src/misc/sht.py::rsh_cart_4 through the oracle (tests/golden/sh_basis_goldens.pt).
+__device__ constexpr float SH_C4[9] = {2.5033429417967046f, -1.7701307697799304f, 0.9461746957575601f,
+                                       -0.6690465435572892f, 0.10578554691520431f, -0.6690465435572892f,
+                                       0.47308734787878004f, -1.7701307697799304f, 0.6258357354491761f};
 
 // ---- DPP wave-64 reductions (result valid in lane 63) --------------------------------------
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>

@@ -34,7 +34,7 @@ from typing import Generic, Literal, Optional, TypeVar
 import torch
 from torch import Tensor, nn
 
-from .rasterizer import rasterize_batch, render_batch
+from .rasterizer import CallRecord, rasterize_batch, render_batch
 
 DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
 
@@ -99,13 +99,16 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  background_color: Tensor, gaussian_means: Tensor, gaussian_sh_coefficients: Tensor,
                  gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
                  scale_invariant: bool = True, use_sh: bool = True, enable_cov_grad: bool = False,
-                 enable_sh_grad: bool = False, max_pairs=None):
+                 enable_sh_grad: bool = False, max_pairs=None, sh_band4: Optional[bool] = None,
+                 return_radii: bool = False, record=None):
     """Batched form of ``render_cuda``: b scenes x v views sharing each scene's Gaussians.
 
     extrinsics [b,v,4,4] (camera-to-world), intrinsics [b,v,3,3] (normalised), near/far [b,v],
     background_color [3] or [b,v,3], gaussian_* [b,g,...] with SH as [b,g,3,d_sh].
     Returns color [b,v,3,h,w], depth [b,v,1,h,w] (in the rasterizer's normalised units: the caller
-    multiplies by near, decoder_splatting_cuda.py:72-76) and alpha [b,v,1,h,w].
+    multiplies by near, decoder_splatting_cuda.py:72-76) and alpha [b,v,1,h,w] (+ radii [b,v,g] int32 with
+    ``return_radii``).  ``sh_band4``: with d_sh = 25 (sh_degree 4, the reference's default) also evaluate SH band 4;
+    None = the ``SPF_SH_BAND4`` environment variable, default off (see ``rasterizer.sh_band4_default``).
     """
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     h, w = image_shape
@@ -117,8 +120,8 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
         extrinsics, intrinsics, near, far, gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
         gaussian_sh_coefficients if use_sh else None, None if use_sh else gaussian_sh_coefficients[..., 0],
         background_color, h, w, degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs,
-        sh_layout="g3k")
-    return color, depth, alpha
+        sh_layout="g3k", sh_band4=sh_band4, record=record)
+    return (color, depth, alpha, _radii) if return_radii else (color, depth, alpha)
 
 
 def camera_tensors(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
@@ -162,13 +165,31 @@ def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, 
                              enable_cov_grad: bool = False, enable_sh_grad: bool = False) -> Tensor:
     """Fake orthographic render (tiny FOV, camera moved back); returns images [B,3,h,w]."""
     del gaussian_covariances
-    b = extrinsics.shape[0]
     h, w = image_shape
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     n = gaussian_sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     shs = gaussian_sh_coefficients.transpose(-1, -2).contiguous()
+    view, proj, tanfov = orthographic_camera(extrinsics, width, height, near, far, fov_degrees, dump)
+    color, _, _, _ = rasterize_batch(
+        gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
+        shs if use_sh else None, None if use_sh else shs[:, :, 0, :],
+        view[:, None], proj[:, None], tanfov, background_color[:, None],
+        h, w, degree, 1.0, enable_cov_grad, enable_sh_grad)
+    return color[:, 0]
 
+
+def orthographic_camera(extrinsics: Tensor, width: Tensor, height: Tensor, near: Tensor, far: Tensor,
+                        fov_degrees: float = 0.1, dump: dict | None = None):
+    """Camera tensors of ``render_cuda_orthographic`` (cuda_splatting.py:168-201): view / projection matrices [B,4,4]
+    (row-vector form) and tanfov [B,1,2] of the tiny-FOV camera moved back by ``distance_to_near``.
+
+    The reference inverts the moved-back pose, ``(extrinsics @ move_back).inverse()``: a float32 inverse of a matrix
+    whose translation is ~0.5*width/tan(fov/2) ~ 10^3 scene units, good to ~1e-7 of THAT -- pixel centres wobble by
+    ~1e-3 px from one inverse routine to the next.  The same matrix is ``move_back^-1 @ extrinsics^-1``, i.e. the
+    inverse of the ORIGINAL pose with ``distance_to_near`` added to its z translation -- identical in exact arithmetic
+    and free of the cancellation, so that is what is built here."""
+    b = extrinsics.shape[0]
     fov_x = torch.tensor(fov_degrees, device=extrinsics.device).deg2rad()
     tan_fov_x = (0.5 * fov_x).tan()
     distance_to_near = (0.5 * width) / tan_fov_x
@@ -176,24 +197,21 @@ def render_cuda_orthographic(extrinsics: Tensor, width: Tensor, height: Tensor, 
     fov_y = (2 * tan_fov_y).atan()
     near = near + distance_to_near
     far = far + distance_to_near
-    # (the reference writes a single 4x4 here, cuda_splatting.py:183-185, which only works for batch 1)
-    move_back = torch.eye(4, dtype=torch.float32, device=extrinsics.device).repeat(b, 1, 1)
-    move_back[:, 2, 3] = -distance_to_near
-    extrinsics = extrinsics @ move_back
     if dump is not None:
-        dump["extrinsics"] = extrinsics
+        # (the reference writes a single 4x4 here, cuda_splatting.py:183-185, which only works for batch 1)
+        move_back = torch.eye(4, dtype=torch.float32, device=extrinsics.device).repeat(b, 1, 1)
+        move_back[:, 2, 3] = -distance_to_near
+        dump["extrinsics"] = extrinsics @ move_back
         dump["fov_x"] = fov_x
         dump["fov_y"] = fov_y
         dump["near"] = near
         dump["far"] = far
-    view, proj = _camera_tensors(extrinsics, near, far, fov_x.expand(b), fov_y)
+    w2c = extrinsics.inverse().clone()
+    w2c[:, 2, 3] = w2c[:, 2, 3] + distance_to_near              # move_back^-1 @ w2c
+    view = w2c.transpose(-1, -2)
+    proj = get_projection_matrix(near, far, fov_x.expand(b), fov_y).transpose(-1, -2)
     tanfov = torch.stack((tan_fov_x.expand(b), tan_fov_y.expand(b)), dim=-1).reshape(b, 1, 2)
-    color, _, _, _ = rasterize_batch(
-        gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
-        shs if use_sh else None, None if use_sh else shs[:, :, 0, :],
-        view[:, None], proj[:, None], tanfov, background_color[:, None],
-        h, w, degree, 1.0, enable_cov_grad, enable_sh_grad)
-    return color[:, 0]
+    return view, proj, tanfov
 
 
 T = TypeVar("T")
@@ -238,19 +256,32 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # ``spfsplatv2_amd.plan_pair_budget(...)`` here after one exact call: no call waits for the device any more
         # (the plan is verified on the device, see rasterizer.PairBudget).
         self.max_pairs = None
+        # None: SH band 4 of a d_sh = 25 model follows the SPF_SH_BAND4 environment variable (default: not evaluated,
+        # as in the published 3DGS kernels); True / False pins it for this decoder.
+        self.sh_band4 = None
+        # statistics / plan counters of THIS decoder's most recent call (two live decoders do not interleave):
+        # `spfsplatv2_amd.plan_flags(decoder.last_call)`, `plan_pair_budget(decoder.last_call)`
+        self.last_call = CallRecord()
+
+    def render(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
+               image_shape: tuple[int, int]):
+        """``forward`` plus the two rasterizer outputs the reference's decoder drops (cuda_splatting.py:128,141-144):
+        returns (DecoderOutput, alpha [b,v,1,h,w], radii [b,v,g] int32)."""
+        color, depth, alpha, radii = render_views(
+            extrinsics, intrinsics, near, far, image_shape, self.background_color,
+            gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
+            scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
+            enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs, sh_band4=self.sh_band4, return_radii=True,
+            record=self.last_call)
+        depth = depth[:, :, 0]                                   # "(b v) 1 h w -> b v h w"
+        if self.make_scale_invariant:
+            depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76
+        return DecoderOutput(color, depth), alpha, radii
 
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], depth_mode: DepthRenderingMode | None = None) -> DecoderOutput:
         # depth_mode is accepted and ignored, as in the reference (decoder_splatting_cuda.py:49)
-        color, depth, _ = render_views(
-            extrinsics, intrinsics, near, far, image_shape, self.background_color,
-            gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
-            scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
-            enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs)
-        depth = depth[:, :, 0]
-        if self.make_scale_invariant:
-            depth = depth * near[:, :, None, None]
-        return DecoderOutput(color, depth)
+        return self.render(gaussians, extrinsics, intrinsics, near, far, image_shape)[0]
 
 
 DecoderSplattingHIP = DecoderSplattingCUDA

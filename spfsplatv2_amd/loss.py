@@ -28,15 +28,6 @@ from . import _lib
 
 T_cfg = TypeVar("T_cfg")
 T_wrapper = TypeVar("T_wrapper")
-_scratch: dict = {}      # per device: partial sums
-
-
-def _scratch_for(dev: torch.device):
-    key = (dev.type, dev.index)
-    if key not in _scratch:
-        n = _lib.load().spf_mse_partial_blocks()
-        _scratch[key] = torch.empty(n, dtype=torch.float32, device=dev)
-    return _scratch[key]
 
 
 def _check(prediction: Tensor, image: Tensor) -> None:
@@ -44,22 +35,28 @@ def _check(prediction: Tensor, image: Tensor) -> None:
         if not t.is_cuda:
             raise RuntimeError(f"mse_loss: {name} is on {t.device}; this build only runs on a HIP device (no CPU "
                                "fallback)")
-        if t.dtype != torch.float32:
-            raise RuntimeError(f"mse_loss: {name} must be float32, got {t.dtype}")
-    if prediction.shape != image.shape:
-        raise RuntimeError(f"mse_loss: shapes differ: {tuple(prediction.shape)} vs {tuple(image.shape)}")
-    if prediction.numel() == 0:
+        if not t.is_floating_point():
+            raise RuntimeError(f"mse_loss: {name} must be a floating-point tensor, got {t.dtype}")
+    if prediction.numel() == 0 or image.numel() == 0:
         raise RuntimeError("mse_loss: empty input")
+
+
+def _kernel_operand(t: Tensor) -> Tensor:
+    """What the kernel reads: float32, contiguous, 16-byte aligned (a slice of an odd-sized image is contiguous but
+    may start anywhere: copied once rather than refused)."""
+    t = t.to(torch.float32).contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
 
 
 class _Mse(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prediction: Tensor, image: Tensor, weight: float):
-        _check(prediction, image)
-        p, t = prediction.contiguous(), image.contiguous()
+        p, t = _kernel_operand(prediction), _kernel_operand(image)
         lib = _lib.load()
         dev = p.device
-        partial = _scratch_for(dev)
+        # per-call scratch for the block partials (a few KB from the caching allocator): two streams computing
+        # losses at the same time never share it
+        partial = torch.empty(lib.spf_mse_partial_blocks(), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -90,7 +87,17 @@ class _Mse(torch.autograd.Function):
 
 
 def mse_loss(prediction: Tensor, image: Tensor, weight: float = 1.0) -> Tensor:
-    """``weight * ((prediction - image) ** 2).mean()`` (loss_mse.py:48-51) as one fused pass; 0-dim float32 result."""
+    """``weight * ((prediction - image) ** 2).mean()`` (loss_mse.py:48-51) as one fused pass; 0-dim float32 result.
+    Like the reference's expression it accepts broadcastable shapes and any floating dtype (bf16 under autocast):
+    operands are expanded / cast to float32 on the host side of the kernel and the gradients are cast / reduced back
+    by autograd."""
+    _check(prediction, image)
+    if prediction.shape != image.shape:
+        prediction, image = torch.broadcast_tensors(prediction, image)
+    if prediction.dtype != torch.float32:
+        prediction = prediction.float()
+    if image.dtype != torch.float32:
+        image = image.float()
     return _Mse.apply(prediction, image, weight)
 
 

@@ -22,12 +22,30 @@ from torch import Tensor
 
 from . import _lib
 
+import os
+
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward",
-           "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags"]
+           "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags", "plan_flags", "CallRecord",
+           "sh_band4_default"]
 
 _REC = 12
-_stats: dict = {}
-_last_counters: list = [None]      # device counters of the most recent planned (max_pairs=...) forward call
+
+
+class CallRecord(dict):
+    """What one forward call left behind: ``num_pairs / max_tile_list / dense_tiles / tiles`` (exact mode) and, for a
+    planned call, ``counters`` -- the device tensor whose element 2 is the plan verdict.  Pass your own instance as
+    ``record=`` to keep the calls of several decoders / threads apart; without one the process-wide ``_last`` is used
+    (what ``last_forward_stats`` / ``last_plan_flags`` read)."""
+
+
+_last = CallRecord()
+
+
+def sh_band4_default() -> bool:
+    """Whether SH band 4 of a d_sh = 25 model is evaluated when the caller does not say: the ``SPF_SH_BAND4``
+    environment variable ("1" = yes).  Default off: the published 3DGS kernels stop at degree 3 and only carry the
+    25-coefficient stride; the `pose` fork's behaviour cannot be checked offline."""
+    return os.environ.get("SPF_SH_BAND4", "0") == "1"
 
 
 class PairBudget(NamedTuple):
@@ -54,7 +72,7 @@ def plan_pair_budget(stats: Optional[dict] = None, slack: float = 1.25, check: s
     """Budget for the next calls from the statistics of an exact-mode call (default: the most recent one, see
     ``last_forward_stats``): ``slack`` x the pairs it produced, the list-length class its longest list (x slack) falls
     in, and its sparse/dense tile census when that was one-sided."""
-    st = dict(_stats if stats is None else stats)
+    st = dict(_last if stats is None else stats)
     if "num_pairs" not in st:
         raise RuntimeError("plan_pair_budget needs the statistics of an exact-mode forward call (max_pairs=None)")
     want = int(st["max_tile_list"] * slack) + 1
@@ -63,18 +81,23 @@ def plan_pair_budget(stats: Optional[dict] = None, slack: float = 1.25, check: s
     return PairBudget(int(st["num_pairs"] * slack) + 1024, max_tile, dense, check)
 
 
-def last_plan_flags() -> int:
-    """Device-side verdict on the plan of the most recent planned forward call (synchronises with the device):
-    0 = the plan held; bit 1 = pair buffer too small, bit 2 = a tile list longer than planned, bit 4 = dense/sparse
-    assumption wrong.  Non-zero: that call's outputs (and its backward's gradients) are invalid -- re-run it in
-    exact mode or with a larger budget."""
-    c = _last_counters[0]
+def plan_flags(record: Optional[CallRecord] = None) -> int:
+    """Device-side verdict on the plan of a planned forward call (synchronises with the device): 0 = the plan held;
+    bit 1 = pair buffer too small, bit 2 = a tile list longer than planned, bit 4 = dense/sparse assumption wrong.
+    Non-zero: that call's outputs and its backward's gradients are all NaN (never garbage) -- re-run it in exact mode
+    or with a larger budget.  `record`: the CallRecord the call was given (default: the process-wide last call)."""
+    c = (_last if record is None else record).get("counters")
     return 0 if c is None else int(c[2])
 
 
+def last_plan_flags() -> int:
+    """``plan_flags()`` of the most recent planned forward call in this process."""
+    return plan_flags(None)
+
+
 def last_forward_stats() -> dict:
-    """{'num_pairs': D, 'max_tile_list': n} of the most recent forward call in this process."""
-    return dict(_stats)
+    """{'num_pairs': D, 'max_tile_list': n, ...} of the most recent exact-mode forward call in this process."""
+    return {k: v for k, v in _last.items() if k != "counters"}
 
 
 def _ptr(t: Optional[Tensor]):
@@ -132,7 +155,8 @@ def _on_device_of_first_arg(fn):
 
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
-                  view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None):
+                  view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None, sh_band4=False,
+                  record=None, nothing_needs_grad=False):
     """Launch the forward chain.  Returns (outputs, saved state tensors).  `camera` (an SpfCamera whose outputs are
     viewmatrix / projmatrix / tanfov / view_scale): the decoder fast path -- camera set-up and the clearing of the tile
     counters are one kernel."""
@@ -142,9 +166,10 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     R = S * V
     dev = means3D.device
     K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout))
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)))
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
+    rec_out = _last if record is None else record
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -181,20 +206,28 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         host = counters.cpu()
         D, max_tile, dense = int(host[0]), int(host[1]), int(host[3])
         capacity = D
-        _stats.update(num_pairs=D, max_tile_list=max_tile, dense_tiles=dense, tiles=R * T)
+        rec_out.update(num_pairs=D, max_tile_list=max_tile, dense_tiles=dense, tiles=R * T, counters=None)
+        if rec_out is not _last:
+            _last.update(rec_out)
     else:
         plan = max_pairs if isinstance(max_pairs, PairBudget) else PairBudget(int(max_pairs))
         capacity, max_tile = int(plan.capacity), int(plan.max_tile_list)
         dense = 0xFFFFFFFF if plan.dense_tiles is None else (R * T if plan.dense_tiles < 0 else int(plan.dense_tiles))
         if 0 < dense < R * T:
             dense = 0xFFFFFFFF      # only "none" and "all" are assumptions the device can check
-        _last_counters[0] = counters
+        rec_out["counters"] = counters
+        _last["counters"] = counters
     pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
     st.pairs = _ptr(pairs)
     out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
                                              capacity, max_tile, dense, stream),
                "spf_raster_forward_render")
+    if max_pairs is not None and _plan_mode(max_pairs) == 1 and (nothing_needs_grad or not torch.is_grad_enabled()) \
+            and not torch.cuda.is_current_stream_capturing():
+        # check="backward" promises that a failed plan raises -- but no backward will come (evaluation under
+        # no_grad, or nothing requires grad): verify now (one host sync; eval loops should use exact mode anyway)
+        _raise_if_plan_failed(counters, pairs.numel())
     return ((image, depth, alpha, radii.view(S, V, G)),
             (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
 
@@ -206,6 +239,17 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(tiles[4 * RT + 1:]), _ptr(pairs),
                          _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib))
+
+
+def _raise_if_plan_failed(counters: Tensor, capacity: int) -> None:
+    host = counters.cpu()
+    flag = int(host[2])
+    if flag & 1:
+        raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
+                            f"({capacity} < {int(host[0])}); the outputs are NaN")
+    if flag:
+        raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = a tile list longer "
+                            f"than planned ({int(host[1])}), 4 = dense-tile assumption wrong); the outputs are NaN")
 
 
 def _plan_mode(max_pairs) -> int:
@@ -221,22 +265,15 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
-    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense, sh_layout = geom
+    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense, sh_layout, sh_band4 = geom
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
     # (a device->host read is illegal while a HIP graph is being captured: graph users check the flag themselves
     # with `pair_buffer_overflowed` after a replay)
     if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
-        flag = int(tiles[4 * R * T + 1 + 2])
-        if flag & 1:
-            raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
-                                f"({pairs.numel()} < {int(tiles[4 * R * T + 1])}); outputs were not rendered")
-        if flag:
-            raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = a tile list longer "
-                                f"than planned ({int(tiles[4 * R * T + 2])}), 4 = dense-tile assumption wrong); "
-                                "outputs are invalid")
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout))
+        _raise_if_plan_failed(tiles[4 * R * T + 1:], pairs.numel())
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout), int(sh_band4))
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
@@ -268,14 +305,16 @@ def _backward_impl(inputs, state, geom, grads_out, want):
 class _RasterizeBatch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
-                view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs):
+                view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs,
+                sh_band4, record):
         ctx.set_materialize_grads(False)
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix,
                                            projmatrix, tanfov, bg, view_scale, H, W, sh_degree, scale_modifier,
-                                           max_pairs)
+                                           max_pairs, sh_band4=sh_band4, record=record,
+                                           nothing_needs_grad=not any(ctx.needs_input_grad))
         S, G, _ = means3D.shape
         ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
-                    float(scale_modifier), _plan_mode(max_pairs), dense, 0)
+                    float(scale_modifier), _plan_mode(max_pairs), dense, 0, bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
@@ -295,7 +334,7 @@ class _RasterizeBatch(torch.autograd.Function):
         if d_m2d is not None:
             d_m2d = d_m2d.view(ctx.means2D_shape)
         return (d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, None, None, None, None,
-                None, None, None, None, None, None, d_m2d, None)
+                None, None, None, None, None, None, d_m2d, None, None, None)
 
 
 class _DecoderRender(torch.autograd.Function):
@@ -304,7 +343,8 @@ class _DecoderRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
-                H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout):
+                H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout, sh_band4,
+                record):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         S, V = extrinsics.shape[:2]
@@ -317,10 +357,12 @@ class _DecoderRender(torch.autograd.Function):
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
-                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam)
+                                           bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam,
+                                           sh_band4=sh_band4, record=record,
+                                           nothing_needs_grad=not any(ctx.needs_input_grad))
         G = means3D.shape[1]
         K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
-        ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout))
+        ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout), bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
                               *state, near)
@@ -348,7 +390,7 @@ class _DecoderRender(torch.autograd.Function):
                                                             _ptr(d_ext), _stream_ptr(view.device)),
                            "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
@@ -375,13 +417,15 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  shs: Optional[Tensor], colors_precomp: Optional[Tensor], bg: Tensor,
                  image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
                  enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs=None,
-                 sh_layout: str = "gk3"):
+                 sh_layout: str = "gk3", sh_band4: Optional[bool] = None, record: Optional[CallRecord] = None):
     """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
 
     extrinsics [S,V,4,4] camera-to-world, intrinsics [S,V,3,3] normalised, near/far [S,V]; Gaussians as in
     ``rasterize_batch``; ``sh_layout="g3k"`` takes ``shs`` as [S,G,3,K] -- the encoder's native layout
-    (``Gaussians.harmonics``), so the transposed copy at cuda_splatting.py:79 never happens.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units), alpha [S,V,1,H,W],
-    radii [S,V,G]."""
+    (``Gaussians.harmonics``), so the transposed copy at cuda_splatting.py:79 never happens.  ``sh_band4``: evaluate
+    band 4 when ``sh_degree`` is 4 (None = ``sh_band4_default()``).  ``record``: a ``CallRecord`` that receives this
+    call's statistics / plan counters.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units),
+    alpha [S,V,1,H,W], radii [S,V,G]."""
     if (shs is None) == (colors_precomp is None):
         raise RuntimeError("provide exactly one of shs / colors_precomp")
     S, G, _ = means3D.shape
@@ -397,17 +441,22 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     if sh_layout not in ("gk3", "g3k"):
         raise RuntimeError(f"sh_layout must be 'gk3' or 'g3k', got {sh_layout!r}")
     native = sh_layout == "g3k"
+    if sh_band4 is None:
+        sh_band4 = sh_band4_default()
     if shs is not None:
         K = shs.shape[3 if native else 2]
-        if K < (min(sh_degree, 3) + 1) ** 2:
+        if K < (min(sh_degree, 4 if sh_band4 else 3) + 1) ** 2:
             raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
         shs = _f32c(shs, "shs", (S, G, 3, K) if native else (S, G, K, 3))
     else:
         colors_precomp = _f32c(colors_precomp, "colors_precomp", (S, G, 3))
+    if not (0 <= sh_degree <= 4):
+        raise RuntimeError(f"sh_degree {sh_degree} outside 0..4")
     bg = _background(bg, S, V)
     return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
-                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0)
+                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0,
+                                bool(sh_band4), record)
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
@@ -416,7 +465,8 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
                     image_height: int, image_width: int, sh_degree: int, scale_modifier: float = 1.0,
                     enable_cov_grad: bool = True, enable_sh_grad: bool = True,
                     means2D: Optional[Tensor] = None, max_pairs=None,
-                    view_scale: Optional[Tensor] = None):
+                    view_scale: Optional[Tensor] = None, sh_band4: Optional[bool] = None,
+                    record: Optional[CallRecord] = None):
     """Render S scenes x V views.
 
     means3D [S,G,3], scales [S,G,3], rotations [S,G,4] (r,x,y,z; used as given), opacities [S,G] or
@@ -442,6 +492,8 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     if means3D.dim() != 3 or means3D.shape[-1] != 3:
         raise RuntimeError(f"means3D must be [S,G,3], got {tuple(means3D.shape)}")
     S, G, _ = means3D.shape
+    if sh_band4 is None:
+        sh_band4 = sh_band4_default()
     if viewmatrix.dim() != 4:
         raise RuntimeError(f"viewmatrix must be [S,V,4,4], got {tuple(viewmatrix.shape)}")
     V = viewmatrix.shape[1]
@@ -453,7 +505,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
         if shs.dim() != 4 or shs.shape[-1] != 3:
             raise RuntimeError(f"shs must be [S,G,K,3], got {tuple(shs.shape)}")
         K = shs.shape[2]
-        if K < (min(sh_degree, 3) + 1) ** 2:
+        if K < (min(sh_degree, 4 if sh_band4 else 3) + 1) ** 2:
             raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
         shs = _f32c(shs, "shs", (S, G, K, 3))
     else:
@@ -471,7 +523,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     return _RasterizeBatch.apply(means3D, scales, rotations, opacities, shs, colors_precomp, viewmatrix,
                                  projmatrix, tanfov, bg, view_scale, int(image_height), int(image_width),
                                  int(sh_degree), float(scale_modifier), enable_cov_grad, enable_sh_grad, means2D,
-                                 max_pairs)
+                                 max_pairs, bool(sh_band4), record)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -491,6 +543,7 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool = False
     enable_cov_grad: bool = True
     enable_sh_grad: bool = True
+    sh_band4: Optional[bool] = None    # (not a field of the reference's tuple) None = sh_band4_default()
 
 
 class GaussianRasterizer(torch.nn.Module):
@@ -524,5 +577,5 @@ class GaussianRasterizer(torch.nn.Module):
             None if shs is None else shs[None], None if colors_precomp is None else colors_precomp[None],
             viewmatrix[None, None], s.projmatrix[None, None], tanfov, s.bg.reshape(1, 1, 3),
             s.image_height, s.image_width, s.sh_degree, s.scale_modifier,
-            s.enable_cov_grad, s.enable_sh_grad, means2D=means2D)
+            s.enable_cov_grad, s.enable_sh_grad, means2D=means2D, sh_band4=s.sh_band4)
         return image[0, 0], depth[0, 0], None, alpha[0, 0], radii[0, 0], None

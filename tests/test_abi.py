@@ -23,7 +23,7 @@ def test_header_symbols_all_exported(hip_lib):
 
 def test_struct_sizes_match_header():
     from spfsplatv2_amd import _lib
-    assert C.sizeof(_lib.SpfDims) == 36
+    assert C.sizeof(_lib.SpfDims) == 40
     assert C.sizeof(_lib.SpfInputs) == 11 * 8
     assert C.sizeof(_lib.SpfState) == 15 * 8
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
@@ -41,13 +41,13 @@ def test_host_helpers_no_gpu(hip_lib):
 def test_argument_validation_without_compute(hip_lib):
     """Bad arguments are rejected before anything touches a device."""
     from spfsplatv2_amd import _lib
-    d = _lib.SpfDims(1, 1, 0, 1, 0, 64, 64, 1.0, 0)         # G = 0
+    d = _lib.SpfDims(1, 1, 0, 1, 0, 64, 64, 1.0, 0, 0)         # G = 0
     rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
     assert rc == -1 and b"positive" in hip_lib.spf_last_error()
-    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 64, 1.0, 0)
+    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 64, 1.0, 0, 0)
     rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
     assert rc == -1 and b"null" in hip_lib.spf_last_error()
-    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 5000, 1.0, 0)
+    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 5000, 1.0, 0, 0)
     rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
     assert rc == -1 and b"4080" in hip_lib.spf_last_error()
     rc = hip_lib.spf_rope2d(None, None, 1, 1, 1, 64, 64, 64, 64, 1, 0, 100.0, 1.0, None)

@@ -175,3 +175,33 @@ def test_product_decoder_registry_and_types():
     assert isinstance(d, dec.DecoderSplattingCUDA) and isinstance(d, dec.Decoder)
     assert list(dec.DECODERS) == ["splatting_cuda"] and len(list(d.parameters())) == 0
     assert "background_color" not in d.state_dict()          # non-persistent buffer, like the reference
+
+
+@pytest.mark.parametrize("tag", ["decoder_k4_si", "decoder_k25_nosi"])
+def test_decoder_module_postprocessing_matches_reference(golden_dir, monkeypatch, tag):
+    """A2: `DecoderSplattingCUDA.forward` itself -- shapes and its `depth x near` post-processing
+    (decoder_splatting_cuda.py:66-78) -- against what the reference's own module returned around a stand-in
+    rasterizer whose depth is `2 + call number` (tests/golden/make_callsite_goldens.py)."""
+    from spfsplatv2_amd import decoder as dec
+    g = torch.load(golden_dir / f"callsite_{tag}.pt")
+    i = g["inputs"]
+    seen = {}
+
+    def fake_render_batch(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
+                          H, W, sh_degree, scale_invariant, *a, **kw):
+        S, V = extrinsics.shape[:2]
+        seen.update(scale_invariant=scale_invariant, sh_degree=sh_degree, shs=shs)
+        call = torch.arange(1, S * V + 1, dtype=torch.float32).reshape(S, V, 1, 1, 1)   # the reference's call order
+        return (torch.zeros(S, V, 3, H, W), (2.0 + call).expand(S, V, 1, H, W).clone(), torch.zeros(S, V, 1, H, W),
+                torch.zeros(S, V, means3D.shape[1], dtype=torch.int32))
+
+    monkeypatch.setattr(dec, "render_batch", fake_render_batch)
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=i["background_color"],
+                                                    make_scale_invariant=i["make_scale_invariant"],
+                                                    enable_cov_grad=True, enable_sh_grad=True))
+    gs = dec.Gaussians(i["means"], i["covariances"], i["rotations"], i["scales"], i["harmonics"], i["opacities"])
+    out = d.forward(gs, i["extrinsics"], i["intrinsics"], i["near"], i["far"], i["image_shape"], depth_mode="depth")
+    assert isinstance(out, dec.DecoderOutput) and tuple(out.color.shape) == g["decoder_color_shape"]
+    assert out.depth.shape == g["decoder_depth"].shape and torch.equal(out.depth, g["decoder_depth"])
+    assert seen["scale_invariant"] == i["make_scale_invariant"]
+    assert seen["sh_degree"] == g["calls"][0]["settings"]["sh_degree"]

@@ -13,7 +13,7 @@ def test_adapter_matches_reference(hip_lib, golden_dir, deg):
     ad = adapter.UnifiedGaussianAdapter(adapter.GaussianAdapterCfg(0.5, 15.0, deg)).cuda()
     assert torch.allclose(ad.sh_mask.cpu(), g["sh_mask"])
     raw = g["raw"].cuda().requires_grad_(True)
-    out = ad(g["means"].cuda(), g["opacities"].cuda(), raw, with_covariances=True)
+    out = ad(g["means"].cuda(), g["opacities"].cuda(), raw)          # covariances by default, like the reference
     for name in ("scales", "rotations", "harmonics", "covariances"):
         got, want = getattr(out, name).detach().cpu(), g[name]
         assert got.shape == want.shape, name
@@ -22,8 +22,9 @@ def test_adapter_matches_reference(hip_lib, golden_dir, deg):
     ((out.scales * w[0]).sum() + (out.rotations * w[1]).sum() + (out.harmonics * w[2]).sum()).backward()
     err = float((raw.grad.cpu() - g["raw_grad"]).abs().max())
     assert err <= 1e-5 * max(1.0, float(g["raw_grad"].abs().max())), err
-    lean = ad(g["means"].cuda(), g["opacities"].cuda(), g["raw"].cuda())
+    lean = ad(g["means"].cuda(), g["opacities"].cuda(), g["raw"].cuda(), with_covariances=False)
     assert lean.covariances.shape == g["covariances"].shape and lean.covariances.stride()[-1] == 0   # not materialised
+    assert bool(torch.isnan(lean.covariances).all())                                                  # and loud if used
 
 
 def test_adapter_feeds_decoder(hip_lib):
@@ -33,7 +34,7 @@ def test_adapter_feeds_decoder(hip_lib):
     b = syn.make_batch("TEST", 2, 2, seed=51, G=500, K=4, image_hw=(48, 48)).to("cuda")
     ad = adapter.UnifiedGaussianAdapter(adapter.GaussianAdapterCfg(0.5, 15.0, 1)).cuda()
     raw = torch.randn(2, 500, ad.d_in, device="cuda", generator=torch.Generator("cuda").manual_seed(1)).requires_grad_(True)
-    g = ad(b.means, b.opacities, raw)
+    g = ad(b.means, b.opacities, raw, with_covariances=False)
     dec = spf.get_decoder(spf.DecoderSplattingCUDACfg("splatting_cuda", [0.0, 0.0, 0.0], True, True, True)).cuda()
     out = dec(spf.Gaussians(g.means, g.covariances, g.rotations, g.scales * 5.0, g.harmonics, g.opacities),
               b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)

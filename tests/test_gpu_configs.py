@@ -1,0 +1,206 @@
+"""Every BASELINE.json config under `-m gpu` (C3, C4 and C5 had no GPU test).
+
+* oracle parity at FULL size, one (scene, view) each -- C3: 320,000 Gaussians at 256x256 (five context grids: lists of
+  ~1,400 entries per tile, the (1024, 2048] register-sort class and the LDS classes), C5: 500,000 Gaussians, 16 SH
+  coefficients, 512x512 (1,024 tiles) -- same gates as everywhere (RGB 1e-4, gradients 1e-3, radii bit-exact);
+* size-independent properties on the full BATCHES the bench runs: C3 2 scenes x 4 views, C5 1 x 8, and BASELINE
+  config 4's per-GPU share (8 scenes x 4 views of C2): bit-stable forward, background linearity, every scene of the
+  batch bit-equal to rendering it alone (renders are independent: the multi-GPU sharding argument), a gradient checksum
+  over all (Gaussian, tile) pairs, planned mode == exact mode;
+* the reference's test-time pose alignment (model_wrapper.py:549-588): Gaussians frozen, ONLY the poses require grad,
+  three Adam steps at lr 0.005 on the product and on the oracle;
+* d_sh = 25 (the reference's default sh_degree 4): stride-only by default, band 4 evaluated on request;
+* a failed plan is loud and deterministic: NaN everywhere, never uninitialised memory.
+"""
+import pytest
+import torch
+
+from spfsplatv2_amd import synthetic as syn
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SH_C0 = 0.28209479177387814
+
+
+# ---- oracle parity at full size --------------------------------------------------------------------------------
+@pytest.mark.parametrize("config,min_pairs,min_list", [("C3", 300000, 1025), ("C5", 500000, 513)])
+def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
+    batch = syn.make_batch(config, 1, 1, seed=5)
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
+    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    # lists of >1000 entries per pixel: proportionally more pixels sit next to an alpha / transmittance threshold
+    rep = util.compare(prod, ref, max_fragile_frac=0.06)
+    rep.update(num_pairs=prod["stats"]["num_pairs"], max_tile_list=prod["stats"]["max_tile_list"])
+    assert not rep["fails"], rep
+    assert prod["stats"]["num_pairs"] >= min_pairs and prod["stats"]["max_tile_list"] >= min_list, prod["stats"]
+
+
+# ---- properties on the bench's batches -------------------------------------------------------------------------
+def _render(b, harm=None, bg=(0.0, 0.0, 0.0), max_pairs=None, scenes=None, leaves=False):
+    import spfsplatv2_amd as spf
+    pick = (lambda t: t) if scenes is None else (lambda t: t[scenes])
+    harm = b.harmonics if harm is None else harm
+    args = [pick(b.extrinsics), pick(b.intrinsics), pick(b.near), pick(b.far), b.image_shape,
+            torch.tensor(bg, device="cuda"), pick(b.means), pick(harm), pick(b.opacities), pick(b.rotations),
+            pick(b.scales)]
+    return spf.render_views(*args, enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
+
+
+@pytest.mark.parametrize("config,S,V,min_pairs_per_render,min_list",
+                         [("C2", 8, 4, 60000, 257), ("C3", 2, 4, 300000, 1025), ("C5", 1, 8, 500000, 513)],
+                         ids=["C4_share_8x4", "C3_2x4", "C5_1x8"])
+def test_full_batch_properties(hip_lib, config, S, V, min_pairs_per_render, min_list):
+    import spfsplatv2_amd as spf
+    b = syn.make_batch(config, S, V, seed=1000).to("cuda")
+    K = b.harmonics.shape[-1]
+    b.harmonics[..., 0] = b.harmonics[..., 0].abs() + 1.0       # colours stay > 0: no clamp, the image is linear in DC
+    img, dep, alp = _render(b)
+    st = spf.last_forward_stats()
+    assert st["num_pairs"] >= min_pairs_per_render * S * V and st["max_tile_list"] >= min_list, st
+    assert bool(torch.isfinite(img).all()) and bool(torch.isfinite(dep).all())
+    assert float(alp.min()) >= 0.0 and float(alp.max()) <= 1.0 and float(alp.mean()) > 0.3
+    img2, dep2, _ = _render(b)
+    assert torch.equal(img, img2) and torch.equal(dep, dep2)                                  # bit-stable forward
+    bgc = (0.3, 0.6, 0.9)
+    img_bg, _, _ = _render(b, bg=bgc)                                                         # out = C + T_final * bg
+    assert float((img_bg - img - (1 - alp) * torch.tensor(bgc, device="cuda")[None, None, :, None, None])
+                 .abs().max()) < 2e-6
+    # a scene rendered inside the batch == the scene rendered alone: renders are independent, which is the whole
+    # multi-GPU story (scene-first sharding needs no data-path collective)
+    for s in sorted({0, S - 1}):
+        solo, solo_d, _ = _render(b, scenes=[s])
+        assert torch.equal(solo[0], img[s]) and torch.equal(solo_d[0], dep[s]), s
+    # planned mode (no host read-back) gives the same pixels as exact mode
+    plan = spf.plan_pair_budget(st, check="deferred")
+    img_p, dep_p, _ = _render(b, max_pairs=plan)
+    assert spf.last_plan_flags() == 0 and torch.equal(img_p, img) and torch.equal(dep_p, dep)
+    # gradient checksum: loss = sum(image), bg = 0  =>  d loss / d DC coefficient of (g, c) = SH_C0 * sum_pixels w_g,
+    # so sum_g of it / SH_C0 = sum_pixels (1 - T_final) = sum(alpha), per scene and channel -- a checksum over every
+    # (Gaussian, tile) pair of binning, sort order, compositing, pair records and the per-Gaussian reduction
+    harm = b.harmonics.clone().requires_grad_(True)
+    opac_leaf = b.opacities.clone().requires_grad_(True)
+    b2 = syn.Batch(**{**b.__dict__, "opacities": opac_leaf})
+    i2, _, a2 = _render(b2, harm=harm)
+    i2.sum().backward()
+    got = harm.grad[..., 0].sum(dim=1) / SH_C0                                                # [S,3]
+    want = a2.detach().sum(dim=(1, 2, 3, 4))                                                  # [S]
+    assert float(((got - want[:, None]).abs() / want[:, None]).max()) < 2e-4
+    if K > 1:
+        assert float(harm.grad[..., 1:].abs().max()) > 0
+    assert bool(torch.isfinite(opac_leaf.grad).all()) and float(opac_leaf.grad.abs().max()) > 0
+
+
+# ---- pose-only backward (test_step_align) ----------------------------------------------------------------------
+def test_pose_alignment_only_extrinsics_require_grad(hip_lib):
+    """model_wrapper.py:549-588: `extrinsics = nn.Parameter(...)`, Adam(lr = test.opt_lr = 0.005), every step =
+    decoder.forward + MSE + backward; the Gaussians are frozen encoder outputs, so gradient flows ONLY into the poses
+    (rasterizer.py: want["view"] = "partials", everything else off)."""
+    from oracle import glue_ref
+    from spfsplatv2_amd import decoder as dec, loss as spf_loss
+    batch = syn.make_batch("TEST", 1, 2, seed=41, s_mult=6.0, G=1500, K=4, image_hw=(64, 64))
+    steps, lr = 3, 0.005
+
+    def align_oracle():
+        ext = torch.nn.Parameter(batch.extrinsics.clone().double())
+        opt = torch.optim.Adam([{"params": [ext], "lr": lr}])
+        losses, grads = [], []
+        d = lambda t: t.double()
+        for _ in range(steps):
+            opt.zero_grad()
+            color = glue_ref.decoder_forward(d(batch.means), d(batch.harmonics), d(batch.opacities),
+                                             d(batch.rotations), d(batch.scales), ext, d(batch.intrinsics),
+                                             d(batch.near), d(batch.far), batch.image_shape, (0.0, 0.0, 0.0),
+                                             dtype=torch.float64)[0]
+            loss = ((color - d(batch.target)) ** 2).mean()
+            loss.backward()
+            losses.append(float(loss.detach()))
+            grads.append(ext.grad.clone())
+            opt.step()
+        return ext.detach(), losses, grads
+
+    def align_product():
+        b = batch.to("cuda")
+        decoder = util.product_decoder()
+        g = dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
+        assert not any(t.requires_grad for t in (g.means, g.rotations, g.scales, g.harmonics, g.opacities))
+        mse = spf_loss.LossMse(spf_loss.LossMseCfgWrapper(spf_loss.LossMseCfg(weight=1.0, apply_after_step=0)))
+        ext = torch.nn.Parameter(b.extrinsics.clone())
+        opt = torch.optim.Adam([{"params": [ext], "lr": lr}])
+        losses, grads = [], []
+        for _ in range(steps):
+            opt.zero_grad()
+            out = decoder.forward(g, ext, b.intrinsics, b.near, b.far, b.image_shape)
+            loss = mse.forward(out.color, b.target, g, 0)
+            loss.backward()
+            losses.append(float(loss.detach()))
+            grads.append(ext.grad.clone().cpu())
+            opt.step()
+        return ext.detach().cpu(), losses, grads
+
+    e_ref, l_ref, g_ref = align_oracle()
+    e_got, l_got, g_got = align_product()
+    assert util.rel_linf(g_got[0], g_ref[0]) < 1e-3, "first-step pose gradient"
+    for a, r in zip(l_got, l_ref):
+        assert abs(a - r) / r < 1e-5, (l_got, l_ref)
+    assert l_got[-1] < l_got[0]                                         # it actually aligns
+    assert float((e_got.double() - e_ref).abs().max()) < 5e-5           # 1 % of one Adam step
+    assert float((e_got - batch.extrinsics).abs().max()) > 0.5 * lr * steps
+
+
+# ---- d_sh = 25 -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("band4", [False, True], ids=["k25_stride_only", "k25_deg4"])
+def test_parity_k25_with_and_without_band4(hip_lib, band4):
+    batch = syn.make_batch("TEST", 2, 2, seed=6, s_mult=10.0, G=1200, K=25, image_hw=(64, 48))
+    batch.harmonics[..., 1:] *= 4.0                      # make the view-dependent part (and band 4) clearly visible
+    ref = util.run_oracle(batch, torch.float64, background=(0.2, 0.1, 0.3), mask_fragile=True, band4=band4)
+    prod = util.run_product(batch, background=(0.2, 0.1, 0.3), pixel_mask=ref["pixel_mask"], band4=band4)
+    rep = util.compare(prod, ref)
+    assert not rep["fails"], rep
+    hg = prod["grads"]["harmonics"]
+    assert (float(hg[..., 16:].abs().max()) > 0) == band4           # band-4 coefficients get gradient only on request
+    other = util.run_oracle(batch, torch.float64, background=(0.2, 0.1, 0.3), with_grads=False, want_fragile=False,
+                            band4=not band4)
+    assert float((other["color"] - ref["color"]).abs().max()) > 1e-3   # the two conventions really differ here
+
+
+def test_band4_switches(hip_lib, monkeypatch):
+    """Default: SPF_SH_BAND4 unset -> degree 3; the environment variable, the decoder attribute and the settings field
+    all turn it on."""
+    import spfsplatv2_amd as spf
+    b = syn.make_batch("TEST", 1, 1, seed=6, s_mult=10.0, G=600, K=25, image_hw=(48, 48)).to("cuda")
+    b.harmonics[..., 1:] *= 4.0
+    args = (b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape, torch.zeros(3, device="cuda"), b.means,
+            b.harmonics, b.opacities, b.rotations, b.scales)
+    monkeypatch.delenv("SPF_SH_BAND4", raising=False)
+    base = spf.render_views(*args)[0]
+    on = spf.render_views(*args, sh_band4=True)[0]
+    assert float((on - base).abs().max()) > 1e-3
+    assert torch.equal(spf.render_views(*args, sh_band4=False)[0], base)
+    monkeypatch.setenv("SPF_SH_BAND4", "1")
+    assert torch.equal(spf.render_views(*args)[0], on)
+
+
+# ---- failed plans ----------------------------------------------------------------------------------------------
+def test_failed_plan_is_nan_everywhere_and_raises_without_backward(hip_lib):
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd._lib import SpfError
+    batch = syn.make_batch("TEST", 2, 3, seed=3, s_mult=8.0, G=1500, K=4, image_hw=(80, 112))
+    exact = util.run_product(batch)
+    st = exact["stats"]
+    good = spf.plan_pair_budget(st, check="deferred")
+    bad_plans = {1: good._replace(capacity=st["num_pairs"] // 2),
+                 2: good._replace(max_tile_list=max(st["max_tile_list"] // 2, 1)),
+                 4: good._replace(dense_tiles=-1 if st["dense_tiles"] < st["tiles"] else 0)}
+    for bit, plan in bad_plans.items():
+        res = util.run_product(batch, max_pairs=plan)
+        assert spf.plan_flags(res["decoder"].last_call) & bit
+        for k in ("color", "depth", "alpha"):
+            assert bool(torch.isnan(res[k]).all()), (bit, k)           # never uninitialised memory
+        for n, g in res["grads"].items():
+            assert bool(torch.isnan(g).all()), (bit, n)
+        # check="backward" with no backward to come (evaluation): the forward itself verifies and raises
+        with pytest.raises(SpfError):
+            with torch.no_grad():
+                util.run_product(batch, max_pairs=plan._replace(check="backward"), with_grads=False)
+    ok = util.run_product(batch, max_pairs=good)
+    assert spf.plan_flags(ok["decoder"].last_call) == 0 and torch.equal(ok["color"], exact["color"])

@@ -69,8 +69,9 @@ def test_parity_vs_oracle(hip_lib, name):
     rep["num_pairs"] = prod["stats"].get("num_pairs")
     _report(name, rep)
     assert not rep["fails"], rep
-    # radii are integers: exact except on a rounding knife-edge
-    # (checked loosely: at most 0.1 % may differ by one pixel)
+    # (util.compare also gates: radii bit-exact off the Gaussian's own rounding knife-edges, and the number of pixels
+    # of the UNMASKED image that are off by > 1e-4 is bounded by the number of flagged pixels)
+    assert rep["radii_mismatch"] == 0 and rep["bad_frac_all"] <= rep["fragile_frac"]
 
 
 def test_radii_and_determinism(hip_lib):

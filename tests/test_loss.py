@@ -73,3 +73,42 @@ def test_hip_loss_is_deterministic_and_takes_views(hip_lib):
     assert av.grad.shape == a.shape
     want = 0.25 * 2.0 / a.numel() * (a - b)
     assert float((av.grad - want).abs().max()) < 1e-12 + 1e-6 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_hip_loss_accepts_what_the_reference_expression_accepts(hip_lib):
+    """bf16 inputs (autocast), broadcastable shapes and contiguous-but-unaligned slices are cast / expanded /
+    copied on the host side instead of being refused; two calls never share scratch."""
+    from spfsplatv2_amd import loss as L
+    gen = torch.Generator().manual_seed(9)
+    a = torch.rand(2, 3, 3, 17, 19, generator=gen).cuda()
+    b = torch.rand(2, 3, 3, 17, 19, generator=gen).cuda()
+    want = ((a - b) ** 2).mean()
+    # odd-sized image, leading-dim slice starting at an address that is not a multiple of 16 bytes
+    big_a, big_b = torch.rand(3, 3, 3, 17, 19, generator=gen).cuda(), torch.rand(3, 3, 3, 17, 19, generator=gen).cuda()
+    sa, sb = big_a[1:], big_b[1:]
+    assert sa.is_contiguous() and sa.data_ptr() % 16 != 0
+    assert _rel(L.mse_loss(sa, sb), ((sa - sb) ** 2).mean()) < 2e-6
+    # bf16 prediction: evaluated in float32, gradient comes back in bf16
+    ah = a.bfloat16().requires_grad_(True)
+    lh = L.mse_loss(ah, b)
+    assert lh.dtype == torch.float32 and _rel(lh, ((ah.float() - b) ** 2).mean()) < 2e-6
+    lh.backward()
+    assert ah.grad.dtype == torch.bfloat16 and ah.grad.shape == a.shape
+    # broadcast: one target image for every view
+    tgt = b[:, :1].clone().requires_grad_(True)
+    lb = L.mse_loss(a, tgt)
+    assert _rel(lb, ((a - tgt) ** 2).mean()) < 2e-6
+    lb.backward()
+    wantg = (-2.0 / a.numel() * (a - tgt.detach())).sum(dim=1, keepdim=True)
+    assert tgt.grad.shape == tgt.shape and float((tgt.grad - wantg).abs().max()) < 1e-9 + 1e-5 * float(wantg.abs().max())
+    # concurrent streams: each call owns its partial sums
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        l1 = [L.mse_loss(a, b) for _ in range(20)]
+    with torch.cuda.stream(s2):
+        l2 = [L.mse_loss(big_a, big_b) for _ in range(20)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, l1[0]) for x in l1) and all(torch.equal(x, l2[0]) for x in l2)
+    assert _rel(l1[0], want) < 2e-6

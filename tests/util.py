@@ -65,19 +65,22 @@ def scalar_loss(color, depth_bvhw, alpha_bv1hw, target, wd, wa, mask=None):
 
 
 def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_invariant=True, want_fragile=True,
-               with_grads=True, mask_fragile=False):
+               with_grads=True, mask_fragile=False, band4=False, grad_names=GRAD_NAMES):
     """`mask_fragile`: the loss ignores the pixels the oracle flags as knife-edge; the mask comes back as
-    res["pixel_mask"] for `run_product(..., pixel_mask=...)`."""
+    res["pixel_mask"] for `run_product(..., pixel_mask=...)`.  `grad_names`: the inputs that require grad (the others
+    are constants, e.g. only "extrinsics" for the reference's test-time pose alignment)."""
     from oracle import glue_ref
-    leaves = {n: getattr(batch, n).detach().clone().to(dtype).requires_grad_(with_grads) for n in GRAD_NAMES}
+    leaves = {n: getattr(batch, n).detach().clone().to(dtype).requires_grad_(with_grads and n in grad_names)
+              for n in GRAD_NAMES}
     # the rasterizer consumes float32 inputs: keep the float32 values exactly, evaluate in `dtype`
     out = glue_ref.decoder_forward(leaves["means"], leaves["harmonics"], leaves["opacities"], leaves["rotations"],
                                    leaves["scales"], leaves["extrinsics"], batch.intrinsics.to(dtype),
                                    batch.near.to(dtype), batch.far.to(dtype), batch.image_shape, background,
-                                   make_scale_invariant=scale_invariant, dtype=dtype, want_fragile=want_fragile)
+                                   make_scale_invariant=scale_invariant, dtype=dtype, want_fragile=want_fragile,
+                                   band4=band4, want_radii_fragile=want_fragile)
     color, depth, alpha, radii = out[:4]
     res = dict(color=color.detach(), depth=depth.detach(), alpha=alpha.detach(), radii=radii,
-               fragile=out[4] if want_fragile else None)
+               fragile=out[4] if want_fragile else None, radii_fragile=out[5] if want_fragile else None)
     if with_grads:
         wd, wa = loss_weights(batch)
         mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else None
@@ -87,32 +90,44 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
             loss.backward()
         res["loss"] = float(loss.detach())
         res["grads"] = {n: (leaves[n].grad.detach() if leaves[n].grad is not None else torch.zeros_like(leaves[n]))
-                        for n in GRAD_NAMES}
+                        for n in grad_names}
     return res
 
 
+def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cuda", max_pairs=None, band4=None):
+    """The product's decoder MODULE under the reference's registry name and config
+    (decoder/__init__.py:4-12, decoder_splatting_cuda.py:15-21)."""
+    from spfsplatv2_amd import decoder as dec
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=list(background),
+                                                    make_scale_invariant=scale_invariant, enable_cov_grad=True,
+                                                    enable_sh_grad=True)).to(device)
+    d.max_pairs = max_pairs
+    d.sh_band4 = band4
+    return d
+
+
 def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invariant=True, with_grads=True,
-                max_pairs=None, pixel_mask=None):
-    import spfsplatv2_amd as spf
+                max_pairs=None, pixel_mask=None, band4=None, grad_names=GRAD_NAMES):
+    """The product, end to end THROUGH ITS DECODER MODULE (`DecoderSplattingCUDA.render` = `forward` + the alpha and
+    radii the reference's decoder drops): colour and depth are the module's own outputs, including its depth x near
+    post-processing (decoder_splatting_cuda.py:72-76) -- nothing of it is re-implemented here."""
+    from spfsplatv2_amd import decoder as dec
     bd = batch.to(device)
-    leaves = {n: getattr(bd, n).detach().clone().requires_grad_(with_grads) for n in GRAD_NAMES}
-    bg = torch.tensor(background, dtype=torch.float32, device=device)
-    color, depth, alpha = spf.render_views(
-        leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape, bg, leaves["means"],
-        leaves["harmonics"], leaves["opacities"], leaves["rotations"], leaves["scales"],
-        scale_invariant=scale_invariant, enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
-    depth = depth[:, :, 0]
-    if scale_invariant:
-        depth = depth * bd.near[:, :, None, None]
+    leaves = {n: getattr(bd, n).detach().clone().requires_grad_(with_grads and n in grad_names) for n in GRAD_NAMES}
+    d = product_decoder(background, scale_invariant, device, max_pairs, band4)
+    g = dec.Gaussians(leaves["means"], bd.covariances, leaves["rotations"], leaves["scales"], leaves["harmonics"],
+                      leaves["opacities"])
+    out, alpha, radii = d.render(g, leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)
+    color, depth = out.color, out.depth
     res = dict(color=color.detach().cpu(), depth=depth.detach().cpu(), alpha=alpha.detach().cpu(),
-               stats=spf.last_forward_stats())
+               radii=radii.cpu(), stats={k: v for k, v in d.last_call.items() if k != "counters"}, decoder=d)
     if with_grads:
         wd, wa = loss_weights(batch)
         loss = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device),
                            None if pixel_mask is None else pixel_mask.to(device))
         loss.backward()
         res["loss"] = float(loss.detach())
-        res["grads"] = {n: leaves[n].grad.detach().cpu() for n in GRAD_NAMES}
+        res["grads"] = {n: leaves[n].grad.detach().cpu() for n in grad_names}
     return res
 
 
@@ -130,15 +145,29 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
     d = (prod["color"].double() - ref["color"].double()).abs()
     rep["rgb_max_all"] = float(d.max())
     rep["rgb_max"] = float((d * ok[:, :, None]).max())
+    # the UNMASKED image: pixels off by more than the tolerance (any channel) may not outnumber the pixels the oracle
+    # flagged -- the mask cannot hide a real disagreement larger than itself
+    rep["bad_frac_all"] = float((d.amax(dim=2) > rgb_tol).float().mean())
+    # radii are integer work: bit-exact wherever the oracle does not flag a rounding knife-edge of the Gaussian itself
+    if prod.get("radii") is not None and ref.get("radii_fragile") is not None:
+        rok = ~ref["radii_fragile"]
+        rep["radii_fragile_frac"] = float(ref["radii_fragile"].float().mean())
+        rep["radii_mismatch"] = int(((prod["radii"].long() != ref["radii"].long()) & rok).sum())
     dd = (prod["depth"].double() - ref["depth"].double()).abs() * ok
     rep["depth_rel"] = float(dd.max() / max(float(ref["depth"].abs().max()), 1e-30))
     rep["alpha_max"] = float(((prod["alpha"].double() - ref["alpha"].double()).abs() * ok[:, :, None]).max())
     if "grads" in prod and "grads" in ref:
-        for n in GRAD_NAMES:
+        for n in ref["grads"]:
             rep["g_" + n] = rel_linf(prod["grads"][n], ref["grads"][n])
     fails = []
     if rep["fragile_frac"] > max_fragile_frac:
         fails.append("fragile_frac")
+    if rep["bad_frac_all"] > rep["fragile_frac"]:
+        fails.append("bad_frac_all")
+    if rep.get("radii_mismatch", 0) > 0:
+        fails.append("radii_mismatch")
+    if rep.get("radii_fragile_frac", 0.0) > 0.01:
+        fails.append("radii_fragile_frac")
     if rep["rgb_max"] > rgb_tol:
         fails.append("rgb_max")
     if rep["depth_rel"] > 1e-4:
