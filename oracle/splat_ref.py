@@ -308,7 +308,14 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
             if want_fragile:
                 with torch.no_grad():
                     rel = 2e-4
-                    near_alpha = ((alpha - ALPHA_MIN).abs() < rel * ALPHA_MIN) & (power <= 0)
+                    # ... plus what the float32 resolution of the pixel centre itself can move alpha by: the centre
+                    # comes out of ((ndc + 1) * W - 1) / 2, i.e. it is only good to ~1.2e-7 * (|x| + W/2) pixels
+                    # (6e-5 px at x = 500), and at the rim of a footprint d(ln alpha)/dx = A dx + B dy is ~5 per pixel
+                    ex = 1.2e-7 * (gxy[None, :, 0].abs() + 0.5 * W + 1.0)
+                    ey = 1.2e-7 * (gxy[None, :, 1].abs() + 0.5 * H + 1.0)
+                    win = rel + (con[None, :, 0] * dx + con[None, :, 1] * dy).abs() * ex \
+                        + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey
+                    near_alpha = ((alpha - ALPHA_MIN).abs() < win * ALPHA_MIN) & (power <= 0)
                     # power > 0 (skipped) vs <= 0 can only flip where the three terms cancel to rounding level
                     mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) \
                         + (con[None, :, 1] * dx * dy).abs()
