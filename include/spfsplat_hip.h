@@ -118,8 +118,9 @@ typedef struct SpfGrads {
     const float* dL_dimage;   /* [R,3,H,W] */
     const float* dL_ddepth;   /* [R,1,H,W] */
     const float* dL_dalpha;   /* [R,1,H,W] */
-    float* gpair;             /* [capacity,12] scratch: screen-space gradient of every (Gaussian, tile) pair, written
-                                 once per pair by its tile (no global atomics, no memset), indexed by pair_off + k */
+    float* gpair;             /* [capacity,10] scratch: screen-space gradient of every (Gaussian, tile) pair, written
+                                 once per pair by its tile (no global atomics, no memset), indexed by pair_off + k;
+                                 records are packed: 9 floats each, 10 when dL_ddepth != NULL */
     float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
                                  nblk = spf_raster_view_partial_blocks(G) */
     float* dL_dmeans3D;       /* [S,G,3] */
@@ -192,7 +193,7 @@ int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, in
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
                               uint64_t capacity, uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream);
 
-/* Backward of both stages.  `capacity` = number of 12-float records g->gpair can hold (>= D). */
+/* Backward of both stages.  `capacity` = number of 10-float records g->gpair can hold (>= D). */
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
                         const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
 

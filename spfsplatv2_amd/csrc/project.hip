@@ -178,8 +178,6 @@ __device__ __forceinline__ void sh_basis(float x, float y, float z, float* __res
 // block of a Gaussian starts at a multiple of 4 bytes only and the same dwordx4 instructions are issued with dword
 // alignment (legal for global memory on gfx9+; a 75-float block read through 4-byte loads costs 4x the instructions
 // and address-coalescer cycles).  v[i][c] = coefficient 4*k4+i of channel c.
-typedef float f4a __attribute__((ext_vector_type(4)));
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <bool ALIGNED>
 __device__ __forceinline__ f4a ld4(const float* __restrict__ p) {
     if (ALIGNED) return *reinterpret_cast<const f4a*>(p);
@@ -523,13 +521,15 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             // sum the screen-space gradient records of this Gaussian's (Gaussian, tile) pairs
             float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
             {
-                const float4* __restrict__ gp =
-                    reinterpret_cast<const float4*>(gr.gpair + (size_t)st.pair_off[rg] * kRec);
+                const int gs = grec_floats(gr.dL_ddepth != nullptr);       // packed records: 9 or 10 floats
+                const float* __restrict__ gp = gr.gpair + (size_t)st.pair_off[rg] * gs;
                 for (int i = 0; i < npair; ++i) {
-                    const float4 a0 = gp[3 * i], a1 = gp[3 * i + 1], a2 = gp[3 * i + 2];
+                    const f4a a0 = *reinterpret_cast<const f4u*>(gp + gs * i);
+                    const f4a a1 = *reinterpret_cast<const f4u*>(gp + gs * i + 4);
                     g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
                     g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
-                    g2.x += a2.x; g2.y += a2.y;
+                    g2.x += gp[gs * i + 8];
+                    if (gs == 10) g2.y += gp[gs * i + 9];
                 }
             }
             const float sc = in.view_scale ? in.view_scale[r] : 1.0f;

@@ -432,11 +432,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kAcc = 10;
 
+template <bool DEPTH_GRAD>
 __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t slot, const float* acc) {
-    float4* __restrict__ o = reinterpret_cast<float4*>(gpair + (size_t)slot * kRec);
-    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-    o[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+    store_grec<DEPTH_GRAD>(gpair, slot, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8], acc[9]);
 }
 
 template <bool DEPTH_GRAD>
@@ -506,12 +504,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     // Entries behind every pixel's last contributor get a zero record (every pair slot is written exactly once,
     // so the scratch needs no memset).
     {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t idx = bmax + threadIdx.x; idx < n; idx += kBlock) {
-            float4* __restrict__ o =
-                reinterpret_cast<float4*>(gpair + (size_t)pair_slot((uint32_t)pairs[beg + idx]) * kRec);
-            o[0] = z; o[1] = z; o[2] = z;
-        }
+        for (uint32_t idx = bmax + threadIdx.x; idx < n; idx += kBlock)
+            store_grec<DEPTH_GRAD>(gpair, pair_slot((uint32_t)pairs[beg + idx]), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                   0.f, 0.f);
     }
     if (bmax == 0) return;
 
@@ -522,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     bool staged = false;
     for (int base = (int)((bmax - 1) / kStage) * kStage; base >= 0; base -= kStage) {
         // flush the previous round's accumulators: ONE plain 48-byte store per (Gaussian, tile) pair
-        if (staged) flush_pair(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
+        if (staged) flush_pair<DEPTH_GRAD>(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
         uint32_t bits = 0;
         const uint32_t idx = (uint32_t)base + threadIdx.x;
         staged = idx < n && idx < bmax;
@@ -623,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
         }
         __syncthreads();
     }
-    if (staged) flush_pair(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
+    if (staged) flush_pair<DEPTH_GRAD>(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -693,43 +688,54 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     PHASE_INIT();
     if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
-    // ---- lane <-> pixel assignment by the number of contributors the forward recorded ----
+    // ---- per-pixel state, then the lane <-> pixel assignment by the number of contributors the forward recorded ----
+    // Everything a pixel needs is loaded in the NATURAL order first (coalesced, and independent of the assignment, so
+    // these loads are in flight while the counting sort runs) and parked in LDS; after the sort every lane picks up
+    // the values of ITS pixel from there -- one dependent global round trip less per tile than loading after the sort.
     int mypix;
+    float T_final, gI0, gI1, gI2, gD, gA;
+    uint32_t ncon;
     {
         const int qx = X0 + (tid & 15), qy = Y0 + (tid >> 4);
-        uint32_t h = 0;
-        if (qx < W && qy < H) h = n_contrib[2 * ((size_t)r * P + (size_t)qy * W + qx) + 1];
+        uint32_t h = 0, nc = 0;
+        float tf = 1.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, qd = 0.f, qa = 0.f;
+        if (qx < W && qy < H) {
+            const size_t qpix = (size_t)qy * W + qx;
+            const uint2 c2 = reinterpret_cast<const uint2*>(n_contrib)[(size_t)r * P + qpix];   // (last, hits)
+            nc = c2.x; h = c2.y;
+            tf = final_T[(size_t)r * P + qpix];
+            if (dL_dimage) {
+                const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
+                q0 = gi[qpix]; q1 = gi[P + qpix]; q2 = gi[2 * P + qpix];
+            }
+            if (DEPTH_GRAD) qd = dL_ddepth[(size_t)r * P + qpix];
+            if (dL_dalpha) qa = dL_dalpha[(size_t)r * P + qpix];
+        }
         s_pm[0][tid] = 0u;                        // (s_pm is free before the rounds: bins in word 0, order in word 1)
         __syncthreads();
         mypix = assign_pixels_by_load(h, &s_pm[0][0], &s_pm[1][0]);
+        // (the loads are only needed from here on)
+        s_gI[tid] = make_float4(q0, q1, q2, DEPTH_GRAD ? qd : 1.f);   // .w == 1 lets phase C fold sum(u) into a packed fma
+        s_pool[tid] = make_float2(tf, __uint_as_float(nc));           // (the pool is free before the rounds too)
+        s_pool[kBlock + tid] = make_float2(qa, 0.f);
+        __syncthreads();
+        const float4 g4 = s_gI[mypix];
+        const float2 t2 = s_pool[mypix];
+        T_final = t2.x; ncon = __float_as_uint(t2.y);
+        gI0 = g4.x; gI1 = g4.y; gI2 = g4.z; gD = DEPTH_GRAD ? g4.w : 0.f;
+        gA = s_pool[kBlock + mypix].x;
     }
     const int lx = mypix & 15, ly = mypix >> 4;
     const int px = X0 + lx, py = Y0 + ly;
-    const bool inside = px < W && py < H;
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
-    const size_t pix = (size_t)py * W + px;
     auto pair_slot = [&](uint32_t gid) -> uint32_t {
         const size_t rg = (size_t)r * G + gid;
         const uint32_t rc = rect[rg];
         const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
         return pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     };
-
-    float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
-    uint32_t ncon = 0;
-    if (inside) {
-        T_final = final_T[(size_t)r * P + pix];
-        ncon = n_contrib[2 * ((size_t)r * P + pix)];
-        if (dL_dimage) {
-            const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
-            gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
-        }
-        if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + pix];
-        if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + pix];
-    }
-    s_gI[mypix] = make_float4(gI0, gI1, gI2, DEPTH_GRAD ? gD : 1.f);   // .w == 1 lets phase C fold sum(u) into a packed fma
     const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
 
@@ -739,12 +745,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const uint32_t bmax = min(n, max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3])));   // (clamp: see the rows kernel)
     if (ABLATE(2)) { if (tail == 123.f) gpair[0] = T_final; return; }
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (uint32_t idx = bmax + tid; idx < n; idx += kBlock) {
-            float4* __restrict__ o =
-                reinterpret_cast<float4*>(gpair + (size_t)pair_slot((uint32_t)pairs[beg + idx]) * kRec);
-            o[0] = z; o[1] = z; o[2] = z;
-        }
+        for (uint32_t idx = bmax + tid; idx < n; idx += kBlock)
+            store_grec<DEPTH_GRAD>(gpair, pair_slot((uint32_t)pairs[beg + idx]), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                   0.f, 0.f);
     }
     if (bmax == 0) return;
     PHASE_MARK(0);
@@ -752,7 +755,6 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
 
     float Tr = T_final;
     float sB = -tail * T_final;          // running "behind" scalar of the replay (see phase B)
-    const uint32_t kconst = (uint32_t)(lx + ly - 256);   // per-pixel part of the slot index (mod 2^32)
 
     uint32_t hi = bmax;   // entries [0, hi) are still to be replayed
     while (hi > 0) {
@@ -776,12 +778,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             }
         }
         const uint32_t size = (uint32_t)(bw * bh);
-        uint32_t inc = size;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
-            if (lane >= o) inc += y;
-        }
+        const uint32_t inc = wave_iscan_u32(size);      // DPP ladder: 7 VALU adds, no LDS permutes
         // (the barrier that closed the previous round makes s_w / s_wacc / s_pool / s_p* reusable here)
         if (lane == kWave - 1) s_w[wave] = inc;
         __syncthreads();
@@ -794,11 +791,10 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         if (lane == 0) s_wacc[wave] = (uint32_t)__popcll(accb);
         if (acc) {
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
-            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, b.w, b.z);
-            // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + ly*bw + lx; the
-            // bracket is >= -255 and travels biased by 256 (13 bits) next to bw-1
-            s_p2[tid] = make_float4(cc.x, cc.y, cc.z,
-                                    __int_as_float(max(bw - 1, 0) | (((int)off - yl * bw - xl + 256) << 4)));
+            // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + bw*ly + lx: the box width
+            // and the (signed) bracket travel as integers in the two fields phase B has no other use for
+            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, __int_as_float(bw), b.z);
+            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, __int_as_float((int)off - yl * bw - xl));
         }
 #pragma unroll
         for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
@@ -853,8 +849,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                     const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));
                     const float wgt = alpha * Tr;
                     sB = fmaf(cg, wgt, sB);
-                    const uint32_t box = __float_as_uint(p2.w);
-                    const uint32_t k = __builtin_amdgcn_ubfe(box, 4, 13) + __umul24(box & 15u, (uint32_t)ly) + kconst;
+                    const int k = __mul24(__float_as_int(p1.z), ly) + (__float_as_int(p2.w) + lx);   // v_mad_i32_i24 + add
                     s_pool[k] = make_float2(wgt, Gv * dL_dalpha_);
                 }
             };
@@ -913,11 +908,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                 sxy = fmaf(t.x, dc.y, sxy);
             }
             const float o = b.y;   // [3DGS-grad] dL/dG = opacity * dL/dalpha (the 0.99 clamp is straight-through)
-            float4* __restrict__ out = reinterpret_cast<float4*>(gpair + (size_t)pair_slot(gid) * kRec);
-            out[0] = make_float4(-o * (a.z * s1.x + a.w * s1.y), -o * (b.x * s1.y + a.w * s1.x), -0.5f * o * s2.x,
-                                 -o * sxy);
-            out[1] = make_float4(-0.5f * o * s2.y, c2s.y, c01.x, c01.y);
-            out[2] = make_float4(c2s.x, cd, 0.f, 0.f);
+            store_grec<DEPTH_GRAD>(gpair, pair_slot(gid), -o * (a.z * s1.x + a.w * s1.y),
+                                   -o * (b.x * s1.y + a.w * s1.x), -0.5f * o * s2.x, -o * sxy, -0.5f * o * s2.y, c2s.y,
+                                   c01.x, c01.y, c2s.x, cd);
         }
         hi -= (uint32_t)cnt;
         __syncthreads();                         // round over: LDS scratch may be reused

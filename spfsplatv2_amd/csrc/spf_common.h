@@ -18,7 +18,21 @@ constexpr int kMaxLdsTiles = 4096;  // per-render tile histograms up to this man
 // Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
 // 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).
 // Gradient record (one per (Gaussian, tile) pair): 0 dx, 1 dy (pixel space), 2 dA, 3 dB, 4 dC, 5 dopacity,
-// 6..8 drgb, 9 ddepth, 10..11 unused.
+// 6..8 drgb [, 9 ddepth]: 9 floats, 10 when the depth output has an upstream gradient -- packed (36 / 40-byte
+// stride, dword aligned), because every byte of it crosses HBM twice (render backward -> projection backward).
+
+typedef float f4a __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dwordx4 access at dword alignment (legal for global memory)
+__host__ __device__ __forceinline__ constexpr int grec_floats(bool depth_grad) { return depth_grad ? 10 : 9; }
+template <bool DEPTH_GRAD>
+__device__ __forceinline__ void store_grec(float* __restrict__ gpair, uint32_t slot, float v0, float v1, float v2,
+                                           float v3, float v4, float v5, float v6, float v7, float v8, float v9) {
+    float* __restrict__ o = gpair + (size_t)slot * grec_floats(DEPTH_GRAD);
+    *reinterpret_cast<f4u*>(o) = f4a{v0, v1, v2, v3};
+    *reinterpret_cast<f4u*>(o + 4) = f4a{v4, v5, v6, v7};
+    o[8] = v8;
+    if (DEPTH_GRAD) o[9] = v9;
+}
 
 constexpr float kNearCull = 0.2f;
 constexpr float kLowPass = 0.3f;

@@ -278,7 +278,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
     capacity = pairs.numel()
-    gpair = torch.empty((capacity, _REC), **f32)
+    gpair = torch.empty((capacity, 10), **f32)     # packed gradient records: 9 (+1 with a depth gradient) floats
     d_means = torch.empty_like(means3D)
     d_opac = torch.empty_like(opacities)
     d_scales = torch.empty_like(scales) if want["scales_rot"] else None
