@@ -283,6 +283,9 @@ __device__ __forceinline__ void sh_store_grad(float* __restrict__ o, int K, cons
 #ifndef SPF_PFWD_BPC
 #define SPF_PFWD_BPC 1
 #endif
+#ifndef SPF_PABL
+#define SPF_PABL 0
+#endif
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
@@ -406,15 +409,18 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                     if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
                 }
             }
+            if (SPF_PABL != 1 || cA == 123.f) {
             st.radii[rg] = (int)radius;
             st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
             st.zkey[rg] = pr.tz;
             rec[0] = make_float4(pr.px, pr.py, cA, cB);
             rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
             rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
+            }
             uint32_t* __restrict__ cnt = lds_hist ? s_hist : st.tile_count + (size_t)r * T;
             uint32_t* __restrict__ are = lds_hist ? s_area : st.tile_flags + (size_t)r * T;
             const uint32_t area = disc_area_capped(pr.px, pr.py, cull_r2);
+            if (SPF_PABL != 2 || cA == 123.f)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     atomicAdd(&cnt[ty * tiles_x + tx], 1u);
@@ -422,12 +428,14 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 }
         }
         // pairs produced by this block for this render (feeds the Gaussian-major pair numbering)
+        if (SPF_PABL != 3) {
         const uint32_t wsum = wave_sum_u32(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u);
         if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = wsum;
         __syncthreads();
         if (threadIdx.x == 0)
             st.blk_total[(size_t)r * gridDim.x + blockIdx.x] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (lds_hist) {
+        }
+        if (lds_hist && SPF_PABL != 4) {
             uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
             uint32_t* __restrict__ gare = st.tile_flags + (size_t)r * T;
             for (int t = threadIdx.x; t < T; t += kBlock) {
@@ -502,6 +510,26 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
     extern __shared__ float s_part[];        // [min(V, kViewChunk)][4 waves][12]: viewmatrix partials of a chunk of views
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
+    // Software pipeline over the views.  A view's gradient records hang off two dependent global reads (rect /
+    // pair_off -> records); issued inside the view they cost two memory round trips per view with three waves per SIMD to
+    // hide them (24 of 72 us on the bench step).  So: the (rect, pair_off) words of view v+2 and the FIRST record of
+    // view v+1 (93 % of the visible Gaussians touch one tile) are in flight while view v is chained.
+    const int gs = grec_floats(gr.dL_ddepth != nullptr);       // packed records: 9 or 10 floats
+    const size_t rg0 = (size_t)s * d.V * d.G + (live ? g : 0);
+    auto pairs_of = [](uint32_t rc) -> int {
+        return (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
+    };
+    uint32_t rc_cur = live ? st.rect[rg0] : 0u, po_cur = live ? st.pair_off[rg0] : 0u;
+    uint32_t rc_nxt = 0u, po_nxt = 0u;
+    if (live && d.V > 1) { rc_nxt = st.rect[rg0 + d.G]; po_nxt = st.pair_off[rg0 + d.G]; }
+    f4a q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+    float q8 = 0.f, q9 = 0.f;
+    if (pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
+        const float* __restrict__ gp = gr.gpair + (size_t)po_cur * gs;
+        q0 = *reinterpret_cast<const f4u*>(gp); q1 = *reinterpret_cast<const f4u*>(gp + 4); q8 = gp[8];
+        if (gs == 10) q9 = gp[9];
+    }
+
     for (int v = 0; v < d.V; ++v) {
         const int r = s * d.V + v;
         const float* __restrict__ Vm = in.viewmatrix + 16 * r;
@@ -514,16 +542,26 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
 
         // a Gaussian without (Gaussian, tile) pairs in this view (culled: rect == 0, or no pixel centre in its
         // cull disc) received no gradient record -> nothing to chain
-        const uint32_t rc = live ? st.rect[rg] : 0u;
-        const int npair = (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
+        const uint32_t rc = rc_cur, po = po_cur;
+        const int npair = pairs_of(rc);
         const bool vis = npair > 0;
+        // this view's first record (loaded one view ago) ...
+        float4 g0 = make_float4(q0.x, q0.y, q0.z, q0.w), g1 = make_float4(q1.x, q1.y, q1.z, q1.w);
+        float4 g2 = make_float4(q8, q9, 0.f, 0.f);
+        // ... and the loads of the views behind it
+        rc_cur = rc_nxt; po_cur = po_nxt;
+        if (live && v + 2 < d.V) { rc_nxt = st.rect[rg + 2 * (size_t)d.G]; po_nxt = st.pair_off[rg + 2 * (size_t)d.G]; }
+        q0 = f4a{0.f, 0.f, 0.f, 0.f}; q1 = q0; q8 = 0.f; q9 = 0.f;
+        if (v + 1 < d.V && pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
+            const float* __restrict__ gp = gr.gpair + (size_t)po_cur * gs;
+            q0 = *reinterpret_cast<const f4u*>(gp); q1 = *reinterpret_cast<const f4u*>(gp + 4); q8 = gp[8];
+            if (gs == 10) q9 = gp[9];
+        }
         if (vis) {
-            // sum the screen-space gradient records of this Gaussian's (Gaussian, tile) pairs
-            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+            // the rest of this Gaussian's (Gaussian, tile) pairs: their screen-space gradient records add up
             {
-                const int gs = grec_floats(gr.dL_ddepth != nullptr);       // packed records: 9 or 10 floats
-                const float* __restrict__ gp = gr.gpair + (size_t)st.pair_off[rg] * gs;
-                for (int i = 0; i < npair; ++i) {
+                const float* __restrict__ gp = gr.gpair + (size_t)po * gs;
+                for (int i = 1; i < (SPF_PABL == 5 ? 0 : npair); ++i) {
                     const f4a a0 = *reinterpret_cast<const f4u*>(gp + gs * i);
                     const f4a a1 = *reinterpret_cast<const f4u*>(gp + gs * i + 4);
                     g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
@@ -665,11 +703,12 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
-        if (gr.vpartial) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                const float tot = wave_sum(dV[k]);
-                if (lane == 0) s_part[((v & (kViewChunk - 1)) * 4 + wave) * 12 + k] = tot;
+        if (gr.vpartial && SPF_PABL != 6) {
+            float tot[3];
+            wave_sum12(dV, tot);                       // tot[j] = total of dV[4j + (lane & 3)], in every lane
+            if (lane < 4) {
+                float* __restrict__ sp = s_part + ((v & (kViewChunk - 1)) * 4 + wave) * 12 + lane;
+                sp[0] = tot[0]; sp[4] = tot[1]; sp[8] = tot[2];
             }
             // the four wave totals are combined once per chunk of kViewChunk views (normally: once, after the loop)
             if (((v + 1) & (kViewChunk - 1)) == 0 || v + 1 == d.V) {
@@ -686,6 +725,7 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
         }
     }
     if (!live) return;
+    if (SPF_PABL == 7 && dp0[0] != 123.f) return;
 
     gr.dL_dmeans3D[3 * sg] = dp0[0]; gr.dL_dmeans3D[3 * sg + 1] = dp0[1]; gr.dL_dmeans3D[3 * sg + 2] = dp0[2];
     gr.dL_dopacities[sg] = dopac;
