@@ -165,10 +165,13 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
 
 /* Decoder fast path (the batched DecoderSplattingCUDA.forward, decoder_splatting_cuda.py:41-78): two launches fewer
  * per step than the calls above.
- *   spf_decoder_prepare           = spf_camera_forward AND the clearing of `zero_bytes` bytes at `zero` (pass
- *                                   st->tile_count with tile_flags laid out right behind it: 8*R*T bytes; 16-byte
- *                                   aligned) in ONE kernel;
- *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing of those counters;
+ *   spf_decoder_prepare           = spf_camera_forward AND the clearing of `zero_bytes` bytes at `zero` in ONE kernel.
+ *                                   Pass ONE buffer laid out tile_count | tile_flags | tile_start (R*T+1) | tile_fill |
+ *                                   counters (4) [| padding] and clear all of it (16*R*T + 20 bytes rounded up to 16;
+ *                                   16-byte aligned);
+ *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing; because tile_fill and
+ *                                   the counters arrive zeroed as well, the tile scan runs with one block per render
+ *                                   instead of a single block;
  *   spf_camera_backward_partials  = the deterministic sum of g->vpartial [R,nblk,12] (as written by spf_raster_backward
  *                                   when g->vpartial != NULL; pass g->dL_dviewmatrix = NULL to skip its own reduction)
  *                                   AND spf_camera_backward, in ONE kernel. */

@@ -9,7 +9,7 @@
 namespace spf {
 hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&, int, int, hipStream_t);
 hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, uint64_t, hipStream_t);
-hipError_t launch_tile_scan(const SpfState&, int, int, uint32_t, hipStream_t);
+hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, hipStream_t);
 hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
@@ -165,7 +165,7 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
     if (tiles_cleared) {
-        // spf_decoder_prepare cleared tile_count | tile_flags together with the camera set-up
+        // spf_decoder_prepare cleared tile_count | tile_flags | tile_start | tile_fill | counters with the camera set-up
     } else if (st->tile_flags == st->tile_count + RT) {   // adjacent (the Python binding lays them out so): one fill
         SPF_HIP(hipMemsetAsync(st->tile_count, 0, sizeof(uint32_t) * 2 * (size_t)RT, stream));
     } else {
@@ -178,8 +178,8 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     }
     {
         StageScope t(SPF_STAGE_SCAN, stream);
-        SPF_HIP(spf::launch_tile_scan(*st, RT, d->S * d->V * spf_raster_view_partial_blocks(d->G),
-                                      spf::dense_threshold(), stream));
+        SPF_HIP(spf::launch_tile_scan(*st, d->S * d->V, tiles_x * tiles_y, spf_raster_view_partial_blocks(d->G),
+                                      spf::dense_threshold(), tiles_cleared, stream));
     }
     return SPF_OK;
 }

@@ -78,6 +78,77 @@ __global__ __launch_bounds__(kScanThreads) void spf_tile_scan_kernel(const uint3
     }
 }
 
+// The same scan with one block PER RENDER (grid = R): block r first adds up the tile counts of the renders before it
+// (its base -- at most R*T coalesced reads that hit the L2), then scans only its own T tile counts and its own nb block
+// totals (both add up to the render's pairs, so one base serves both).  R blocks instead of one: the single-block scan
+// is pure latency (13 us for 8,192 + 8,192 counters on the bench step, 3 % of it) and it is on the critical path.
+// counters[1] / counters[3] are combined with atomics, so counters[0..3] must be ZERO on entry.
+__global__ __launch_bounds__(kScanThreads) void spf_tile_scan_render_kernel(const uint32_t* __restrict__ count,
+                                                                            uint32_t* __restrict__ start,
+                                                                            const uint32_t* __restrict__ flags,
+                                                                            uint32_t dense_thr,
+                                                                            uint32_t* __restrict__ counters, int T,
+                                                                            const uint32_t* __restrict__ blk_total,
+                                                                            uint32_t* __restrict__ blk_base, int nb) {
+    constexpr int kWaves = kScanThreads / kWave;
+    __shared__ uint32_t s_red[kWaves], s_a[kWaves], s_b[kWaves], s_mx[kWaves], s_dn[kWaves];
+    const int r = blockIdx.x, R = gridDim.x;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    // base = pairs of the renders before this one
+    uint32_t pre = 0;
+    for (int i = threadIdx.x; i < r * T; i += kScanThreads) pre += count[i];
+    pre = wave_sum_u32(pre);
+    if (lane == 0) s_red[wave] = pre;
+    count += (size_t)r * T; flags += (size_t)r * T; start += (size_t)r * T;
+    blk_total += (size_t)r * nb; blk_base += (size_t)r * nb;
+    const int sega = ((T + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;      // multiples of 64 elements
+    const int segb = ((nb + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;
+    const int a0 = min(T, wave * sega), a1 = min(T, a0 + sega), b0 = min(nb, wave * segb), b1 = min(nb, b0 + segb);
+    uint32_t sa = 0, sb = 0, mx = 0, dn = 0;
+    for (int i = a0 + lane; i < a1; i += kWave) {
+        const uint32_t c = count[i];
+        sa += c;
+        mx = max(mx, c);
+        dn += tile_is_dense(flags[i], c, dense_thr) ? 1u : 0u;
+    }
+    for (int i = b0 + lane; i < b1; i += kWave) sb += blk_total[i];
+    sa = wave_sum_u32(sa); sb = wave_sum_u32(sb); mx = wave_max_u32(mx); dn = wave_sum_u32(dn);
+    if (lane == 0) { s_a[wave] = sa; s_b[wave] = sb; s_mx[wave] = mx; s_dn[wave] = dn; }
+    __syncthreads();
+    uint32_t base = 0, runa = 0, runb = 0, total = 0, gmax = 0, dense = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+        base += s_red[w];
+        if (w < wave) { runa += s_a[w]; runb += s_b[w]; }
+        total += s_a[w];
+        gmax = max(gmax, s_mx[w]);
+        dense += s_dn[w];
+    }
+    runa += base; runb += base;
+    for (int i0 = a0; i0 < a1; i0 += kWave) {
+        const int i = i0 + lane;
+        const uint32_t c = i < a1 ? count[i] : 0u;
+        const uint32_t inc = wave_iscan_u32(c);
+        if (i < a1) start[i] = runa + inc - c;
+        runa += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
+    }
+    for (int i0 = b0; i0 < b1; i0 += kWave) {
+        const int i = i0 + lane;
+        const uint32_t c = i < b1 ? blk_total[i] : 0u;
+        const uint32_t inc = wave_iscan_u32(c);
+        if (i < b1) blk_base[i] = runb + inc - c;
+        runb += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
+    }
+    if (threadIdx.x == 0) {
+        if (gmax) atomicMax(&counters[1], gmax);      // longest tile list
+        if (dense) atomicAdd(&counters[3], dense);    // tiles the dense "rows" render kernels take
+        if (r == R - 1) {
+            start[T] = base + total;                  // = tile_start[R*T]
+            counters[0] = base + total;               // D
+        }
+    }
+}
+
 // ---- scatter-with-keys: block = 256 consecutive Gaussians of one render -----------------------------
 // Three phases per block, all tile bookkeeping in LDS: (1) count the block's pairs per tile, (2) reserve one
 // contiguous range per touched tile with ONE global atomic, (3) hand out slots inside the range with LDS
@@ -358,10 +429,19 @@ __global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint3
 }
 
 // ---- launchers ----------------------------------------------------------------------------------
-hipError_t launch_tile_scan(const SpfState& st, int RT, int nb, uint32_t dense_thr, hipStream_t stream) {
-    spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.tile_flags,
-                                                         dense_thr, st.counters, RT,
-                                                         st.blk_total, st.blk_base, nb);
+// `zeroed`: the caller cleared tile_fill and counters[0..3] (together with the tile counters): the scan can then run
+// with one block per render; otherwise (or when there are too many renders for every block to add up its
+// predecessors) the single-block scan, which initialises both itself.
+hipError_t launch_tile_scan(const SpfState& st, int R, int T, int nblk, uint32_t dense_thr, bool zeroed,
+                            hipStream_t stream) {
+    if (zeroed && R > 1 && R <= 256 && (long)R * T <= (1L << 18))
+        spf_tile_scan_render_kernel<<<R, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_flags,
+                                                                    dense_thr, st.counters, T, st.blk_total,
+                                                                    st.blk_base, nblk);
+    else
+        spf_tile_scan_kernel<<<1, kScanThreads, 0, stream>>>(st.tile_count, st.tile_start, st.tile_fill, st.tile_flags,
+                                                             dense_thr, st.counters, R * T, st.blk_total, st.blk_base,
+                                                             R * nblk);
     return hipGetLastError();
 }
 

@@ -178,8 +178,9 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     rect = torch.empty((2 * R * G,), **i32)        # packed tile rect | depth key (float bits)
     nblk = lib.spf_raster_view_partial_blocks(G)
     pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
-    tiles = torch.empty((4 * R * T + 1 + 4,), **i32)   # tile_count | tile_flags | tile_start (+1) | tile_fill | counters
-    counters = tiles[4 * R * T + 1:]
+    # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | padding to a multiple of 16 bytes
+    tiles = torch.empty((4 * R * T + 8,), **i32)
+    counters = tiles[4 * R * T + 1:4 * R * T + 5]
     final_T = torch.empty((R * P,), **f32)
     n_contrib = torch.empty((2 * R * P,), **i32)
     image = torch.empty((S, V, 3, H, W), **f32)
@@ -191,8 +192,11 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
                          _ptr(view_scale))
     st = _state_struct(rec, radii, rect, tiles, None, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
-    if camera is not None and tiles.data_ptr() % 16 == 0 and (R * T) % 2 == 0:
-        _lib.check(lib.spf_decoder_prepare(C.byref(camera), _ptr(tiles), 8 * R * T, stream), "spf_decoder_prepare")
+    if camera is not None and tiles.data_ptr() % 16 == 0:
+        # camera set-up and the clearing of ALL the tile bookkeeping in one kernel (the scan then needs no single-block
+        # pass: see spf_tile_scan_render_kernel)
+        _lib.check(lib.spf_decoder_prepare(C.byref(camera), _ptr(tiles), 4 * tiles.numel(), stream),
+                   "spf_decoder_prepare")
         _lib.check(lib.spf_raster_forward_project_prepared(C.byref(dims), C.byref(inp), C.byref(st), stream),
                    "spf_raster_forward_project_prepared")
     else:
@@ -236,7 +240,7 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
                          _ptr(tiles[2 * RT:3 * RT + 1]),
                          _ptr(tiles[3 * RT + 1:4 * RT + 1]), _ptr(tiles[RT:2 * RT]),
-                         _ptr(tiles[4 * RT + 1:]), _ptr(pairs),
+                         _ptr(tiles[4 * RT + 1:4 * RT + 5]), _ptr(pairs),
                          _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib))
 
