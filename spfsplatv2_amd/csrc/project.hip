@@ -94,83 +94,71 @@ __device__ __forceinline__ void project_point(const float p[3], const float* __r
     o.det = o.a * o.c - o.b * o.b;
 }
 
-// SH basis (deg <= 4) for unit direction (x,y,z); optional derivatives (of the polynomials as written; the caller
-// projects them onto the tangent space of the unit sphere).
-template <int DEG, bool WITH_GRAD>
-__device__ __forceinline__ void sh_basis(float x, float y, float z, float* __restrict__ b,
-                                         float* __restrict__ dbx, float* __restrict__ dby,
-                                         float* __restrict__ dbz) {
-    b[0] = SH_C0;
-    if (WITH_GRAD) { dbx[0] = dby[0] = dbz[0] = 0.f; }
-    if (DEG > 0) {
-        b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
-        if (WITH_GRAD) {
-            dbx[1] = 0.f; dby[1] = -SH_C1; dbz[1] = 0.f;
-            dbx[2] = 0.f; dby[2] = 0.f; dbz[2] = SH_C1;
-            dbx[3] = -SH_C1; dby[3] = 0.f; dbz[3] = 0.f;
-        }
-    }
-    if (DEG > 1) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        b[4] = SH_C2[0] * xy; b[5] = SH_C2[1] * yz; b[6] = SH_C2[2] * (2.f * zz - xx - yy);
-        b[7] = SH_C2[3] * xz; b[8] = SH_C2[4] * (xx - yy);
-        if (WITH_GRAD) {
-            dbx[4] = SH_C2[0] * y; dby[4] = SH_C2[0] * x; dbz[4] = 0.f;
-            dbx[5] = 0.f; dby[5] = SH_C2[1] * z; dbz[5] = SH_C2[1] * y;
-            dbx[6] = SH_C2[2] * -2.f * x; dby[6] = SH_C2[2] * -2.f * y; dbz[6] = SH_C2[2] * 4.f * z;
-            dbx[7] = SH_C2[3] * z; dby[7] = 0.f; dbz[7] = SH_C2[3] * x;
-            dbx[8] = SH_C2[4] * 2.f * x; dby[8] = SH_C2[4] * -2.f * y; dbz[8] = 0.f;
-        }
-        if (DEG > 2) {
-            b[9] = SH_C3[0] * y * (3.f * xx - yy);
-            b[10] = SH_C3[1] * xy * z;
-            b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
-            b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-            b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
-            b[14] = SH_C3[5] * z * (xx - yy);
-            b[15] = SH_C3[6] * x * (xx - 3.f * yy);
-            if (WITH_GRAD) {
-                dbx[9] = SH_C3[0] * 6.f * xy; dby[9] = SH_C3[0] * (3.f * xx - 3.f * yy); dbz[9] = 0.f;
-                dbx[10] = SH_C3[1] * yz; dby[10] = SH_C3[1] * xz; dbz[10] = SH_C3[1] * xy;
-                dbx[11] = SH_C3[2] * -2.f * xy; dby[11] = SH_C3[2] * (4.f * zz - xx - 3.f * yy);
-                dbz[11] = SH_C3[2] * 8.f * yz;
-                dbx[12] = SH_C3[3] * -6.f * xz; dby[12] = SH_C3[3] * -6.f * yz;
-                dbz[12] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
-                dbx[13] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); dby[13] = SH_C3[4] * -2.f * xy;
-                dbz[13] = SH_C3[4] * 8.f * xz;
-                dbx[14] = SH_C3[5] * 2.f * xz; dby[14] = SH_C3[5] * -2.f * yz; dbz[14] = SH_C3[5] * (xx - yy);
-                dbx[15] = SH_C3[6] * (3.f * xx - 3.f * yy); dby[15] = SH_C3[6] * -6.f * xy; dbz[15] = 0.f;
-            }
-            if (DEG > 3) {
-                const float z7m1 = 7.f * zz - 1.f, z7m3 = 7.f * zz - 3.f, xmy = xx - yy;
-                b[16] = SH_C4[0] * xy * xmy;
-                b[17] = SH_C4[1] * yz * (3.f * xx - yy);
-                b[18] = SH_C4[2] * xy * z7m1;
-                b[19] = SH_C4[3] * yz * z7m3;
-                b[20] = SH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f);
-                b[21] = SH_C4[5] * xz * z7m3;
-                b[22] = SH_C4[6] * xmy * z7m1;
-                b[23] = SH_C4[7] * xz * (xx - 3.f * yy);
-                b[24] = SH_C4[8] * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
-                if (WITH_GRAD) {
-                    dbx[16] = SH_C4[0] * y * (3.f * xx - yy); dby[16] = SH_C4[0] * x * (xx - 3.f * yy); dbz[16] = 0.f;
-                    dbx[17] = SH_C4[1] * 6.f * xy * z; dby[17] = SH_C4[1] * z * (3.f * xx - 3.f * yy);
-                    dbz[17] = SH_C4[1] * y * (3.f * xx - yy);
-                    dbx[18] = SH_C4[2] * y * z7m1; dby[18] = SH_C4[2] * x * z7m1; dbz[18] = SH_C4[2] * 14.f * xy * z;
-                    dbx[19] = 0.f; dby[19] = SH_C4[3] * z * z7m3; dbz[19] = SH_C4[3] * y * (21.f * zz - 3.f);
-                    dbx[20] = 0.f; dby[20] = 0.f; dbz[20] = SH_C4[4] * z * (140.f * zz - 60.f);
-                    dbx[21] = SH_C4[5] * z * z7m3; dby[21] = 0.f; dbz[21] = SH_C4[5] * x * (21.f * zz - 3.f);
-                    dbx[22] = SH_C4[6] * 2.f * x * z7m1; dby[22] = SH_C4[6] * -2.f * y * z7m1;
-                    dbz[22] = SH_C4[6] * 14.f * z * xmy;
-                    dbx[23] = SH_C4[7] * z * (3.f * xx - 3.f * yy); dby[23] = SH_C4[7] * -6.f * xy * z;
-                    dbz[23] = SH_C4[7] * x * (xx - 3.f * yy);
-                    dbx[24] = SH_C4[8] * 4.f * x * (xx - 3.f * yy); dby[24] = SH_C4[8] * 4.f * y * (yy - 3.f * xx);
-                    dbz[24] = 0.f;
-                }
-            }
-        }
-    }
+// Real-SH basis function k (0..24; index n(n+1)+m, the 3DGS family's signs) at the unit direction d, optionally with
+// the partial derivatives of the polynomial as written (the caller projects them onto the tangent space of the unit
+// sphere).  `k` is a compile-time constant at every call site (fully unrolled loops), so the switch folds away; terms
+// are evaluated one at a time, right where they are consumed, instead of into 4 x 25-entry arrays -- the projection
+// backward with 16 / 25 coefficients was register-bound (300+ VGPRs, one wave per SIMD).
+struct ShDir {
+    float x, y, z, xx, yy, zz, xy, yz, xz;
+};
+__device__ __forceinline__ ShDir sh_dir(float x, float y, float z) {
+    return ShDir{x, y, z, x * x, y * y, z * z, x * y, y * z, x * z};
 }
+template <bool WITH_GRAD>
+__device__ __forceinline__ float sh_term(int k, const ShDir& d, float& gx, float& gy, float& gz) {
+    const float x = d.x, y = d.y, z = d.z, xx = d.xx, yy = d.yy, zz = d.zz, xy = d.xy, yz = d.yz, xz = d.xz;
+    float b = 0.f;
+    gx = gy = gz = 0.f;
+    switch (k) {
+        case 0: b = SH_C0; break;
+        case 1: b = -SH_C1 * y; if (WITH_GRAD) gy = -SH_C1; break;
+        case 2: b = SH_C1 * z; if (WITH_GRAD) gz = SH_C1; break;
+        case 3: b = -SH_C1 * x; if (WITH_GRAD) gx = -SH_C1; break;
+        case 4: b = SH_C2[0] * xy; if (WITH_GRAD) { gx = SH_C2[0] * y; gy = SH_C2[0] * x; } break;
+        case 5: b = SH_C2[1] * yz; if (WITH_GRAD) { gy = SH_C2[1] * z; gz = SH_C2[1] * y; } break;
+        case 6: b = SH_C2[2] * (2.f * zz - xx - yy);
+            if (WITH_GRAD) { gx = SH_C2[2] * -2.f * x; gy = SH_C2[2] * -2.f * y; gz = SH_C2[2] * 4.f * z; } break;
+        case 7: b = SH_C2[3] * xz; if (WITH_GRAD) { gx = SH_C2[3] * z; gz = SH_C2[3] * x; } break;
+        case 8: b = SH_C2[4] * (xx - yy); if (WITH_GRAD) { gx = SH_C2[4] * 2.f * x; gy = SH_C2[4] * -2.f * y; } break;
+        case 9: b = SH_C3[0] * y * (3.f * xx - yy);
+            if (WITH_GRAD) { gx = SH_C3[0] * 6.f * xy; gy = SH_C3[0] * (3.f * xx - 3.f * yy); } break;
+        case 10: b = SH_C3[1] * xy * z; if (WITH_GRAD) { gx = SH_C3[1] * yz; gy = SH_C3[1] * xz; gz = SH_C3[1] * xy; } break;
+        case 11: b = SH_C3[2] * y * (4.f * zz - xx - yy);
+            if (WITH_GRAD) { gx = SH_C3[2] * -2.f * xy; gy = SH_C3[2] * (4.f * zz - xx - 3.f * yy); gz = SH_C3[2] * 8.f * yz; } break;
+        case 12: b = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            if (WITH_GRAD) { gx = SH_C3[3] * -6.f * xz; gy = SH_C3[3] * -6.f * yz; gz = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy); } break;
+        case 13: b = SH_C3[4] * x * (4.f * zz - xx - yy);
+            if (WITH_GRAD) { gx = SH_C3[4] * (4.f * zz - 3.f * xx - yy); gy = SH_C3[4] * -2.f * xy; gz = SH_C3[4] * 8.f * xz; } break;
+        case 14: b = SH_C3[5] * z * (xx - yy);
+            if (WITH_GRAD) { gx = SH_C3[5] * 2.f * xz; gy = SH_C3[5] * -2.f * yz; gz = SH_C3[5] * (xx - yy); } break;
+        case 15: b = SH_C3[6] * x * (xx - 3.f * yy);
+            if (WITH_GRAD) { gx = SH_C3[6] * (3.f * xx - 3.f * yy); gy = SH_C3[6] * -6.f * xy; } break;
+        case 16: b = SH_C4[0] * xy * (xx - yy);
+            if (WITH_GRAD) { gx = SH_C4[0] * y * (3.f * xx - yy); gy = SH_C4[0] * x * (xx - 3.f * yy); } break;
+        case 17: b = SH_C4[1] * yz * (3.f * xx - yy);
+            if (WITH_GRAD) { gx = SH_C4[1] * 6.f * xy * z; gy = SH_C4[1] * z * (3.f * xx - 3.f * yy); gz = SH_C4[1] * y * (3.f * xx - yy); } break;
+        case 18: b = SH_C4[2] * xy * (7.f * zz - 1.f);
+            if (WITH_GRAD) { gx = SH_C4[2] * y * (7.f * zz - 1.f); gy = SH_C4[2] * x * (7.f * zz - 1.f); gz = SH_C4[2] * 14.f * xy * z; } break;
+        case 19: b = SH_C4[3] * yz * (7.f * zz - 3.f);
+            if (WITH_GRAD) { gy = SH_C4[3] * z * (7.f * zz - 3.f); gz = SH_C4[3] * y * (21.f * zz - 3.f); } break;
+        case 20: b = SH_C4[4] * (zz * (35.f * zz - 30.f) + 3.f); if (WITH_GRAD) gz = SH_C4[4] * z * (140.f * zz - 60.f); break;
+        case 21: b = SH_C4[5] * xz * (7.f * zz - 3.f);
+            if (WITH_GRAD) { gx = SH_C4[5] * z * (7.f * zz - 3.f); gz = SH_C4[5] * x * (21.f * zz - 3.f); } break;
+        case 22: b = SH_C4[6] * (xx - yy) * (7.f * zz - 1.f);
+            if (WITH_GRAD) { gx = SH_C4[6] * 2.f * x * (7.f * zz - 1.f); gy = SH_C4[6] * -2.f * y * (7.f * zz - 1.f); gz = SH_C4[6] * 14.f * z * (xx - yy); } break;
+        case 23: b = SH_C4[7] * xz * (xx - 3.f * yy);
+            if (WITH_GRAD) { gx = SH_C4[7] * z * (3.f * xx - 3.f * yy); gy = SH_C4[7] * -6.f * xy * z; gz = SH_C4[7] * x * (xx - 3.f * yy); } break;
+        case 24: b = SH_C4[8] * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+            if (WITH_GRAD) { gx = SH_C4[8] * 4.f * x * (xx - 3.f * yy); gy = SH_C4[8] * 4.f * y * (yy - 3.f * xx); } break;
+        default: break;
+    }
+    return b;
+}
+// which partial derivatives of term k are structurally zero (so that no `0 * coefficient` is ever issued)
+__device__ __forceinline__ constexpr bool sh_has_gx(int k) { return k != 0 && k != 1 && k != 2 && k != 5 && k != 19 && k != 20; }
+__device__ __forceinline__ constexpr bool sh_has_gy(int k) { return k != 0 && k != 2 && k != 3 && k != 7 && k != 20 && k != 21; }
+__device__ __forceinline__ constexpr bool sh_has_gz(int k) { return k != 0 && k != 1 && k != 3 && k != 4 && k != 8 && k != 9 && k != 15 && k != 16 && k != 24; }
 
 // SH coefficient block of one Gaussian: K coefficients per channel, stored [K,3] (layout 0) or [3,K] (layout 1).
 // Coefficients are consumed four at a time through three 16-byte accesses (any layout), the remaining NB % 4 one by
@@ -226,44 +214,103 @@ __device__ __forceinline__ float sh_at(const float* __restrict__ sh, int K, int 
     return NATIVE ? sh[c * K + k] : sh[3 * k + c];
 }
 
-// colour = sum_k basis_k sh_k (forward), optionally with D{x,y,z}[c] = sum_k dbasis_k/d{x,y,z} sh_k[c] (backward)
+// colour = sum_k basis_k sh_k (forward), optionally with D{x,y,z}[c] = sum_k dbasis_k/d{x,y,z} sh_k[c] (backward).
+// The forward and the backward both come through here, so they take the same clamp decisions on the colour.
+template <bool WITH_GRAD>
+__device__ __forceinline__ void sh_accumulate(int k, const ShDir& dir, const float v[3], float col[3], float Dx[3],
+                                              float Dy[3], float Dz[3]) {
+    float gx, gy, gz;
+    const float b = sh_term<WITH_GRAD>(k, dir, gx, gy, gz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        col[c] += b * v[c];
+        if (WITH_GRAD) {
+            if (sh_has_gx(k)) Dx[c] += gx * v[c];
+            if (sh_has_gy(k)) Dy[c] += gy * v[c];
+            if (sh_has_gz(k)) Dz[c] += gz * v[c];
+        }
+    }
+}
 template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD>
-__device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const float* basis,
-                                            const float* dbx, const float* dby, const float* dbz, float col[3],
+__device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const ShDir& dir, float col[3],
                                             float Dx[3], float Dy[3], float Dz[3]) {
     constexpr int NV = NB / 4;
+    if (NV <= 1) {
 #pragma unroll
-    for (int k4 = 0; k4 < NV; ++k4) {
-        float v[4][3];
-        sh_load4<NATIVE, ALIGNED>(sh, K, k4, v);
+        for (int k4 = 0; k4 < NV; ++k4) {
+            float v[4][3];
+            sh_load4<NATIVE, ALIGNED>(sh, K, k4, v);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[i], col, Dx, Dy, Dz);
+        }
+    } else {
+        // Groups of four coefficients, double-buffered by hand: group k4+1 is in flight while group k4 is consumed, and
+        // a compiler barrier after every group keeps the scheduler from hoisting ALL the loads to the top (which costs
+        // 3*NB live registers -- with 16 / 25 coefficients that alone pushed the backward to one wave per SIMD).
+        float v[2][4][3];
+        sh_load4<NATIVE, ALIGNED>(sh, K, 0, v[0]);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int k = 4 * k4 + i;
-                col[c] += basis[k] * v[i][c];
-                if (WITH_GRAD) { Dx[c] += dbx[k] * v[i][c]; Dy[c] += dby[k] * v[i][c]; Dz[c] += dbz[k] * v[i][c]; }
-            }
+        for (int k4 = 0; k4 < NV; ++k4) {
+            if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, K, k4 + 1, v[(k4 + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[k4 & 1][i], col, Dx, Dy, Dz);
+            asm volatile("" ::: "memory");
+        }
     }
 #pragma unroll
-    for (int k = 4 * NV; k < NB; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = sh_at<NATIVE>(sh, K, k, c);
-            col[c] += basis[k] * v;
-            if (WITH_GRAD) { Dx[c] += dbx[k] * v; Dy[c] += dby[k] * v; Dz[c] += dbz[k] * v; }
-        }
+    for (int k = 4 * NV; k < NB; ++k) {
+        const float v[3] = {sh_at<NATIVE>(sh, K, k, 0), sh_at<NATIVE>(sh, K, k, 1), sh_at<NATIVE>(sh, K, k, 2)};
+        sh_accumulate<WITH_GRAD>(k, dir, v, col, Dx, Dy, Dz);
+    }
 }
-// dL/dsh of the NB evaluated coefficients, zeros for the K - NB that are only carried
+// dL/dsh_k = sum over the parked views of basis_k(direction_v) * dL/dcolour_v: evaluated group by group at the END of
+// the view loop from six floats per view that every thread parks in LDS for itself (unit direction, colour gradient
+// with clamped channels already zeroed) -- instead of 3*NB accumulator registers carried through the whole loop.
+// park[(6 * v + j) * kBlock + tid]; `first`: store, otherwise add to what an earlier chunk of views stored.
 template <int NB, bool NATIVE, bool ALIGNED>
-__device__ __forceinline__ void sh_store_grad(float* __restrict__ o, int K, const float (*dsh)[3]) {
+__device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K, const float* __restrict__ park,
+                                                    int nviews, bool first) {
     constexpr int NV = NB / 4;
-#pragma unroll
-    for (int k4 = 0; k4 < NV; ++k4) sh_store4<NATIVE, ALIGNED>(o, K, k4, &dsh[4 * k4]);
     const int sk = NATIVE ? 1 : 3, sc = NATIVE ? K : 1;
+    auto group = [&](int k0, int n, float (&acc)[4][3]) {
 #pragma unroll
-    for (int k = 4 * NV; k < NB; ++k) { o[sk * k] = dsh[k][0]; o[sk * k + sc] = dsh[k][1]; o[sk * k + 2 * sc] = dsh[k][2]; }
-    if (K > NB) {
+        for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = acc[i][2] = 0.f;
+        for (int v = 0; v < nviews; ++v) {
+            const float* __restrict__ pv = park + (size_t)(6 * v) * kBlock;
+            const ShDir dir = sh_dir(pv[0], pv[kBlock], pv[2 * kBlock]);
+            const float g[3] = {pv[3 * kBlock], pv[4 * kBlock], pv[5 * kBlock]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n) {
+                    float gx, gy, gz;
+                    const float b = sh_term<false>(k0 + i, dir, gx, gy, gz);
+                    acc[i][0] += b * g[0]; acc[i][1] += b * g[1]; acc[i][2] += b * g[2];
+                }
+        }
+    };
+#pragma unroll
+    for (int k4 = 0; k4 < NV; ++k4) {
+        float acc[4][3];
+        group(4 * k4, 4, acc);
+        if (!first) {
+            float old[4][3];
+            sh_load4<NATIVE, ALIGNED>(o, K, k4, old);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { acc[i][0] += old[i][0]; acc[i][1] += old[i][1]; acc[i][2] += old[i][2]; }
+        }
+        sh_store4<NATIVE, ALIGNED>(o, K, k4, acc);
+    }
+    if (NB % 4 != 0) {
+        float acc[4][3];
+        group(4 * NV, NB % 4, acc);
+#pragma unroll
+        for (int i = 0; i < NB % 4; ++i) {
+            const int k = 4 * NV + i;
+            if (!first) { acc[i][0] += o[sk * k]; acc[i][1] += o[sk * k + sc]; acc[i][2] += o[sk * k + 2 * sc]; }
+            o[sk * k] = acc[i][0]; o[sk * k + sc] = acc[i][1]; o[sk * k + 2 * sc] = acc[i][2];
+        }
+    }
+    if (first && K > NB) {     // coefficients that are carried but not evaluated: zero gradient
         if (NATIVE) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) zero_floats(o + c * K + NB, K - NB);
@@ -369,13 +416,11 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 for (int j = 0; j < 3; ++j)
                     dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
                 const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-                float basis[NB];
-                sh_basis<(DEG < 0 ? 0 : DEG), false>(dir[0] * inv, dir[1] * inv, dir[2] * inv, basis, nullptr,
-                                                     nullptr, nullptr);
+                const ShDir sd = sh_dir(dir[0] * inv, dir[1] * inv, dir[2] * inv);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
                 col[0] = col[1] = col[2] = 0.f;
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, basis, nullptr, nullptr, nullptr, col, nullptr, nullptr, nullptr);
-                else sh_contract<NB, NATIVE, false, false>(sh, d.K, basis, nullptr, nullptr, nullptr, col, nullptr, nullptr, nullptr);
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -457,9 +502,12 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
 // vpartial[r][block][12] (no float atomics -> deterministic), summed by spf_view_reduce_kernel.
 // ------------------------------------------------------------------------------------------
 constexpr int kViewChunk = 64;
+constexpr int kShChunk = 8;      // views parked per thread before their SH gradient is formed (6 floats each, in LDS)
 
+// (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
+// the SH section -- 300+ VGPRs, one wave per SIMD; asking for two blocks per CU caps it at 256 VGPRs)
 template <int DEG, bool NATIVE>
-__global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+__global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
     (void)capacity;
     const int g = blockIdx.x * kBlock + threadIdx.x;
@@ -503,12 +551,17 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
                                              // xx, xy(+yx), xz(+zx), yy, yz(+zy), zz
     float dopac = 0.f;
     float dcol[3] = {0.f, 0.f, 0.f};        // colours given directly
-    float dsh[NB][3];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
 
     extern __shared__ float s_part[];        // [min(V, kViewChunk)][4 waves][12]: viewmatrix partials of a chunk of views
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // SH only: six floats per view that every thread parks for ITSELF (no barrier): see sh_grad_from_parked
+    float* __restrict__ s_park = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + threadIdx.x;
+    constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
+    const bool want_dsh = DEG >= 0 && gr.dL_dshs != nullptr;
+    float* __restrict__ dsh_out = want_dsh ? gr.dL_dshs + sg * (size_t)d.K * 3 : nullptr;
+    float dsh[kPark ? 1 : NB][3];
+#pragma unroll
+    for (int k = 0; k < (kPark ? 1 : NB); ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
 
     // Software pipeline over the views.  A view's gradient records hang off two dependent global reads (rect /
     // pair_off -> records); issued inside the view they cost two memory round trips per view with three waves per SIMD to
@@ -557,6 +610,7 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             q0 = *reinterpret_cast<const f4u*>(gp); q1 = *reinterpret_cast<const f4u*>(gp + 4); q8 = gp[8];
             if (gs == 10) q9 = gp[9];
         }
+        float sh_x = 0.f, sh_y = 0.f, sh_z = 1.f, sh_g0 = 0.f, sh_g1 = 0.f, sh_g2 = 0.f;   // parked below (SH only)
         if (vis) {
             // the rest of this Gaussian's (Gaussian, tile) pairs: their screen-space gradient records add up
             {
@@ -582,6 +636,55 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             if (gr.dL_dmeans2D) {
                 float* m2 = gr.dL_dmeans2D + rg * 3;
                 m2[0] = gx * 0.5f * d.W; m2[1] = gy * 0.5f * d.H; m2[2] = 0.f;
+            }
+            // ---- colour (first: while the SH working set is live none of the projection state below is yet) ----
+            if (DEG < 0) {
+                dcol[0] += gcol[0]; dcol[1] += gcol[1]; dcol[2] += gcol[2];
+            } else {
+                float vdir[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    vdir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
+                const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
+                const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
+                const ShDir sd = sh_dir(x, y, z);
+                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                // One pass over the coefficient block: re-evaluate the colour exactly as the forward kernel does
+                // (colours clamped at 0 pass no gradient; cheaper than re-reading the 48-byte record) and collect
+                // s_k = sh_k . dL/dcolour for the direction gradient.
+                float col[3] = {0.f, 0.f, 0.f};
+                float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};  // sum_k dbasis_k sh_k[c]
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, (DEG > 0)>(sh, d.K, sd, col, Dx, Dy, Dz);
+                else sh_contract<NB, NATIVE, false, (DEG > 0)>(sh, d.K, sd, col, Dx, Dy, Dz);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
+                sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
+                if (!kPark) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        float t0, t1, t2;
+                        const float bk = sh_term<false>(k, sd, t0, t1, t2);
+                        dsh[k][0] += bk * gcol[0]; dsh[k][1] += bk * gcol[1]; dsh[k][2] += bk * gcol[2];
+                    }
+                }
+                const float dd[3] = {Dx[0] * gcol[0] + Dx[1] * gcol[1] + Dx[2] * gcol[2],
+                                     Dy[0] * gcol[0] + Dy[1] * gcol[1] + Dy[2] * gcol[2],
+                                     Dz[0] * gcol[0] + Dz[1] * gcol[1] + Dz[2] * gcol[2]};
+                if (DEG > 0) {
+                    const float dot = dd[0] * x + dd[1] * y + dd[2] * z;
+                    float dv[3] = {(dd[0] - x * dot) * inv, (dd[1] - y * dot) * inv, (dd[2] - z * dot) * inv};
+                    // v = p - c, c_j = -sum_i tvec_i Vm[4j+i]  ->  v_j = p_j + sum_i tvec_i Vm[4j+i]
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        dp[j] += dv[j];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            dV[9 + i] += dv[j] * Vm[4 * j + i];    // d/dtvec_i
+                            dV[3 * j + i] += dv[j] * Vm[12 + i];   // d/dVm[4j+i]
+                        }
+                    }
+                }
             }
             Proj pr;
             project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
@@ -642,53 +745,6 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
                 dt[2] += -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.f * fx * pr.tcx * itz3 * dJ02 +
                          2.f * fy * pr.tcy * itz3 * dJ12;
             }
-            // ---- colour ----
-            if (DEG < 0) {
-                dcol[0] += gcol[0]; dcol[1] += gcol[1]; dcol[2] += gcol[2];
-            } else {
-                float vdir[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    vdir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
-                const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
-                const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
-                float basis[NB], dbx[NB], dby[NB], dbz[NB];
-                sh_basis<(DEG < 0 ? 0 : DEG), true>(x, y, z, basis, dbx, dby, dbz);
-                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
-                // One pass over the coefficient block: re-evaluate the colour exactly as the forward kernel does
-                // (colours clamped at 0 pass no gradient; cheaper than re-reading the 48-byte record) and collect
-                // s_k = sh_k . dL/dcolour for the direction gradient.
-                float col[3] = {0.f, 0.f, 0.f};
-                float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};  // sum_k dbasis_k sh_k[c]
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, (DEG > 0)>(sh, d.K, basis, dbx, dby, dbz, col, Dx, Dy, Dz);
-                else sh_contract<NB, NATIVE, false, (DEG > 0)>(sh, d.K, basis, dbx, dby, dbz, col, Dx, Dy, Dz);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    dsh[k][0] += basis[k] * gcol[0];
-                    dsh[k][1] += basis[k] * gcol[1];
-                    dsh[k][2] += basis[k] * gcol[2];
-                }
-                const float dd[3] = {Dx[0] * gcol[0] + Dx[1] * gcol[1] + Dx[2] * gcol[2],
-                                     Dy[0] * gcol[0] + Dy[1] * gcol[1] + Dy[2] * gcol[2],
-                                     Dz[0] * gcol[0] + Dz[1] * gcol[1] + Dz[2] * gcol[2]};
-                if (DEG > 0) {
-                    const float dot = dd[0] * x + dd[1] * y + dd[2] * z;
-                    float dv[3] = {(dd[0] - x * dot) * inv, (dd[1] - y * dot) * inv, (dd[2] - z * dot) * inv};
-                    // v = p - c, c_j = -sum_i tvec_i Vm[4j+i]  ->  v_j = p_j + sum_i tvec_i Vm[4j+i]
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        dp[j] += dv[j];
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            dV[9 + i] += dv[j] * Vm[4 * j + i];    // d/dtvec_i
-                            dV[3 * j + i] += dv[j] * Vm[12 + i];   // d/dVm[4j+i]
-                        }
-                    }
-                }
-            }
             // ---- t = p R + tvec ----
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -701,6 +757,19 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
             for (int i = 0; i < 3; ++i) dp0[i] += sc * dp[i];
 #pragma unroll
             for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
+        }
+        if (kPark && want_dsh) {
+            // park this view's direction and colour gradient (zeros when the Gaussian is not visible in it); every
+            // kShChunk views -- normally once, after the loop -- turn the parked views into dL/dsh
+            float* __restrict__ pk = s_park + (size_t)(6 * (v % kShChunk)) * kBlock;
+            pk[0] = sh_x; pk[kBlock] = sh_y; pk[2 * kBlock] = sh_z;
+            pk[3 * kBlock] = sh_g0; pk[4 * kBlock] = sh_g1; pk[5 * kBlock] = sh_g2;
+            if (live && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
+                const int nv = v % kShChunk + 1;
+                const bool first = v < kShChunk;
+                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, d.K, s_park, nv, first);
+                else sh_grad_from_parked<NB, NATIVE, false>(dsh_out, d.K, s_park, nv, first);
+            }
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
         if (gr.vpartial && SPF_PABL != 6) {
@@ -733,10 +802,19 @@ __global__ __launch_bounds__(kBlock, SPF_PBWD_BPC) void spf_project_bwd_kernel(S
         if (gr.dL_dcolors) {
             gr.dL_dcolors[3 * sg] = dcol[0]; gr.dL_dcolors[3 * sg + 1] = dcol[1]; gr.dL_dcolors[3 * sg + 2] = dcol[2];
         }
-    } else if (gr.dL_dshs) {
-        float* __restrict__ o = gr.dL_dshs + sg * (size_t)d.K * 3;
-        if (d.K % 4 == 0) sh_store_grad<NB, NATIVE, true>(o, d.K, dsh);
-        else sh_store_grad<NB, NATIVE, false>(o, d.K, dsh);
+    } else if (!kPark && want_dsh) {
+        const int sk = NATIVE ? 1 : 3, sc = NATIVE ? d.K : 1;
+#pragma unroll
+        for (int k = 0; k < (kPark ? 0 : NB); ++k) {
+            dsh_out[sk * k] = dsh[k][0]; dsh_out[sk * k + sc] = dsh[k][1]; dsh_out[sk * k + 2 * sc] = dsh[k][2];
+        }
+        if (d.K > NB) {
+            if (NATIVE) {
+                for (int c = 0; c < 3; ++c) zero_floats(dsh_out + c * d.K + NB, d.K - NB);
+            } else {
+                zero_floats(dsh_out + 3 * NB, 3 * (d.K - NB));
+            }
+        }
     }
     if (gr.dL_dscales && gr.dL_drotations) {
         // Sigma = Rm diag(s^2) Rm^T.  G = symmetric gradient matrix with G_ij = dL/dSigma_ij (full partials).
@@ -813,8 +891,9 @@ static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDim
 template <int DEG, bool NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
                           const SpfGrads& g, int nblk, uint64_t capacity) {
-    spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float), stream>>>(d, in, st, g,
-                                                                                                          nblk, capacity);
+    size_t lds = (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float);
+    if (DEG >= 2 && g.dL_dshs) lds += (size_t)(d.V < kShChunk ? d.V : kShChunk) * 6 * kBlock * sizeof(float);
+    spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), lds, stream>>>(d, in, st, g, nblk, capacity);
 }
 #define SPF_DISPATCH_DEG(FN, ...)                                        \
     switch (deg * 2 + (native ? 1 : 0)) {                                \
