@@ -262,8 +262,20 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
 constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
-__device__ __forceinline__ float lists_power2(float dx, float dy, float A, float B, float C) {
-    return fmaf(dx, fmaf(A, dx, B * dy), (C * dy) * dy);
+// Packed form: the lists kernels stage (x, y | A', C') in one 16-byte LDS record, so the pixel offset is one
+// v_pk_add_f32 and (A' dx, C' dy) one v_pk_mul_f32; then exponent = dx * (A' dx + B' dy) + (C' dy) * dy.
+__device__ __forceinline__ float lists_power2(const float4& p0, float Bs, v2f fxy, v2f& dxy) {
+    dxy = v2f{p0.x, p0.y} - fxy;
+    const v2f u = v2f{p0.z, p0.w} * dxy;                      // (A' dx, C' dy)
+    return fmaf(dxy.x, fmaf(Bs, dxy.y, u.x), u.y * dxy.y);
+}
+// The same expression tree with scalar instructions -- bit-identical results (the backward replay must take the
+// forward's hit decisions), for the backward kernel, where the even-aligned register pairs of the packed form cost more
+// moves than they save (measured: +8 us).
+__device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs, float fx, float fy) {
+    const float dx = p0.x - fx, dy = p0.y - fy;
+    const float ux = p0.z * dx, uy = p0.w * dy;
+    return fmaf(dx, fmaf(Bs, dy, ux), uy * dy);
 }
 
 __device__ __forceinline__ void scatter_footprint(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2,
@@ -314,9 +326,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
     int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;   // (the top bits carry the ablation code of profiling builds)
-    __shared__ float4 s_p0[kStage];   // x, y, A, B
-    __shared__ float4 s_p1[kStage];   // C, opacity, cull r^2, depth
-    __shared__ float4 s_p2[kStage];   // r, g, b, -
+    __shared__ float4 s_p0[kStage];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
+    __shared__ float4 s_p1[kStage];   // B', opacity, cull r^2, -
+    __shared__ float4 s_p2[kStage];   // r, g | b, depth
     __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
 
     (void)capacity;
@@ -335,8 +347,10 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
+    const v2f fxy = {fx, fy};
 
-    float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float Tr = 1.0f;
+    v2f c01 = {0.f, 0.f}, c2d = {0.f, 0.f};      // (r, g), (b, depth) accumulators
     uint32_t last = 0, hits = 0;
     bool done = !inside;
     bool wave_done = __ballot(!done) == 0;
@@ -352,9 +366,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             if (ABLATE(11)) gid = (uint32_t)tid;                             // (profiling: always the same 12 KB)
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
-            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, b.w, b.z);
-            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, 0.f);
+            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
+            s_p1[tid] = make_float4(kLog2e * a.w, b.y, b.w, 0.f);
+            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
             gx = a.x; gy = a.y; r2 = b.w;
         }
         __syncthreads();
@@ -378,14 +392,17 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 return w * 32 + bit;
             };
             auto composite = [&](bool has, int j, const float4& p0, const float4& p1, const float4& p2) {
-                const float pw = lists_power2(p0.x - fx, p0.y - fy, p0.z, p0.w, p1.x);
+                v2f dxy;
+                const float pw = lists_power2(p0, p1.x, fxy, dxy);
                 const float alpha = fminf(kAlphaMax, p1.y * __builtin_amdgcn_exp2f(pw));
                 const bool hit = has && !done && pw <= 0.f && alpha >= kAlphaMin;
                 const float test_T = Tr * (1.f - alpha);
                 const bool stop = hit && test_T < kTMin;
                 const bool take = hit && !stop;
                 const float wgt = take ? alpha * Tr : 0.f;
-                C0 = fmaf(p2.x, wgt, C0); C1 = fmaf(p2.y, wgt, C1); C2 = fmaf(p2.z, wgt, C2); Dp = fmaf(p1.w, wgt, Dp);
+                const v2f ww = {wgt, wgt};
+                c01 = __builtin_elementwise_fma(v2f{p2.x, p2.y}, ww, c01);      // two v_pk_fma_f32 for (r, g | b, depth)
+                c2d = __builtin_elementwise_fma(v2f{p2.z, p2.w}, ww, c2d);
                 Tr = take ? test_T : Tr;
                 last = take ? base + (uint32_t)j + 1u : last;
                 hits += take ? 1u : 0u;
@@ -414,10 +431,10 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         const float* __restrict__ bg = bg_all + 3 * r;
         const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
         float* __restrict__ img = image + (size_t)r * 3 * P;
-        img[pix] = C0 + Tr * bg[0];
-        img[P + pix] = C1 + Tr * bg[1];
-        img[2 * P + pix] = C2 + Tr * bg[2];
-        depth_out[(size_t)r * P + pix] = Dp;
+        img[pix] = c01.x + Tr * bg[0];
+        img[P + pix] = c01.y + Tr * bg[1];
+        img[2 * P + pix] = c2d.x + Tr * bg[2];
+        depth_out[(size_t)r * P + pix] = c2d.y;
         alpha_out[(size_t)r * P + pix] = 1.0f - Tr;
         final_T[(size_t)r * P + pix] = Tr;
         reinterpret_cast<uint2*>(n_contrib)[(size_t)r * P + pix] = make_uint2(last, hits);
@@ -666,8 +683,8 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     (void)capacity;
     if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;
-    __shared__ float4 s_p0[kRoundL];                 // x, y, A, B
-    __shared__ float4 s_p1[kRoundL];                 // C, opacity, cull r^2, depth
+    __shared__ float4 s_p0[kRoundL];                 // x, y | A', C'   (as in the forward)
+    __shared__ float4 s_p1[kRoundL];                 // B', opacity, box width (int), depth
     __shared__ float4 s_p2[kRoundL];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
     __shared__ __attribute__((aligned(16))) uint32_t s_pm[kRoundL / 32][kBlock];  // [32-entry word][pixel]: candidate bits
     __shared__ float2 s_pool[kPool];                // (w, u) slots of this round's entries
@@ -790,10 +807,10 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         const uint64_t accb = __ballot(acc);
         if (lane == 0) s_wacc[wave] = (uint32_t)__popcll(accb);
         if (acc) {
-            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kLog2e * a.w);
+            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
             // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + bw*ly + lx: the box width
             // and the (signed) bracket travel as integers in the two fields phase B has no other use for
-            s_p1[tid] = make_float4(kHalfLog2e * b.x, b.y, __int_as_float(bw), b.z);
+            s_p1[tid] = make_float4(kLog2e * a.w, b.y, __int_as_float(bw), b.z);
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, __int_as_float((int)off - yl * bw - xl));
         }
 #pragma unroll
@@ -834,7 +851,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                 return w * 32 + bit;
             };
             auto replay = [&](bool has, const float4& p0, const float4& p1, const float4& p2) {
-                const float pw = lists_power2(p0.x - fx, p0.y - fy, p0.z, p0.w, p1.x);
+                const float pw = lists_power2_scalar(p0, p1.x, fx, fy);
                 const float Gv = __builtin_amdgcn_exp2f(pw);
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
                 if (has && pw <= 0.f && alpha >= kAlphaMin) {
