@@ -143,6 +143,11 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="capture one whole step (decoder fwd + loss + bwd) in a HIP graph and replay it "
                          "(implies --sync-free)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="N > 1: the per-GPU batch is split by scene into N micro-batches, each captured in its own HIP "
+                         "graph and replayed on its own stream, so that the latency-bound stages of one micro-batch "
+                         "(projection, binning, sort) run under the VALU-bound compositing of another (implies --graph; "
+                         "same renders, same loss -- each micro-batch weighs 1/N --, same backward)")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -243,23 +248,46 @@ def main():
     h, w = b.image_shape
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
-    leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in names}
     bg = torch.zeros(3, device=dev)
     one = torch.ones((), device=dev)
-    max_pairs = None
+    if args.streams > 1:
+        if S % args.streams or args.allreduce:
+            sys.exit("bench.py: --streams N needs a scene count divisible by N (and is not combined with --allreduce)")
+        args.graph = True
+
+    class MicroBatch:
+        """Scenes [s0, s1) of the resident batch: own leaves, own call record / pair budget, own loss share."""
+
+        def __init__(self, s0, s1):
+            self.sl = slice(s0, s1)
+            self.leaves = {n: getattr(b, n)[self.sl].clone().requires_grad_(True) for n in names}
+            self.weight = (s1 - s0) / S
+            self.record = spf.CallRecord()
+            self.max_pairs = None
+
+        def step(self):
+            L, sl = self.leaves, self.sl
+            for t in L.values():
+                t.grad = None
+            color, depth, _alpha = spf.render_views(
+                L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
+                L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
+                enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record)
+            if args.torch_loss:
+                loss = torch.nn.functional.mse_loss(color, b.target[sl]) * self.weight
+            else:
+                loss = spf.mse_loss(color, b.target[sl], self.weight)
+            loss.backward(gradient=one)          # (a cached dL/dloss = 1 saves autograd's fill kernel)
+            if args.allreduce:
+                shard.allreduce_gaussian_grads([L[n].grad for n in names[:5]])
+            return loss
+
+    per = S // args.streams
+    micro = [MicroBatch(i * per, (i + 1) * per) for i in range(args.streams)]
 
     def step():
-        for t in leaves.values():
-            t.grad = None
-        color, depth, _alpha = spf.render_views(
-            leaves["extrinsics"], b.intrinsics, b.near, b.far, (h, w), bg, leaves["means"], leaves["harmonics"],
-            leaves["opacities"], leaves["rotations"], leaves["scales"], scale_invariant=True,
-            enable_cov_grad=True, enable_sh_grad=True, max_pairs=max_pairs)
-        loss = (torch.nn.functional.mse_loss if args.torch_loss else spf.mse_loss)(color, b.target)
-        loss.backward(gradient=one)          # (a cached dL/dloss = 1 saves autograd's fill kernel)
-        if args.allreduce:
-            shard.allreduce_gaussian_grads([leaves[n].grad for n in names[:5]])
-        return loss
+        for m in micro:
+            m.step()
 
     def barrier():
         if world > 1:
@@ -276,29 +304,42 @@ def main():
     log(f"batch resident: {S} scenes x {V} views, G={G}, K={K}, {h}x{w}")
     step()
     torch.cuda.synchronize(dev)
-    D_total = spf.last_forward_stats()["num_pairs"]
-    log(f"first step done: D={D_total}, max tile list={spf.last_forward_stats()['max_tile_list']}")
+    D_total = sum(m.record["num_pairs"] for m in micro)
+    log(f"first step done: D={D_total}, max tile list={max(m.record['max_tile_list'] for m in micro)}")
     if not args.exact or args.graph:
-        max_pairs = spf.plan_pair_budget(slack=1.25, check="deferred")
-        log(f"planned budget: {max_pairs}")
+        for m in micro:
+            m.max_pairs = spf.plan_pair_budget(m.record, slack=1.25, check="deferred")
+        log(f"planned budget: {micro[0].max_pairs}" + (f" x {len(micro)} micro-batches" if len(micro) > 1 else ""))
+    max_pairs = micro[0].max_pairs
     run = step
     eager_survey = None
     if args.graph:
         # per-stage survey and dominant-kernel timing need eager launches (events are recorded at launch time,
-        # a replayed graph launches nothing from the host)
+        # a replayed graph launches nothing from the host); with --streams the surveyed launches are one
+        # micro-batch's, timed exclusively (in the timed region the kernels of the streams overlap)
         _lib.stage_timing_enable(True)
         for _ in range(max(args.warmup, 3)):
-            step()
+            micro[0].step()
         torch.cuda.synchronize(dev)
         eager_survey = {k: (v[0] / v[1], 1) for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
         _lib.stage_timing_enable(False)
-        for t in leaves.values():
-            t.grad = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
-        run = graph.replay
-        log("step captured in a HIP graph")
+        streams = [torch.cuda.Stream(dev) for _ in micro] if len(micro) > 1 else [torch.cuda.current_stream(dev)]
+        graphs = []
+        for m, st_ in zip(micro, streams):
+            for t in m.leaves.values():
+                t.grad = None
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, **({"stream": st_} if len(micro) > 1 else {})):
+                m.step()
+            graphs.append(g_)
+        if len(micro) == 1:
+            run = graphs[0].replay
+        else:
+            def run():
+                for g_, st_ in zip(graphs, streams):
+                    with torch.cuda.stream(st_):
+                        g_.replay()
+        log(f"step captured in {len(graphs)} HIP graph(s)")
     # warm-up doubles as the per-stage survey (HIP events around every stage); the timed region then keeps
     # events only around the dominant kernel, so the headline number is not diluted by 14 event records/step
     _lib.stage_timing_enable(True)
@@ -332,8 +373,9 @@ def main():
     stages = _lib.stage_times()
     _lib.stage_timing_enable(False)
     _lib.stage_timing_sample_every(1)
-    if max_pairs is not None and spf.last_plan_flags() != 0:
-        raise RuntimeError(f"the planned pair budget did not hold (flags {spf.last_plan_flags()}): results invalid")
+    if max_pairs is not None and any(spf.plan_flags(m.record) != 0 for m in micro):
+        raise RuntimeError(f"the planned pair budget did not hold (flags "
+                           f"{[spf.plan_flags(m.record) for m in micro]}): results invalid")
     trials = max_over_ranks(trials)                       # per trial: the slowest rank
     dt = sorted(trials)[len(trials) // 2]                 # median trial
     log(f"timed region: {n_trials} trials x {args.steps} steps = {sum(trials):.3f} s; median trial {dt * 1e3:.3f} ms, "
@@ -344,11 +386,13 @@ def main():
         renders = world * S * V
         value = renders * P * args.steps / dt / 1e6
         dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1]
-        dom_bytes = stage_bytes(dom, S, V, G, K, P, D_total)
+        # (with --streams the surveyed launch is one micro-batch's: its share of the scenes and pairs)
+        dom_bytes = stage_bytes(dom, S // len(micro), V, G, K, P, D_total // len(micro))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "pmc_summary.json"
-        default_workload = (args.config == "C2" and S == 8 and V == 4 and args.s_mult == 1.0 and not args.allreduce)
+        default_workload = (args.config == "C2" and S == 8 and V == 4 and args.s_mult == 1.0 and not args.allreduce
+                            and len(micro) == 1)
         kernel = _lib.stage_kernel_name(dom)
         if prof.exists() and default_workload:      # the PMC passes were collected on exactly this workload
             try:
@@ -371,7 +415,10 @@ def main():
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
                        "s_mult": args.s_mult, "pair_buffer": "exact (read-back per step)" if max_pairs is None else
                                       f"planned from step 0 (x1.25 = {max_pairs.capacity} pairs), verified on device",
-                       "launch": "hip-graph replay" if args.graph else "eager",
+                       "launch": (f"{len(micro)} micro-batches of {S // len(micro)} scenes, one HIP graph and one stream "
+                                  "each (kernels of the streams overlap; roofline durations are exclusive, from an "
+                                  "eager survey of one micro-batch)" if len(micro) > 1 else
+                                  "hip-graph replay" if args.graph else "eager"),
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},
             "timing": {"trials": n_trials, "statistic": "median trial; each trial = exactly `steps` steps between "
