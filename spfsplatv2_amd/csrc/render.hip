@@ -355,9 +355,13 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     bool done = !inside;
     bool wave_done = __ballot(!done) == 0;
 
+    // (candidate words: every thread keeps ITS pixel's column clear -- before the first round here, afterwards right
+    // after it has consumed it -- so that staging and scatter of a round need no barrier between them)
+#pragma unroll
+    for (int w = 0; w < kStage / 32; ++w) s_pm[w][tid] = 0u;
+    __syncthreads();
     for (uint32_t base = 0; base < n; base += kStage) {
         const int nw = (int)((min((uint32_t)kStage, n - base) + 31u) >> 5);
-        for (int w = 0; w < nw; ++w) s_pm[w][tid] = 0u;
         const uint32_t idx = base + tid;
         float gx = 0.f, gy = 0.f, r2 = -1.f;
         if (idx < n) {
@@ -371,7 +375,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
             gx = a.x; gy = a.y; r2 = b.w;
         }
-        __syncthreads();
         if (!ABLATE(8) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) scatter_footprint(s_pm, tid, gx, gy, r2, X0, Y0);
         __syncthreads();
         if (!wave_done && !ABLATE(8) && !ABLATE(9) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             }
             wave_done = __ballot(!done) == 0;
         }
+        for (int w = 0; w < nw; ++w) s_pm[w][tid] = 0u;
         if (__syncthreads_and(wave_done)) break;
     }
     if (inside && !(ABLATE(12) && Tr == 123.f)) {
@@ -815,13 +819,10 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         }
 #pragma unroll
         for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
+        // ---- phase A (the candidate words were cleared before the prefix-sum barrier above) ----
+        if (acc && !ABLATE(4)) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
         __syncthreads();
         const int cnt = (int)(s_wacc[0] + s_wacc[1] + s_wacc[2] + s_wacc[3]);   // >= 1: one entry needs <= 256 slots
-        PHASE_MARK(1);
-        if (ABLATE(4)) { hi -= (uint32_t)cnt; __syncthreads(); continue; }
-        // ---- phase A ----
-        if (acc) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
-        __syncthreads();
         PHASE_MARK(2);
         if (ABLATE(5)) { hi -= (uint32_t)cnt; __syncthreads(); continue; }
         // ---- phase B: ascending bits = descending list position ----
