@@ -396,25 +396,74 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint3
     }
 }
 
-// Lists longer than the LDS classes: same network straight on global memory, one 1024-thread
-// block per tile (L2-resident; slow but exact -- a correctness fallback for degenerate scenes
-// where one tile holds > 16384 Gaussians).
-__global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint32_t* __restrict__ tile_start,
-                                                                     const uint32_t* __restrict__ counters,
-                                                                     uint64_t* pairs, uint64_t capacity,
-                                                                     uint32_t lo) {
+// Lists longer than the LDS classes (> 16384 entries: degenerate scenes where one tile holds a large part of the
+// Gaussians).  Same all-ascending network, one 1024-thread block per tile, organised around 16384-entry CHUNKS that
+// fit the LDS: every chunk is first sorted in LDS; then, per merge size k = 2, 4, ... chunks, only the steps whose
+// partner distance is >= one chunk go through global memory (log2(k / chunk) passes), and the rest of the merge is
+// finished chunk by chunk in LDS again.  65,536 entries: 3 global passes instead of the 136 of a network that lives
+// in global memory throughout.
+constexpr uint32_t kBigChunk = 16384;
+
+__device__ __forceinline__ void lds_steps(uint64_t* s, uint32_t cn, uint32_t kfirst, uint32_t klast) {
+    // merges of size kfirst .. klast (powers of two, <= kBigChunk) on the cn (<= kBigChunk) keys in LDS
+    const uint32_t half = kBigChunk >> 1;
+    for (uint32_t k = kfirst; k <= klast; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
+            for (uint32_t i = threadIdx.x; i < half; i += 1024) {
+                const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                const uint32_t c = a ^ mask;
+                if (c < cn) {
+                    const uint64_t x = s[a], y = s[c];
+                    if (x > y) { s[a] = y; s[c] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// the tail of a merge whose first steps were done in global memory: partner distances chunk/2 .. 1 (no mirror step)
+__device__ __forceinline__ void lds_tail(uint64_t* s, uint32_t cn) {
+    const uint32_t half = kBigChunk >> 1;
+    for (uint32_t j = kBigChunk >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < half; i += 1024) {
+            const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+            const uint32_t c = a ^ j;
+            if (c < cn) {
+                const uint64_t x = s[a], y = s[c];
+                if (x > y) { s[a] = y; s[c] = x; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void spf_sort_tiles_big_kernel(const uint32_t* __restrict__ tile_start,
+                                                                  const uint32_t* __restrict__ counters,
+                                                                  uint64_t* pairs, uint64_t capacity, uint32_t lo) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
     if (counters[0] > capacity) return;
     const uint32_t b = tile_start[blockIdx.x];
     const uint32_t n = tile_start[blockIdx.x + 1] - b;
     if (n <= lo) return;
-    volatile uint64_t* p = pairs + b;
+    uint64_t* p = pairs + b;
     uint32_t m = 1;
     while (m < n) m <<= 1;
-    const uint32_t half = m >> 1;
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+    // 1) every chunk sorted on its own
+    for (uint32_t c0 = 0; c0 < n; c0 += kBigChunk) {
+        const uint32_t cn = min(kBigChunk, n - c0);
+        for (uint32_t i = threadIdx.x; i < cn; i += 1024) s[i] = p[c0 + i];
+        __syncthreads();
+        lds_steps(s, cn, 2, kBigChunk);
+        for (uint32_t i = threadIdx.x; i < cn; i += 1024) p[c0 + i] = s[i];
+        __syncthreads();
+    }
+    // 2) merges across chunks
+    for (uint32_t k = 2 * kBigChunk; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= kBigChunk; j >>= 1) {                      // global passes
             const uint32_t mask = (j == (k >> 1)) ? (k - 1) : j;
-            for (uint32_t i = threadIdx.x; i < half; i += 1024) {
+            for (uint32_t i = threadIdx.x; i < (m >> 1); i += 1024) {
                 const uint32_t a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
                 const uint32_t c = a ^ mask;
                 if (c < n) {
@@ -423,6 +472,14 @@ __global__ __launch_bounds__(1024) void spf_sort_tiles_global_kernel(const uint3
                 }
             }
             __threadfence_block();
+            __syncthreads();
+        }
+        for (uint32_t c0 = 0; c0 < n; c0 += kBigChunk) {                          // the rest of the merge, in LDS
+            const uint32_t cn = min(kBigChunk, n - c0);
+            for (uint32_t i = threadIdx.x; i < cn; i += 1024) s[i] = p[c0 + i];
+            __syncthreads();
+            lds_tail(s, cn);
+            for (uint32_t i = threadIdx.x; i < cn; i += 1024) p[c0 + i] = s[i];
             __syncthreads();
         }
     }
@@ -456,7 +513,7 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 }
 
 // Size classes: (1, 512] or (1, 1024] and (1024, 2048]: one wave per tile, list in registers; (2048, 8192], (8192, 16384]: one 1024-thread
-// block per tile in LDS; > 16384: global fallback.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
+// block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
@@ -480,12 +537,15 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint3
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_lds_kernel<1024>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_big_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+            if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 8192, 16384);
     }
     if (mx > 16384)
-        spf_sort_tiles_global_kernel<<<RT, 1024, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 16384);
+        spf_sort_tiles_big_kernel<<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 16384);
     return hipGetLastError();
 }
 

@@ -9,10 +9,11 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("G,expect_min_list", [(12000, 2049), (50000, 8193), (110000, 16385)])
+@pytest.mark.parametrize("G,expect_min_list", [(12000, 2049), (50000, 8193), (110000, 16385), (131072, 32769)])
 def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list):
-    """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and the global-memory
-    fallback above 16384 entries."""
+    """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and, above 16384 entries, the
+    chunked sort (16384-entry chunks in LDS, merges across chunks through global memory: one level at 110k, two at
+    131k Gaussians)."""
     batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G)
     batch.opacities = batch.opacities * 0.03        # keep transmittance alive deep into the lists
     prod = util.run_product(batch)

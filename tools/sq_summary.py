@@ -31,8 +31,8 @@ for k, cs in sorted(acc.items()):
     if g("SQ_ACTIVE_INST_VALU") is not None and g("SQ_BUSY_CU_CYCLES"):
         d["valu_busy_frac"] = round(g("SQ_ACTIVE_INST_VALU") / g("SQ_BUSY_CU_CYCLES"), 4)
     if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_INSTS_VALU"):
-        # thread-cycles / (instructions * 4 cycles) = average active lanes per VALU instruction
-        d["active_lanes_per_valu_inst"] = round(g("SQ_THREAD_CYCLES_VALU") / (g("SQ_INSTS_VALU") * 4.0), 2)
+        # the counter adds the active lanes of every VALU instruction: / instructions = average active lanes (of 64)
+        d["active_lanes_per_valu_inst"] = round(g("SQ_THREAD_CYCLES_VALU") / g("SQ_INSTS_VALU"), 1)
     res[k] = {kk: (round(vv, 1) if isinstance(vv, float) and vv > 10 else vv) for kk, vv in d.items()}
 json.dump(res, open(out, "w"), indent=1)
 for k, d in res.items():
