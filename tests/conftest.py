@@ -10,6 +10,16 @@ if str(ROOT) not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def _cap_threads():
+    # the oracle's per-tile tensors are small: on a 256-core GPU host the default thread count only adds
+    # synchronisation cost (the full-size parity cases ran 3x slower on a busy box)
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+
+
+_cap_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -9,12 +9,13 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("G,expect_min_list", [(12000, 2049), (50000, 8193), (110000, 16385), (131072, 32769)])
-def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list):
+@pytest.mark.parametrize("G,expect_min_list,hw", [(12000, 2049, None), (50000, 8193, None), (110000, 16385, None),
+                                                   (131072, 32769, (16, 16))])
+def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list, hw):
     """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and, above 16384 entries, the
     chunked sort (16384-entry chunks in LDS, merges across chunks through global memory: one level at 110k, two at
     131k Gaussians)."""
-    batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G)
+    batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G, image_hw=hw)     # (16x16: everything in ONE tile)
     batch.opacities = batch.opacities * 0.03        # keep transmittance alive deep into the lists
     prod = util.run_product(batch)
     assert prod["stats"]["max_tile_list"] >= expect_min_list, prod["stats"]
@@ -22,7 +23,8 @@ def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list):
     # tens of thousands of Gaussians over a 32x32 image: every pixel is reached by thousands of entries, so
     # proportionally more pixels sit next to a tile-membership / stop-threshold knife-edge and are excluded from the
     # RGB gate (gradients are still gated on everything)
-    rep = util.compare(prod, ref, max_fragile_frac=0.25)
+    # (one 16x16 tile under 40,000 entries: more than a third of its 256 pixels are next to some threshold)
+    rep = util.compare(prod, ref, max_fragile_frac=0.25 if hw is None else 0.5)
     assert not rep["fails"], rep
 
 
