@@ -26,7 +26,7 @@ import os
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward",
            "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags", "plan_flags", "CallRecord",
-           "sh_band4_default"]
+           "sh_band4_default", "gaussian_normals"]
 
 _REC = 12
 
@@ -548,13 +548,35 @@ class GaussianRasterizationSettings(NamedTuple):
     enable_cov_grad: bool = True
     enable_sh_grad: bool = True
     sh_band4: Optional[bool] = None    # (not a field of the reference's tuple) None = sh_band4_default()
+    render_norm: bool = False          # (not a field of the reference's tuple) also produce `rendered_norm`
+
+
+def gaussian_normals(means3D: Tensor, scales: Tensor, rotations: Tensor, viewmatrix: Tensor) -> Tensor:
+    """View-space unit normal of every Gaussian [G,3]: its axis of least extent (the column of R(q) that belongs to the
+    smallest scale; q read as (r,x,y,z) like the rasterizer does), taken to view space with the
+    row-vector `viewmatrix` and turned to face the camera.  ASSUMED definition of the fork's `rendered_norm` (its source
+    is not available offline -- oracle/PINNING.md, last row); the reference never reads that output."""
+    r, x, y, z = rotations.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+    axis = scales.argmin(dim=-1)
+    n_world = R[torch.arange(R.shape[0], device=R.device), :, axis]
+    n_view = n_world @ viewmatrix[:3, :3]
+    t_view = means3D @ viewmatrix[:3, :3] + viewmatrix[3, :3]
+    n_view = n_view / n_view.norm(dim=-1, keepdim=True).clamp_min(1e-20)
+    away = (n_view * t_view).sum(dim=-1, keepdim=True) > 0
+    return torch.where(away, -n_view, n_view)
 
 
 class GaussianRasterizer(torch.nn.Module):
     """``GaussianRasterizer(settings)(means3D=..., means2D=..., shs=..., colors_precomp=..., opacities=...,
     scales=..., rotations=..., viewmatrix=...) -> (image[3,H,W], depth[1,H,W], norm, alpha[1,H,W], radii[G], extra)``
-    (call site: cuda_splatting.py:124-138).  ``norm`` and ``extra`` are not produced (None): the reference
-    never reads them (cuda_splatting.py:141-144)."""
+    (call site: cuda_splatting.py:124-138).  The reference never reads ``norm`` and ``extra``
+    (cuda_splatting.py:141-144), so they cost nothing unless asked for: ``norm`` is None unless
+    ``settings.render_norm`` (or ``SPF_RENDER_NORM=1``), ``extra`` is None unless ``extra_attrs`` [G,C] is passed.  Both are
+    alpha-blended per-Gaussian attributes, ``sum_i a_i alpha_i T_i`` -- rendered by further passes of the same
+    rasterizer, three channels at a time, through its ``colors_precomp`` input (differentiable like any colour)."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -572,14 +594,31 @@ class GaussianRasterizer(torch.nn.Module):
             raise Exception("Please provide scales and rotations")
         if viewmatrix is None:
             raise Exception("viewmatrix is a forward argument of this rasterizer (cuda_splatting.py:137)")
-        if extra_attrs is not None:
-            raise NotImplementedError("extra_attrs is not supported")
         dev = means3D.device
         tanfov = torch.tensor([[[float(s.tanfovx), float(s.tanfovy)]]], dtype=torch.float32, device=dev)
-        image, depth, alpha, radii = rasterize_batch(
-            means3D[None], scales[None], rotations[None], opacities.reshape(1, -1),
-            None if shs is None else shs[None], None if colors_precomp is None else colors_precomp[None],
-            viewmatrix[None, None], s.projmatrix[None, None], tanfov, s.bg.reshape(1, 1, 3),
-            s.image_height, s.image_width, s.sh_degree, s.scale_modifier,
-            s.enable_cov_grad, s.enable_sh_grad, means2D=means2D, sh_band4=s.sh_band4)
-        return image[0, 0], depth[0, 0], None, alpha[0, 0], radii[0, 0], None
+
+        def render(shs_, colors_, bg, m2d=None):
+            return rasterize_batch(
+                means3D[None], scales[None], rotations[None], opacities.reshape(1, -1),
+                None if shs_ is None else shs_[None], None if colors_ is None else colors_[None],
+                viewmatrix[None, None], s.projmatrix[None, None], tanfov, bg.reshape(1, 1, 3),
+                s.image_height, s.image_width, s.sh_degree, s.scale_modifier,
+                s.enable_cov_grad, s.enable_sh_grad, means2D=m2d, sh_band4=s.sh_band4)
+
+        def blend(attrs: Tensor) -> Tensor:            # [G,C] -> [C,H,W], three channels per pass, no background
+            out = []
+            for c0 in range(0, attrs.shape[1], 3):
+                chunk = attrs[:, c0:c0 + 3]
+                pad = 3 - chunk.shape[1]
+                if pad:
+                    chunk = torch.cat([chunk, chunk.new_zeros(chunk.shape[0], pad)], dim=1)
+                out.append(render(None, chunk.contiguous(), torch.zeros(3, device=dev))[0][0, 0][:3 - pad])
+            return torch.cat(out, dim=0)
+
+        image, depth, alpha, radii = render(shs, colors_precomp, s.bg, means2D)
+        norm = extra = None
+        if s.render_norm or os.environ.get("SPF_RENDER_NORM", "0") == "1":
+            norm = blend(gaussian_normals(means3D, scales * s.scale_modifier, rotations, viewmatrix))
+        if extra_attrs is not None:
+            extra = blend(extra_attrs.to(torch.float32))
+        return image[0, 0], depth[0, 0], norm, alpha[0, 0], radii[0, 0], extra

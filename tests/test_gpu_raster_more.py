@@ -228,3 +228,52 @@ def test_decoder_module_with_a_planned_budget(hip_lib):
     planned = d(g, batch.extrinsics, batch.intrinsics, batch.near, batch.far, batch.image_shape)
     assert spf.last_plan_flags() == 0
     assert torch.equal(exact.color, planned.color) and torch.equal(exact.depth, planned.depth)
+
+
+def test_rendered_norm_and_extra_are_opt_in_blends(hip_lib):
+    """Positions 2 and 5 of the rasterizer's 6-tuple (cuda_splatting.py:128): None by default (the reference discards
+    them), alpha-blended per-Gaussian attributes on request -- checked against the oracle's blend of the same attributes,
+    and against geometry: a disc facing the camera has normal (0, 0, -1) in view space."""
+    import spfsplatv2_amd as spf
+    from oracle import glue_ref, splat_ref
+    from spfsplatv2_amd.rasterizer import gaussian_normals
+    batch = syn.make_batch("TEST", 1, 1, seed=9, s_mult=12.0, G=800, K=4, image_hw=(64, 64))
+    a = glue_ref.callsite_args(batch.extrinsics[:, 0], batch.intrinsics[:, 0], batch.near[:, 0], batch.far[:, 0],
+                               batch.image_shape, torch.zeros(1, 3), batch.means, batch.harmonics, batch.opacities,
+                               batch.rotations, batch.scales)[0]
+    dev = "cuda"
+    t = lambda x: x.to(dev)
+    kw = dict(image_height=64, image_width=64, tanfovx=a["tanfovx"], tanfovy=a["tanfovy"], bg=t(a["bg"]),
+              scale_modifier=1.0, projmatrix=t(a["projmatrix"]), sh_degree=a["sh_degree"])
+    call = dict(means3D=t(a["means3D"]), means2D=None, shs=t(a["shs"]), colors_precomp=None, opacities=t(a["opacities"]),
+                scales=t(a["scales"]), rotations=t(a["rotations"]), viewmatrix=t(a["viewmatrix"]))
+    plain = spf.GaussianRasterizer(spf.GaussianRasterizationSettings(**kw))(**call)
+    assert plain[2] is None and plain[5] is None
+    gen = torch.Generator().manual_seed(3)
+    attrs = torch.randn(800, 5, generator=gen)
+    scales = t(a["scales"]).clone().requires_grad_(True)
+    call["scales"] = scales
+    out = spf.GaussianRasterizer(spf.GaussianRasterizationSettings(**kw, render_norm=True))(**call, extra_attrs=t(attrs))
+    norm, extra = out[2], out[5]
+    assert norm.shape == (3, 64, 64) and extra.shape == (5, 64, 64) and torch.equal(out[0], plain[0])
+    n_cpu = gaussian_normals(a["means3D"], a["scales"], a["rotations"], a["viewmatrix"])
+    assert float((n_cpu.norm(dim=-1) - 1).abs().max()) < 1e-5
+    for attr, got in ((n_cpu, norm), (attrs[:, :3], extra[:3]), (torch.cat([attrs[:, 3:], torch.zeros(800, 1)], 1), extra[3:])):
+        want, _, _, _, frag = splat_ref.rasterize(
+            a["means3D"].double(), a["scales"].double(), a["rotations"].double(), a["opacities"].double(), None,
+            attr.double(), a["viewmatrix"].double(), a["projmatrix"].double(), torch.zeros(3).double(), a["tanfovx"],
+            a["tanfovy"], 64, 64, 0, want_fragile=True)
+        n = got.shape[0]
+        assert float(((got.detach().cpu().double() - want[:n]).abs() * ~frag).max()) < 1e-4
+    norm.square().sum().backward()                       # differentiable like any colour (here: through argmin's axis)
+    assert scales.grad is not None and bool(torch.isfinite(scales.grad).all())
+    # one opaque disc, thin along the view axis, in front of an identity camera: its normal faces the camera
+    one = spf.GaussianRasterizer(spf.GaussianRasterizationSettings(
+        **{**kw, "projmatrix": t(a["projmatrix"])}, render_norm=True))(
+        means3D=torch.tensor([[0.0, 0.0, 5.0]], device=dev), means2D=None, shs=None,
+        colors_precomp=torch.ones(1, 3, device=dev), opacities=torch.tensor([[0.9]], device=dev),
+        scales=torch.tensor([[0.5, 0.5, 0.01]], device=dev), rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev),
+        viewmatrix=torch.eye(4, device=dev))
+    n, al = one[2], one[3]
+    assert float(al.max()) > 0.5
+    assert float((n[2] + al[0]).abs().max()) < 1e-5 and float(n[:2].abs().max()) < 1e-6      # (0, 0, -1) * alpha

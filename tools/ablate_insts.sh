@@ -13,8 +13,8 @@ by = collections.defaultdict(dict)
 for r in rows:
     by[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(by)
-per = len(ids) // 10
-for c in range(10):
+per = len(ids) // 13
+for c in range(13):
     sel = ids[c * per:(c + 1) * per]
     out = {k: sum(by[i][k] for i in sel) / len(sel) for k in by[sel[0]]}
     print("cut", c, {k: round(v / 1e6, 2) for k, v in out.items()})
