@@ -267,7 +267,8 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K,
 // the view loop from six floats per view that every thread parks in LDS for itself (unit direction, colour gradient
 // with clamped channels already zeroed) -- instead of 3*NB accumulator registers carried through the whole loop.
 // park[(6 * v + j) * kBlock + tid]; `first`: store, otherwise add to what an earlier chunk of views stored.
-template <int NB, bool NATIVE, bool ALIGNED>
+// TO_LDS: `o` is the thread's own 3*K-float row of an LDS staging buffer (element-wise stores; `first` is true).
+template <int NB, bool NATIVE, bool ALIGNED, bool TO_LDS = false>
 __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K, const float* __restrict__ park,
                                                     int nviews, bool first) {
     constexpr int NV = NB / 4;
@@ -292,6 +293,14 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
     for (int k4 = 0; k4 < NV; ++k4) {
         float acc[4][3];
         group(4 * k4, 4, acc);
+        if (TO_LDS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 4 * k4 + i;
+                o[sk * k] = acc[i][0]; o[sk * k + sc] = acc[i][1]; o[sk * k + 2 * sc] = acc[i][2];
+            }
+            continue;
+        }
         if (!first) {
             float old[4][3];
             sh_load4<NATIVE, ALIGNED>(o, K, k4, old);
@@ -310,7 +319,9 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
             o[sk * k] = acc[i][0]; o[sk * k + sc] = acc[i][1]; o[sk * k + 2 * sc] = acc[i][2];
         }
     }
-    if (first && K > NB) {     // coefficients that are carried but not evaluated: zero gradient
+    if (TO_LDS) {
+        for (int k = NB; k < K; ++k) { o[sk * k] = 0.f; o[sk * k + sc] = 0.f; o[sk * k + 2 * sc] = 0.f; }
+    } else if (first && K > NB) {     // coefficients that are carried but not evaluated: zero gradient
         if (NATIVE) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) zero_floats(o + c * K + NB, K - NB);
@@ -502,7 +513,14 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
 // vpartial[r][block][12] (no float atomics -> deterministic), summed by spf_view_reduce_kernel.
 // ------------------------------------------------------------------------------------------
 constexpr int kViewChunk = 64;
-constexpr int kShChunk = 8;      // views parked per thread before their SH gradient is formed (6 floats each, in LDS)
+constexpr int kShChunk = 8;
+// dL/dsh leaves through an LDS staging buffer (see the backward kernel) when a Gaussian's coefficient block is not a
+// multiple of 16 bytes per channel row (K = 25: every 16-byte piece is misaligned and straddles sectors; with
+// K = 16 the direct stores are as fast: measured), all views fit one parked chunk and the block still fits twice on a
+// CU (<= 80 KB of LDS)
+__host__ __device__ inline bool sh_stage_out(int V, int K) {
+    return K % 4 != 0 && V <= kShChunk && (size_t)V * (6 * 256 + 48) * 4 + (size_t)128 * 3 * K * 4 <= 80 * 1024;
+}      // views parked per thread before their SH gradient is formed (6 floats each, in LDS)
 
 // (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
 // the SH section -- 300+ VGPRs, one wave per SIMD; asking for two blocks per CU caps it at 256 VGPRs)
@@ -559,6 +577,11 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
     constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
     const bool want_dsh = DEG >= 0 && gr.dL_dshs != nullptr;
     float* __restrict__ dsh_out = want_dsh ? gr.dL_dshs + sg * (size_t)d.K * 3 : nullptr;
+    // When every view fits the parked chunk, dL/dsh leaves through an LDS staging buffer (half a block at a time) and
+    // is written with full-wave contiguous stores.  Per-thread stores of a 3*K-float block are 16-byte pieces at a
+    // 12*K-byte stride: lines fill up piece by piece over the whole flush and the set of open lines outgrows the L2
+    // -- at K = 25 the stores alone were 250 of the kernel's 439 us.
+    const bool stage_out = kPark && want_dsh && sh_stage_out(d.V, d.K);
     float dsh[kPark ? 1 : NB][3];
 #pragma unroll
     for (int k = 0; k < (kPark ? 1 : NB); ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
                 const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
                 const ShDir sd = sh_dir(x, y, z);
-                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                const float* __restrict__ sh = in.shs + (SPF_PABL == 9 ? (size_t)s * d.G : sg) * (size_t)d.K * 3;
                 // One pass over the coefficient block: re-evaluate the colour exactly as the forward kernel does
                 // (colours clamped at 0 pass no gradient; cheaper than re-reading the 48-byte record) and collect
                 // s_k = sh_k . dL/dcolour for the direction gradient.
@@ -764,7 +787,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
             float* __restrict__ pk = s_park + (size_t)(6 * (v % kShChunk)) * kBlock;
             pk[0] = sh_x; pk[kBlock] = sh_y; pk[2 * kBlock] = sh_z;
             pk[3 * kBlock] = sh_g0; pk[4 * kBlock] = sh_g1; pk[5 * kBlock] = sh_g2;
-            if (live && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
+            if (live && !stage_out && SPF_PABL != 8 && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
                 const int nv = v % kShChunk + 1;
                 const bool first = v < kShChunk;
                 if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, d.K, s_park, nv, first);
@@ -790,6 +813,30 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                         sp[0] + sp[12] + sp[24] + sp[36];
                 }
                 if (v + 1 < d.V) __syncthreads();
+            }
+        }
+    }
+    if (stage_out && SPF_PABL != 8) {
+        const int row = 3 * d.K;
+        float* __restrict__ s_out = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + d.V * 6 * kBlock;
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                  // (buffer free; the parked views are complete)
+            if ((int)(threadIdx.x >> 7) == half && live) {
+                float* __restrict__ mine = s_out + (threadIdx.x & 127) * row;
+                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true, true>(mine, d.K, s_park, d.V, true);
+                else sh_grad_from_parked<NB, NATIVE, false, true>(mine, d.K, s_park, d.V, true);
+            }
+            __syncthreads();
+            const int g0 = blockIdx.x * kBlock + half * 128;
+            const int nflt = min(128, d.G - g0) * row;        // (<= 0: nothing of this half exists)
+            float* __restrict__ dst = gr.dL_dshs + ((size_t)s * d.G + g0) * row;
+            for (int i = 4 * threadIdx.x; i < nflt; i += 4 * kBlock) {
+                if (i + 4 <= nflt) {
+                    const float4 q = *reinterpret_cast<const float4*>(s_out + i);
+                    *reinterpret_cast<f4u*>(dst + i) = f4a{q.x, q.y, q.z, q.w};
+                } else {
+                    for (int j = i; j < nflt; ++j) dst[j] = s_out[j];
+                }
             }
         }
     }
@@ -892,7 +939,20 @@ template <int DEG, bool NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
                           const SpfGrads& g, int nblk, uint64_t capacity) {
     size_t lds = (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float);
-    if (DEG >= 2 && g.dL_dshs) lds += (size_t)(d.V < kShChunk ? d.V : kShChunk) * 6 * kBlock * sizeof(float);
+    if (DEG >= 2 && g.dL_dshs) {
+        lds += (size_t)(d.V < kShChunk ? d.V : kShChunk) * 6 * kBlock * sizeof(float);
+        if (sh_stage_out(d.V, d.K)) lds += (size_t)128 * 3 * d.K * sizeof(float);   // staged dL/dsh, half a block at a time
+        if (lds > 64 * 1024) {
+            // more than the default 64 KB of dynamic LDS: opt in, once per device and instantiation
+            static bool attr_set[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev]) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_project_bwd_kernel<DEG, NATIVE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            }
+        }
+    }
     spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), lds, stream>>>(d, in, st, g, nblk, capacity);
 }
 #define SPF_DISPATCH_DEG(FN, ...)                                        \
