@@ -505,7 +505,7 @@ hipError_t launch_tile_scan(const SpfState& st, int R, int T, int nblk, uint32_t
 hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
                             uint32_t max_tile_hint, uint32_t dense_hint, hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
-    const int lds = T <= kMaxLdsTiles ? 1 : 0;
+    const int lds = T <= max_lds_tiles() ? 1 : 0;
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
         st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
         d.G, T, tiles_x, lds, max_tile_hint, dense_hint, (uint32_t)(d.S * d.V * T));

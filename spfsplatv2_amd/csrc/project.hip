@@ -976,7 +976,7 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     const int deg = in.colors ? -1 : sh_eval_degree(d);
     const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
-    const int lds = T <= kMaxLdsTiles ? 1 : 0;
+    const int lds = T <= max_lds_tiles() ? 1 : 0;
     const size_t sm = lds ? 2 * sizeof(uint32_t) * T : 0;
     SPF_DISPATCH_DEG(project_fwd_t, grid, sm, stream, d, in, st, tiles_x, tiles_y, lds)
     return hipGetLastError();

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/spfsplat_hip.h"
 
@@ -14,6 +15,12 @@ constexpr int kRec = 12;        // floats per screen-space record / gradient rec
 constexpr int kTile = SPF_TILE; // 16
 constexpr int kBlock = 256;     // one 16x16 tile = 4 waves, one 8x8 sub-tile per wave
 constexpr int kMaxLdsTiles = 4096;  // per-render tile histograms up to this many tiles live in LDS (1024x1024 px)
+// (SPF_MAX_LDS_TILES lowers the limit: lets a test drive the global-atomics fall-back on a small image; read per launch)
+inline int max_lds_tiles() {
+    const char* e = getenv("SPF_MAX_LDS_TILES");
+    const int v = e ? atoi(e) : kMaxLdsTiles;
+    return v < kMaxLdsTiles ? v : kMaxLdsTiles;
+}
 
 // Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
 // 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).

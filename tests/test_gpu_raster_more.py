@@ -277,3 +277,31 @@ def test_rendered_norm_and_extra_are_opt_in_blends(hip_lib):
     n, al = one[2], one[3]
     assert float(al.max()) > 0.5
     assert float((n[2] + al[0]).abs().max()) < 1e-5 and float(n[:2].abs().max()) < 1e-6      # (0, 0, -1) * alpha
+
+
+@pytest.mark.parametrize("hw", [(1024, 1024), (1040, 1072)], ids=["4096_tiles_lds", "4355_tiles_global_atomics"])
+def test_large_images_both_tile_counter_paths(hip_lib, hw):
+    """1024x1024 is what the reference's paper script renders (validate_in_the_wild.py:304): 4,096 tiles, the most the
+    per-block LDS histograms of the projection / binning kernels hold; one tile row more and they fall back to global
+    atomics.  Forward against the oracle at full size (its autograd pass over 4,000 tiles takes minutes: the gradient
+    parity of the fall-back path is `test_global_atomic_tile_counters_with_gradients`)."""
+    batch = syn.make_batch("TEST", 1, 1, seed=61, s_mult=40.0, G=2500, K=4, image_hw=hw)
+    ref = util.run_oracle(batch, torch.float64, background=(0.1, 0.0, 0.2), with_grads=False)
+    prod = util.run_product(batch, background=(0.1, 0.0, 0.2))
+    rep = util.compare(prod, ref)
+    assert not rep["fails"], rep
+    assert prod["stats"]["tiles"] == ((hw[0] + 15) // 16) * ((hw[1] + 15) // 16) and prod["stats"]["num_pairs"] > 2000
+    assert all(bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0 for g in prod["grads"].values())
+
+
+def test_global_atomic_tile_counters_with_gradients(hip_lib, monkeypatch):
+    """The > 4096-tile path of the projection and binning kernels (no LDS histograms) forced on a small image
+    (`SPF_MAX_LDS_TILES`, read at every launch): full parity incl. gradients, and bit-equal images with the LDS path."""
+    batch = syn.make_batch("TEST", 2, 2, seed=62, s_mult=8.0, G=1500, K=4, image_hw=(80, 112))
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
+    lds = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    monkeypatch.setenv("SPF_MAX_LDS_TILES", "1")
+    glob = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    rep = util.compare(glob, ref)
+    assert not rep["fails"], rep
+    assert torch.equal(glob["color"], lds["color"]) and torch.equal(glob["radii"], lds["radii"])
