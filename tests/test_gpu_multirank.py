@@ -129,3 +129,15 @@ def test_bench_gpus2_starts_two_ranks_itself(hip_lib):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and "all-reduce" in out["config"]["sharding"]
+
+
+def test_bench_streams2_micro_batches(hip_lib):
+    """`bench.py --streams 2`: two micro-batches, two HIP graphs, two streams -- same renders per step, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--streams", "2", "--steps", "3", "--warmup", "2",
+                        "--min-trials", "3", "--min-seconds", "0", "--scenes", "2", "--views", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["config"]["renders_per_step"] == 4 and "2 micro-batches" in out["config"]["launch"]
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0
