@@ -305,3 +305,27 @@ def test_global_atomic_tile_counters_with_gradients(hip_lib, monkeypatch):
     rep = util.compare(glob, ref)
     assert not rep["fails"], rep
     assert torch.equal(glob["color"], lds["color"]) and torch.equal(glob["radii"], lds["radii"])
+
+
+def test_many_renders_both_scan_kernels_agree(hip_lib):
+    """More than 256 renders in one call fall back from the one-block-per-render tile scan to the single-block scan:
+    320 views at once (single-block) are bit-equal to the same views rendered as 2 x 160 (one block per render), and
+    the gradients agree."""
+    import spfsplatv2_amd as spf
+    b = syn.make_batch("TEST", 1, 320, seed=71, s_mult=20.0, G=400, K=4, image_hw=(32, 48)).to("cuda")
+
+    def run(vs):
+        means = b.means.clone().requires_grad_(True)
+        color, depth, alpha = spf.render_views(b.extrinsics[:, vs], b.intrinsics[:, vs], b.near[:, vs], b.far[:, vs],
+                                               b.image_shape, torch.zeros(3, device="cuda"), means, b.harmonics,
+                                               b.opacities, b.rotations, b.scales, enable_cov_grad=True,
+                                               enable_sh_grad=True)
+        (color * b.target[:, vs]).sum().backward()
+        return color, depth, means.grad
+
+    c_all, d_all, g_all = run(slice(0, 320))
+    c_a, d_a, g_a = run(slice(0, 160))
+    c_b, d_b, g_b = run(slice(160, 320))
+    assert torch.equal(c_all, torch.cat([c_a, c_b], dim=1)) and torch.equal(d_all, torch.cat([d_a, d_b], dim=1))
+    assert float(c_all.abs().max()) > 0.1
+    assert util.rel_linf(g_all, g_a + g_b) < 1e-5
