@@ -396,6 +396,61 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint3
     }
 }
 
+// ---- per-tile sort, one 256-thread block per tile, E keys per thread (lists of 513 .. 256*E entries) ----------------
+// The same register network with four waves on one list: every wave first sorts its 64*E-key chunk exactly as the
+// wave kernel does; the last two merges (128*E, 256*E) start with steps whose partner sits in another wave -- those
+// three exchanges go through LDS (slot-major, conflict-free), everything below stays lane exchanges and register
+// compare-exchanges.  A single wave on such a list (16 / 32 keys per lane) is a long serial chain and leaves most of
+// the chip idle when the lists are long because the tiles are few (BASELINE config 3: 2,048 tiles of ~1,000 entries).
+template <int E, bool MIRROR>
+__device__ __forceinline__ void block_step(uint64_t (&r)[E], uint64_t* __restrict__ s, int t, int tmask) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) s[k * kBlock + t] = r[k];
+    __syncthreads();
+    const int pt = t ^ tmask;
+    const bool lower = (t & (MIRROR ? (tmask + 1) >> 1 : tmask)) == 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint64_t o = s[(MIRROR ? E - 1 - k : k) * kBlock + pt];
+        r[k] = ((o < r[k]) == lower) ? o : r[k];
+    }
+    __syncthreads();
+}
+
+template <int E>
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint32_t* __restrict__ tile_start,
+                                                                      const uint32_t* __restrict__ counters,
+                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                      uint32_t lo) {
+    __shared__ uint64_t s_x[E * kBlock];
+    if (counters[0] > capacity) return;
+    const uint32_t b = tile_start[blockIdx.x];
+    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    if (n <= lo || n > (uint32_t)(kBlock * E)) return;
+    uint64_t* __restrict__ p = pairs + b;
+    const int t = threadIdx.x, lane = t & (kWave - 1);
+    uint64_t r[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint32_t e = (uint32_t)(E * t + k);
+        r[k] = e < n ? p[e] : ~0ull;
+    }
+    merges_inside<E, 2>(r);
+    merges_across<E, 2 * E>(r, lane);                 // every wave: its 64*E keys sorted
+    block_step<E, true>(r, s_x, t, 127);              // merge of 128*E: mirror step across the wave pair ...
+    lane_steps_down<E, 32 * E>(r, lane);              // ... the rest inside the wave
+    thread_steps_down<E, E / 2>(r);
+    block_step<E, true>(r, s_x, t, 255);              // merge of 256*E: mirror step across the block,
+    block_step<E, false>(r, s_x, t, 64);              // partner distance 64*E across the wave pair,
+    lane_steps_down<E, 32 * E>(r, lane);              // the rest inside the wave
+    thread_steps_down<E, E / 2>(r);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint32_t e = (uint32_t)(E * t + k);
+        if (e < n) p[e] = r[k];
+    }
+}
+
 // Lists longer than the LDS classes (> 16384 entries: degenerate scenes where one tile holds a large part of the
 // Gaussians).  Same all-ascending network, one 1024-thread block per tile, organised around 16384-entry CHUNKS that
 // fit the LDS: every chunk is first sorted in LDS; then, per merge size k = 2, 4, ... chunks, only the steps whose
@@ -512,21 +567,32 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     return hipGetLastError();
 }
 
-// Size classes: (1, 512] or (1, 1024] and (1024, 2048]: one wave per tile, list in registers; (2048, 8192], (8192, 16384]: one 1024-thread
+// Size classes: (1, 512]: one wave per tile, list in registers; (512, 1024], (1024, 2048]: one 256-thread block per tile, list in
+// registers, three LDS exchanges; (2048, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
-    if (mx > 1 && mx <= 512)     // (registers sized for 8 keys per lane: one more wave per SIMD than the 16-key build)
+    // Lists of 513 .. 2048 entries: one wave per tile (16 / 32 keys per lane) when there are enough tiles to fill the
+    // chip with single waves, one 256-thread block per tile when there are not (measured: 2,048 tiles of ~1,000 entries
+    // 68 -> 60 us, 4,096 tiles of ~540 entries 69 -> 52 us with blocks; 8,192 tiles of ~540 entries 55 us with waves,
+    // 65 us with blocks)
+    const char* force = getenv("SPF_SORT_BLOCKS");       // (tests: "0" / "1" pin one of the two families)
+    const bool blocks = force ? force[0] == '1' : RT < 6144;
+    if (mx > 1 && (mx <= 512 || blocks))  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                           capacity, 1, RT);
-    if (mx > 512)
+    if (mx > 512 && !blocks)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
         spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                            capacity, 1, RT);
-    if (mx > 1024)
+    if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                             capacity, 1024, RT);
+    if (mx > 512 && blocks)      // 513 .. 1024: one block per tile, 4 keys per thread
+        spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 512);
+    if (mx > 1024 && blocks)     // 1025 .. 2048: 8 keys per thread
+        spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1024);
     if (mx > 2048)
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {

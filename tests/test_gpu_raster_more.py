@@ -9,10 +9,12 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("G,expect_min_list,hw", [(12000, 2049, None), (50000, 8193, None), (110000, 16385, None),
+@pytest.mark.parametrize("G,expect_min_list,hw", [(3200, 513, None), (6500, 1025, None), (12000, 2049, None),
+                                                   (50000, 8193, None), (110000, 16385, None),
                                                    (131072, 32769, (16, 16))])
 def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list, hw):
-    """4 tiles, thousands of Gaussians each: LDS sort classes (2048, 8192], (8192, 16384] and, above 16384 entries, the
+    """4 tiles, thousands of Gaussians each: the block-per-tile register sorts (512, 1024] and (1024, 2048], the LDS
+    sort classes (2048, 8192], (8192, 16384] and, above 16384 entries, the
     chunked sort (16384-entry chunks in LDS, merges across chunks through global memory: one level at 110k, two at
     131k Gaussians)."""
     batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G, image_hw=hw)     # (16x16: everything in ONE tile)
@@ -329,3 +331,25 @@ def test_many_renders_both_scan_kernels_agree(hip_lib):
     assert torch.equal(c_all, torch.cat([c_a, c_b], dim=1)) and torch.equal(d_all, torch.cat([d_a, d_b], dim=1))
     assert float(c_all.abs().max()) > 0.1
     assert util.rel_linf(g_all, g_a + g_b) < 1e-5
+
+
+def test_both_sort_families_give_the_same_lists(hip_lib, monkeypatch):
+    """Lists of 513..2048 entries are sorted by one wave per tile (16 / 32 keys per lane) when there are many tiles and by
+    one 256-thread block per tile when there are few (`SPF_SORT_BLOCKS` pins the family): the sorted lists are unique
+    (keys are), so images and gradients must be bit-equal -- and one of the two runs is gated against the oracle by the
+    long-list cases above."""
+    outs = []
+    for fam in ("0", "1"):
+        monkeypatch.setenv("SPF_SORT_BLOCKS", fam)
+        per = []
+        for G in (3200, 6500):
+            batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G)
+            batch.opacities = batch.opacities * 0.03
+            p = util.run_product(batch)
+            assert p["stats"]["max_tile_list"] > 512
+            per.append(p)
+        outs.append(per)
+    for a, b in zip(*outs):
+        assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"])
+        for n in util.GRAD_NAMES:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
