@@ -342,7 +342,7 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #define SPF_PFWD_BPC 1
 #endif
 #ifndef SPF_PABL
-#define SPF_PABL 0
+#define SPF_PABL 0      // profiling builds of the BACKWARD kernel only (-DSPF_PABL=5..9: gather / partials / stores / SH cut out)
 #endif
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
@@ -465,18 +465,15 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                     if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
                 }
             }
-            if (SPF_PABL != 1 || cA == 123.f) {
             st.radii[rg] = (int)radius;
             st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
             st.zkey[rg] = pr.tz;
             rec[0] = make_float4(pr.px, pr.py, cA, cB);
             rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
             rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
-            }
             uint32_t* __restrict__ cnt = lds_hist ? s_hist : st.tile_count + (size_t)r * T;
             uint32_t* __restrict__ are = lds_hist ? s_area : st.tile_flags + (size_t)r * T;
             const uint32_t area = disc_area_capped(pr.px, pr.py, cull_r2);
-            if (SPF_PABL != 2 || cA == 123.f)
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     atomicAdd(&cnt[ty * tiles_x + tx], 1u);
@@ -484,14 +481,12 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 }
         }
         // pairs produced by this block for this render (feeds the Gaussian-major pair numbering)
-        if (SPF_PABL != 3) {
         const uint32_t wsum = wave_sum_u32(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u);
         if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = wsum;
         __syncthreads();
         if (threadIdx.x == 0)
             st.blk_total[(size_t)r * gridDim.x + blockIdx.x] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        }
-        if (lds_hist && SPF_PABL != 4) {
+        if (lds_hist) {
             uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
             uint32_t* __restrict__ gare = st.tile_flags + (size_t)r * T;
             for (int t = threadIdx.x; t < T; t += kBlock) {
