@@ -120,7 +120,8 @@ typedef struct SpfGrads {
     const float* dL_dalpha;   /* [R,1,H,W] */
     float* gpair;             /* [capacity,10] scratch: screen-space gradient of every (Gaussian, tile) pair, written
                                  once per pair by its tile (no global atomics, no memset), indexed by pair_off + k;
-                                 records are packed: 9 floats each, 10 when dL_ddepth != NULL */
+                                 records are packed: 9 floats each, 10 when dL_ddepth != NULL
+                                 (dL/d pixel centre xy, dL/d 2-D covariance (a, b, c), dL/d opacity, dL/d rgb[, dL/d depth]) */
     float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
                                  nblk = spf_raster_view_partial_blocks(G) */
     float* dL_dmeans3D;       /* [S,G,3] */

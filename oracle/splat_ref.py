@@ -76,6 +76,7 @@ class Projected:
     rect_max: Tensor    # [G,2] int64 tile rect (x,y), exclusive
     radius_raw: Tensor  # [G] 3*sqrt(lambda_max) before ceil (for knife-edge flagging)
     rgb_raw: Tensor | None = None   # [G,3] SH colour + 0.5 BEFORE the clamp at 0 (for knife-edge flagging)
+    depth_tol: Tensor | None = None  # [G] what float32 arithmetic can move `depth` by (for knife-edge flagging: order)
 
 
 def quat_to_rotmat(q: Tensor) -> Tensor:
@@ -226,9 +227,14 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
             rgb = torch.clamp(rgb, min=0.0)                 # [3DGS-grad] gradient masked where clamped
         if capture is not None:
             capture["rgb_mask"] = (rgb_raw >= 0).to(dt)
+    with torch.no_grad():
+        # view-space z is a 4-term float32 dot product of float32 inputs with a view matrix that is itself the float32
+        # inverse of the pose: good to ~1.5 ulp of the LARGEST term, not of the result
+        depth_tol = 2e-7 * ((means3D.abs() @ Rv.abs())[:, 2] + tv[2].abs())
     return Projected(xy=xy, depth=tz, conic=conic, opacity=opacities.reshape(G),
                      rgb=rgb.to(dt), radii=radii, rect_min=rect_min, rect_max=rect_max,
-                     radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw)
+                     radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw,
+                     depth_tol=depth_tol)
 
 
 def tile_lists(pr: Projected, H: int, W: int):
@@ -323,6 +329,22 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                     # a float32 running product over <= a few thousand factors drifts by ~1e-5..1e-4 relative
                     near_T = valid & ((incl - T_MIN).abs() < 1e-3 * T_MIN) & ~stopped
                     frag = (near_alpha | near_pow | near_T).any(dim=1)
+                    # the ORDER of two entries is decided by float32 depth bits (B#10): where two of a pixel's
+                    # contributors are closer in depth than float32 resolves, either may come first -- flagged where
+                    # swapping them would move a colour channel by more than 2e-5 (T a_i a_j |c_i - c_j|)
+                    if pr.depth_tol is not None and ids.numel() > 1:
+                        zs, zt = pr.depth[ids].detach(), pr.depth_tol[ids]
+                        refused = valid & ~keep
+                        cand = keep | (refused & (torch.cumsum(refused.to(torch.int32), dim=1) == 1))
+                        a_c = torch.where(cand, alpha, torch.zeros_like(alpha))
+                        col = pr.rgb[ids].detach()
+                        for k in range(1, ids.numel()):
+                            tie = (zs[k:] - zs[:-k]) <= (zt[k:] + zt[:-k])
+                            if not bool(tie.any()):
+                                break
+                            dcol = (col[k:] - col[:-k]).abs().amax(dim=1)
+                            swap = T_excl[:, :-k] * a_c[:, :-k] * a_c[:, k:] * dcol[None, :]
+                            frag = frag | ((swap > 2e-5) & tie[None, :]).any(dim=1)
             else:
                 frag = torch.zeros(n_pix, dtype=torch.bool)
         rows_c[ty][tx] = C.reshape(TILE, TILE, 3)

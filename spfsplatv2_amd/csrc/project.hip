@@ -647,7 +647,9 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
             const Sym3 Sg = scaled(Sg0, sc * sc);
             float dp[3] = {0.f, 0.f, 0.f};
             float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const float gx = g0.x, gy = g0.y, gA = g0.z, gB = g0.w, gC = g1.x;
+            // (fields 2..4 are dL/d(a, b, c) of the 2-D covariance itself: the render backward forms them per pixel
+            //  from v = conic * offset, see spf_common.h -- no conic -> covariance step here)
+            const float gx = g0.x, gy = g0.y, da = g0.z, db = g0.w, dc = g1.x;
             const float gdepth = g2.y;
             float gcol[3] = {g1.z, g1.w, g2.x};
             dopac += g1.y;
@@ -716,12 +718,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) dt[i] += Pm[4 * i] * dhx + Pm[4 * i + 1] * dhy + Pm[4 * i + 3] * dhw;
             }
-            // ---- conic -> cov2D ----
-            const float idet = 1.0f / pr.det, id2 = idet * idet;
-            const float a = pr.a, b = pr.b, c = pr.c;
-            const float da = (-c * c * gA + b * c * gB - b * b * gC) * id2;
-            const float db = (2.f * b * c * gA - (a * c + b * b) * gB + 2.f * a * b * gC) * id2;
-            const float dc = (-b * b * gA + a * b * gB - a * a * gC) * id2;
             // ---- cov2D = M Sigma M^T ----
             const float* m0 = pr.m0; const float* m1 = pr.m1;
             dS[0] += da * m0[0] * m0[0] + db * m0[0] * m1[0] + dc * m1[0] * m1[0];

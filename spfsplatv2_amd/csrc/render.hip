@@ -610,11 +610,14 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
                     const float dL_dG = p1.y * dL_dalpha_;
                     const float sg = dL_dG * Gv;
                     r_do = Gv * dL_dalpha_;
-                    r_dx = -sg * (p0.z * dx + p0.w * dy);
-                    r_dy = -sg * (p1.x * dy + p0.w * dx);
-                    r_dA = -0.5f * sg * dx * dx;
-                    r_dB = -sg * dx * dy;
-                    r_dC = -0.5f * sg * dy * dy;
+                    // v = conic * offset; dL/d(a, b, c) of the 2-D covariance directly (spf_common.h: the classic
+                    // sum of dL/dconic cancels in float32 for a far-off-centre anisotropic splat, v does not)
+                    const float vx = p0.z * dx + p0.w * dy, vy = p1.x * dy + p0.w * dx;
+                    r_dx = -sg * vx;
+                    r_dy = -sg * vy;
+                    r_dA = -0.5f * r_dx * vx;
+                    r_dB = -r_dx * vy;
+                    r_dC = -0.5f * r_dy * vy;
                 }
                 r_dx = row_sum4(r_dx); r_dy = row_sum4(r_dy);
                 r_dA = row_sum4(r_dA); r_dB = row_sum4(r_dB); r_dC = row_sum4(r_dC);
@@ -898,8 +901,14 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             // i+1 are in flight while slot i is accumulated -- the loop is latency-, not issue-bound
             const float2* __restrict__ hp = s_pool + off;
             const float4* __restrict__ gp = s_gI + yl * kTile + xl;
-            const float dx0 = a.x - (float)(X0 + xl);
-            v2f d = {dx0, a.y - (float)(Y0 + yl)};
+            // The moments are taken about a LOCAL origin -- the box pixel nearest to the centre -- and shifted to the
+            // centre analytically at the end: offsets stay small integers whatever the distance of the centre, so the
+            // sums carry no cancellation (spf_common.h); for a centre inside its box the shift is below one pixel.
+            const float bx0 = (float)(X0 + xl), by0 = (float)(Y0 + yl);
+            const float ox = fminf(fmaxf(rintf(a.x), bx0), bx0 + (float)(bw - 1));
+            const float oy = fminf(fmaxf(rintf(a.y), by0), by0 + (float)(bh - 1));
+            const float dx0 = ox - bx0;
+            v2f d = {dx0, oy - by0};
             const int nslot = (int)size;
             float2 hn = make_float2(0.f, 0.f);
             float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -926,9 +935,24 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                 sxy = fmaf(t.x, dc.y, sxy);
             }
             const float o = b.y;   // [3DGS-grad] dL/dG = opacity * dL/dalpha (the 0.99 clamp is straight-through)
-            store_grec<DEPTH_GRAD>(gpair, pair_slot(gid), -o * (a.z * s1.x + a.w * s1.y),
-                                   -o * (b.x * s1.y + a.w * s1.x), -0.5f * o * s2.x, -o * sxy, -0.5f * o * s2.y, c2s.y,
-                                   c01.x, c01.y, c2s.x, cd);
+            // With e = origin - pixel (the loop's offsets), d0 = centre - origin, Q = conic, v = Q (d0 + e) = v0 + Q e:
+            //   sum u v = v0 M0 + Q E1,   sum u v v^T = v0 v0^T M0 + v0 (Q E1)^T + (Q E1) v0^T + Q E2 Q
+            // and dL/d(centre) = -o sum u v, dL/d(a, b, c) = o (1/2 sum u vx^2, sum u vx vy, 1/2 sum u vy^2).
+            const float M0 = c2s.y;
+            const v2f P1 = {a.z, a.w}, P2 = {a.w, b.x};                     // conic rows (A, B), (B, C)
+            const float d0x = a.x - ox, d0y = a.y - oy;
+            const v2f v0 = __builtin_elementwise_fma(P2, v2f{d0y, d0y}, P1 * v2f{d0x, d0x});
+            const v2f L = __builtin_elementwise_fma(P2, v2f{s1.y, s1.y}, P1 * v2f{s1.x, s1.x});      // Q E1
+            const v2f S1 = __builtin_elementwise_fma(v0, v2f{M0, M0}, L);
+            const v2f R0 = __builtin_elementwise_fma(P2, v2f{sxy, sxy}, P1 * v2f{s2.x, s2.x});       // rows of E2 Q
+            const v2f R1 = __builtin_elementwise_fma(P2, v2f{s2.y, s2.y}, P1 * v2f{sxy, sxy});
+            const v2f Qx = __builtin_elementwise_fma(R1, v2f{a.w, a.w}, R0 * v2f{a.z, a.z});         // (QEQ_xx, QEQ_xy)
+            const float Qyy = fmaf(b.x, R1.y, a.w * R0.y);
+            const v2f Tt = __builtin_elementwise_fma(v0, v2f{M0, M0}, L + L);
+            const float Sxx = fmaf(v0.x, Tt.x, Qx.x), Syy = fmaf(v0.y, Tt.y, Qyy);
+            const float Sxy = fmaf(v0.x, fmaf(v0.y, M0, L.y), fmaf(v0.y, L.x, Qx.y));
+            store_grec<DEPTH_GRAD>(gpair, pair_slot(gid), -o * S1.x, -o * S1.y, 0.5f * o * Sxx, o * Sxy, 0.5f * o * Syy,
+                                   M0, c01.x, c01.y, c2s.x, cd);
         }
         hi -= (uint32_t)cnt;
         __syncthreads();                         // round over: LDS scratch may be reused

@@ -24,9 +24,14 @@ inline int max_lds_tiles() {
 
 // Record layout (floats): 0 x, 1 y, 2 conic A, 3 conic B | 4 conic C, 5 opacity, 6 depth,
 // 7 cull radius^2 | 8 r, 9 g, 10 b, 11 flags (int bits: colour-channel clamp mask).
-// Gradient record (one per (Gaussian, tile) pair): 0 dx, 1 dy (pixel space), 2 dA, 3 dB, 4 dC, 5 dopacity,
+// Gradient record (one per (Gaussian, tile) pair): 0 dx, 1 dy (pixel space), 2 da, 3 db, 4 dc, 5 dopacity,
 // 6..8 drgb [, 9 ddepth]: 9 floats, 10 when the depth output has an upstream gradient -- packed (36 / 40-byte
 // stride, dword aligned), because every byte of it crosses HBM twice (render backward -> projection backward).
+// (da, db, dc) = dL/d(a, b, c) of the 2-D covariance [[a, b], [b, c]] ITSELF, not of the conic: with u = dL/dpower of
+// a pixel and v = conic * (pixel offset), da = sum 1/2 u vx^2, db = sum u vx vy, dc = sum 1/2 u vy^2.  The classic
+// route (sum dL/dconic over the pixels, then -Q G Q once per Gaussian) cancels catastrophically in float32 when the
+// centre of an anisotropic splat lies hundreds of pixels from the pixels it touches (three terms of ~1e-2 adding up
+// to ~1e-5: 1 % gradient error, found by tools/fuzz_campaign.py); v is small wherever alpha is not.
 
 typedef float f4a __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // dwordx4 access at dword alignment (legal for global memory)

@@ -136,7 +136,8 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
 
     Gates (BASELINE.json north_star): RGB within 1e-4 absolute, gradients within 1e-3 of the tensor's scale.
     Pixels the float64 oracle flags as knife-edge (an alpha within 2e-4 relative of 1/255, a transmittance
-    within 0.1% of the 1e-4 stop, a footprint radius within 1e-4 of an integer) are excluded from the RGB gate
+    within 0.1% of the 1e-4 stop, a footprint radius within 1e-4 of an integer, two contributors closer in depth
+    than float32 resolves -- their order is decided by float32 depth bits) are excluded from the RGB gate
     -- there a one-ulp difference legitimately flips a branch -- but must stay a small fraction.
     """
     frag = ref["fragile"] if ref.get("fragile") is not None else torch.zeros_like(ref["depth"], dtype=torch.bool)
@@ -166,7 +167,7 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
         fails.append("bad_frac_all")
     if rep.get("radii_mismatch", 0) > 0:
         fails.append("radii_mismatch")
-    if rep.get("radii_fragile_frac", 0.0) > 0.01:
+    if rep.get("radii_fragile_frac", 0.0) > max(0.01, 1.5 / max(ref["radii"].numel(), 1)):   # (one of a handful is no signal)
         fails.append("radii_fragile_frac")
     if rep["rgb_max"] > rgb_tol:
         fails.append("rgb_max")
