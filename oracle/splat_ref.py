@@ -319,23 +319,33 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                     # (6e-5 px at x = 500), and at the rim of a footprint d(ln alpha)/dx = A dx + B dy is ~5 per pixel
                     ex = 1.2e-7 * (gxy[None, :, 0].abs() + 0.5 * W + 1.0)
                     ey = 1.2e-7 * (gxy[None, :, 1].abs() + 0.5 * H + 1.0)
-                    win = rel + (con[None, :, 0] * dx + con[None, :, 1] * dy).abs() * ex \
-                        + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey
-                    near_alpha = ((alpha - ALPHA_MIN).abs() < win * ALPHA_MIN) & (power <= 0)
-                    # power > 0 (skipped) vs <= 0 can only flip where the three terms cancel to rounding level
+                    # ... and what evaluating the exponent itself in float32 costs: its three terms are each rounded
+                    # at THEIR size (`mag`), which for a thin splat centred hundreds of pixels away is ~1e2..1e3 while
+                    # their sum is ~ -5 (ln alpha moves by up to ~1e-4 there; negligible for ordinary footprints)
                     mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) \
                         + (con[None, :, 1] * dx * dy).abs()
+                    win = rel + (con[None, :, 0] * dx + con[None, :, 1] * dy).abs() * ex \
+                        + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey + 4e-7 * mag
+                    near_alpha = ((alpha - ALPHA_MIN).abs() < win * ALPHA_MIN) & (power <= 0)
+                    # power > 0 (skipped) vs <= 0 can only flip where the three terms cancel to rounding level
                     near_pow = power.abs() <= 1e-5 * mag
-                    # a float32 running product over <= a few thousand factors drifts by ~1e-5..1e-4 relative
-                    near_T = valid & ((incl - T_MIN).abs() < 1e-3 * T_MIN) & ~stopped
+                    # a float32 running product over <= a few thousand factors drifts by ~1e-5..1e-4 relative; the
+                    # entry that decides is the last one kept OR the first one refused
+                    refused = valid & ~keep
+                    first_refused = refused & (torch.cumsum(refused.to(torch.int32), dim=1) == 1)
+                    near_T = ((incl - T_MIN).abs() < 1e-3 * T_MIN) & (keep | first_refused)
                     frag = (near_alpha | near_pow | near_T).any(dim=1)
+                    # not a branch but a resolution limit: the same exponent rounding moves every alpha SMOOTHLY by
+                    # alpha * 4e-7 * mag; where that adds up to a visible amount no float32 evaluation of the classic
+                    # formula reaches 1e-4 (the oracle's own float32 evaluation is off by 6e-5..9e-5 on the pixels
+                    # this flags) -- only under splats centred hundreds of pixels away
+                    frag = frag | ((w.detach() * mag).sum(dim=1) * 4e-7 > 3e-5)
                     # the ORDER of two entries is decided by float32 depth bits (B#10): where two of a pixel's
                     # contributors are closer in depth than float32 resolves, either may come first -- flagged where
                     # swapping them would move a colour channel by more than 2e-5 (T a_i a_j |c_i - c_j|)
                     if pr.depth_tol is not None and ids.numel() > 1:
                         zs, zt = pr.depth[ids].detach(), pr.depth_tol[ids]
-                        refused = valid & ~keep
-                        cand = keep | (refused & (torch.cumsum(refused.to(torch.int32), dim=1) == 1))
+                        cand = keep | first_refused
                         a_c = torch.where(cand, alpha, torch.zeros_like(alpha))
                         col = pr.rgb[ids].detach()
                         for k in range(1, ids.numel()):
@@ -344,6 +354,10 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                                 break
                             dcol = (col[k:] - col[:-k]).abs().amax(dim=1)
                             swap = T_excl[:, :-k] * a_c[:, :-k] * a_c[:, k:] * dcol[None, :]
+                            # (if one of the two is the entry the 1e-4 stop refuses, the swap decides which of them
+                            #  is composited at all)
+                            at_stop = first_refused[:, k:] | first_refused[:, :-k]
+                            swap = torch.where(at_stop, T_excl[:, :-k] * torch.maximum(a_c[:, :-k], a_c[:, k:]), swap)
                             frag = frag | ((swap > 2e-5) & tie[None, :]).any(dim=1)
             else:
                 frag = torch.zeros(n_pix, dtype=torch.bool)

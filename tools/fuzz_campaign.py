@@ -23,7 +23,7 @@ from spfsplatv2_amd import rasterizer, synthetic as syn  # noqa: E402
 from tests import util  # noqa: E402
 
 
-def random_case(seed: int):
+def random_case(seed: int, wide: bool = False):
     g = torch.Generator().manual_seed(seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
     S, V = ri(1, 3), ri(1, 4)
@@ -45,6 +45,29 @@ def random_case(seed: int):
     if ri(0, 3) == 0:                                    # strong view dependence: the colour clamp fires often
         batch.harmonics[..., 1:] *= 8.0
     desc = dict(S=S, V=V, K=K, G=G, hw=hw, s_mult=s_mult, si=si, band4=band4, planned=planned)
+    if wide:
+        # a second family of draws (own generator: the plain cases keep their seeds): anisotropic, off-centre
+        # intrinsics, large camera rotations, raw (non-unit) quaternions, opacities of exactly 0 and 1, zero scales
+        w = torch.Generator().manual_seed(seed + 1_000_003)
+        ru = lambda *shape: torch.rand(*shape, generator=w)
+        batch.intrinsics[..., 0, 0] = 0.5 + 1.5 * ru(S, V)
+        batch.intrinsics[..., 1, 1] = 0.5 + 1.5 * ru(S, V)
+        batch.intrinsics[..., 0, 2] = 0.4 + 0.2 * ru(S, V)
+        batch.intrinsics[..., 1, 2] = 0.4 + 0.2 * ru(S, V)
+        big_rot = float(ru(1)) < 0.5
+        if big_rot:
+            for s_ in range(S):
+                for v_ in range(V):
+                    axis = torch.randn(3, generator=w)
+                    ang = float(ru(1)) * 3.14159
+                    batch.extrinsics[s_, v_, :3, :3] = syn._rot(axis, torch.tensor(ang)) @ batch.extrinsics[s_, v_, :3, :3]
+        batch.rotations = batch.rotations * (0.4 + 2.0 * ru(S, G, 1))
+        edge = ru(S, G)
+        batch.opacities = torch.where(edge < 0.03, torch.zeros_like(batch.opacities), batch.opacities)
+        batch.opacities = torch.where(edge > 0.97, torch.ones_like(batch.opacities), batch.opacities)
+        flat = ru(S, G, 3) < 0.02
+        batch.scales = torch.where(flat, torch.zeros_like(batch.scales), batch.scales)
+        desc.update(wide=True, big_rot=big_rot)
     return batch, bg, si, band4, planned, desc
 
 
@@ -54,6 +77,8 @@ def main():
     ap.add_argument("--count", type=int, default=200)
     ap.add_argument("--seconds", type=float, default=1e9)
     ap.add_argument("--out", default="gpurun_out/fuzz.jsonl")
+    ap.add_argument("--wide", action="store_true", help="also randomise intrinsics, camera rotation, quaternion norms, "
+                    "opacity 0 / 1 and zero scales")
     a = ap.parse_args()
     torch.set_num_threads(min(torch.get_num_threads(), 16))
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
@@ -64,7 +89,7 @@ def main():
         for seed in range(a.first, a.first + a.count):
             if time.time() - t0 > a.seconds:
                 break
-            batch, bg, si, band4, planned, desc = random_case(seed)
+            batch, bg, si, band4, planned, desc = random_case(seed, a.wide)
             try:
                 ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True,
                                       band4=band4)
