@@ -93,3 +93,40 @@ def test_vggt_rotary_embedding_dropin(hip_lib, goldens):
         B, H, N, D = tok.shape
         want = util.rope_oracle(w.transpose(1, 2).contiguous(), c["positions"], c["frequency"], -1.0).transpose(1, 2)
         assert float((tok.grad.cpu() - want).abs().max()) <= TOL, name
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_vs_c_oracle(hip_lib, seed):
+    """Seeded sweep far from the model's shapes: ragged token counts, 1..16 heads, every head size the kernel accepts
+    (multiples of 4 up to 128), q/k/v-strided and contiguous buffers, both rotation directions, two bases, positions
+    up to the thousands (|angle| ~ 1e3 rad: the float32 sincos argument reduction is what this checks)."""
+    import spfsplatv2_amd as spf
+    g = torch.Generator().manual_seed(9000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    B, N, H, D = ri(1, 5), ri(1, 700), ri(1, 16), 4 * ri(1, 32)
+    base = [100.0, 10000.0][ri(0, 1)]
+    fwd = [1.0, -1.0][ri(0, 1)]
+    pmax = [17, 40, 3000][ri(0, 2)]
+    pos = torch.randint(0, pmax + 1, (B, N, 2), generator=g)
+    strided = bool(ri(0, 1))
+    if strided:
+        qkv = torch.randn(B, N, 3, H, D, generator=g)
+        which = ri(0, 2)
+        want = util.rope_oracle(qkv[:, :, which], pos, base, fwd)
+        dev = qkv.cuda()
+        spf.rope_2d(dev[:, :, which], pos.cuda(), base, fwd)      # [B,N,H,D] view: stride(1) = 3*H*D
+        got = dev.cpu()
+        for other in range(3):
+            if other != which:
+                assert torch.equal(got[:, :, other], qkv[:, :, other])
+        got = got[:, :, which]
+    else:
+        tok = torch.randn(B, N, H, D, generator=g)
+        want = util.rope_oracle(tok, pos, base, fwd)
+        dev = tok.cuda()
+        spf.rope_2d(dev, pos.cuda(), base, fwd)
+        got = dev.cpu()
+    # angles up to 3000 rad: one float32 ulp of the angle is 2.4e-4 rad, and libm (the oracle) and the device both
+    # round pos * inv_freq before reducing it -- the gate scales with that, 1e-5 at the model's positions (<= 40)
+    tol = TOL if pmax <= 40 else 1.5e-7 * pmax * float(want.abs().max()) + TOL
+    assert float((got - want).abs().max()) <= tol, (B, N, H, D, base, fwd, pmax, strided)
