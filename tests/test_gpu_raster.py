@@ -182,3 +182,75 @@ def test_drop_in_rasterizer_surface(hip_lib):
     assert float(means2D.grad[:, 2].abs().max()) == 0.0
     assert float(means2D.grad[(radii == 0)].abs().max()) == 0.0 if bool((radii == 0).any()) else True
     assert float(means2D.grad.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rasterizer_api_random_settings(hip_lib, seed):
+    """The per-view drop-in surface away from the reference's own call pattern: `scale_modifier` != 1, an active
+    `sh_degree` below what the coefficient count allows (3DGS raises it during training), `colors_precomp` instead of
+    SH, non-square images, upstream gradients on all three differentiable outputs; vs the oracle on the same arguments
+    (knife-edge pixels are switched off in both losses)."""
+    import spfsplatv2_amd as spf
+    from oracle import glue_ref, splat_ref
+    g = torch.Generator().manual_seed(700 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    K = [1, 4, 9, 16, 25][ri(0, 4)]
+    max_deg = [0, 1, 2, 3, 3][[1, 4, 9, 16, 25].index(K)]
+    sh_degree = ri(0, max_deg)
+    use_precomp = ri(0, 3) == 0
+    smod = [0.5, 1.0, 1.7][ri(0, 2)]
+    H, W = ri(9, 80), ri(9, 100)
+    G = ri(50, 1500)
+    batch = syn.make_batch("TEST", 1, 1, seed=700 + seed, s_mult=[2.0, 10.0, 40.0][ri(0, 2)], G=G, K=K, image_hw=(H, W))
+    bg = torch.rand(1, 3, generator=g)
+    args = glue_ref.callsite_args(batch.extrinsics[:, 0], batch.intrinsics[:, 0], batch.near[:, 0], batch.far[:, 0],
+                                  batch.image_shape, bg, batch.means, batch.harmonics, batch.opacities,
+                                  batch.rotations, batch.scales)[0]
+    colors = torch.rand(G, 3, generator=g) if use_precomp else None
+    names = ["means3D", "opacities", "scales", "rotations", "viewmatrix"] + (["colors"] if use_precomp else ["shs"])
+    src = dict(args, colors=colors)
+    wd, wa = torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    tgt = batch.target[0, 0]
+
+    def loss_of(img, dep, alp, mask):
+        m = mask.to(img.dtype)
+        return (((img - tgt.to(img)) ** 2) * m).mean() + 0.01 * (dep * wd.to(dep) * m).mean() + \
+            0.1 * (alp * wa.to(alp) * m).mean()
+
+    ol = {k: src[k].double().clone().requires_grad_(True) for k in names}
+    oimg, odep, oalp, orad, frag, rfrag = splat_ref.rasterize(
+        ol["means3D"], ol["scales"], ol["rotations"], ol["opacities"], ol.get("shs"), ol.get("colors"),
+        ol["viewmatrix"], args["projmatrix"].double(), args["bg"].double(), args["tanfovx"], args["tanfovy"], H, W,
+        sh_degree, smod, want_fragile=True, want_radii_fragile=True)
+    mask = (~frag)[None]
+    lo = loss_of(oimg, odep, oalp, mask)
+    if lo.requires_grad:
+        lo.backward()
+
+    dev = "cuda"
+    leaves = {k: src[k].to(dev).clone().requires_grad_(True) for k in names}
+    means2D = torch.zeros(G, 3, device=dev, requires_grad=True)
+    settings = spf.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=args["tanfovx"], tanfovy=args["tanfovy"], bg=args["bg"].to(dev),
+        scale_modifier=smod, projmatrix=args["projmatrix"].to(dev), sh_degree=sh_degree, prefiltered=False,
+        debug=False, enable_cov_grad=True, enable_sh_grad=True)
+    image, depth, _norm, alpha, radii, _extra = spf.GaussianRasterizer(settings)(
+        means3D=leaves["means3D"], means2D=means2D, shs=leaves.get("shs"), colors_precomp=leaves.get("colors"),
+        opacities=leaves["opacities"], scales=leaves["scales"], rotations=leaves["rotations"],
+        viewmatrix=leaves["viewmatrix"])
+    loss_of(image, depth, alpha, mask.to(dev)).backward()
+
+    ok = ~frag
+    desc = dict(K=K, sh_degree=sh_degree, precomp=use_precomp, smod=smod, hw=(H, W), G=G)
+    assert float(frag.float().mean()) < 0.1, desc
+    oimg, odep, oalp = oimg.detach(), odep.detach(), oalp.detach()
+    assert float(((image.detach().cpu().double() - oimg).abs() * ok).max()) < 1e-4, desc
+    assert float(((alpha.detach().cpu().double() - oalp).abs() * ok).max()) < 1e-4, desc
+    assert float(((depth.detach().cpu().double() - odep).abs() * ok).max()) < 1e-4 * max(float(odep.max()), 1e-9), desc
+    assert int(((radii.cpu() != orad) & ~rfrag).sum()) == 0, desc
+    for k in names:
+        ref_g = ol[k].grad if ol[k].grad is not None else torch.zeros_like(ol[k])
+        if float(ref_g.abs().max()) == 0.0:
+            assert leaves[k].grad is None or float(leaves[k].grad.abs().max()) == 0.0, (k, desc)
+        else:
+            assert util.rel_linf(leaves[k].grad, ref_g) < 1e-3, (k, desc)

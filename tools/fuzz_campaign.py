@@ -23,6 +23,25 @@ from spfsplatv2_amd import rasterizer, synthetic as syn  # noqa: E402
 from tests import util  # noqa: E402
 
 
+def large_case(seed: int):
+    """Full-size scenes (the oracle needs seconds per case): 20,000 - 131,072 pixel-aligned Gaussians, images up to
+    256 x 256, lists of hundreds to thousands of entries per tile."""
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    V = ri(1, 2)
+    K = [1, 1, 4, 16, 25][ri(0, 4)]
+    G = ri(20000, 131072)
+    hw = (ri(64, 256), ri(64, 256))
+    s_mult = [0.5, 1.0, 2.0, 4.0][ri(0, 3)]
+    bg = tuple(float(x) for x in torch.rand(3, generator=g))
+    si = bool(ri(0, 1))
+    band4 = bool(ri(0, 1)) if K == 25 else False
+    planned = ri(0, 2) == 0
+    batch = syn.make_batch("REF2V", 1, V, seed=seed, s_mult=s_mult, G=G, K=K, image_hw=hw)
+    desc = dict(S=1, V=V, K=K, G=G, hw=hw, s_mult=s_mult, si=si, band4=band4, planned=planned, large=True)
+    return batch, bg, si, band4, planned, desc
+
+
 def random_case(seed: int, wide: bool = False):
     g = torch.Generator().manual_seed(seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
@@ -79,6 +98,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/fuzz.jsonl")
     ap.add_argument("--wide", action="store_true", help="also randomise intrinsics, camera rotation, quaternion norms, "
                     "opacity 0 / 1 and zero scales")
+    ap.add_argument("--large", action="store_true", help="full-size scenes instead (20k - 131k Gaussians, <= 256 x 256)")
     a = ap.parse_args()
     torch.set_num_threads(min(torch.get_num_threads(), 16))
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
@@ -89,7 +109,7 @@ def main():
         for seed in range(a.first, a.first + a.count):
             if time.time() - t0 > a.seconds:
                 break
-            batch, bg, si, band4, planned, desc = random_case(seed, a.wide)
+            batch, bg, si, band4, planned, desc = large_case(seed) if a.large else random_case(seed, a.wide)
             try:
                 ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True,
                                       band4=band4)
