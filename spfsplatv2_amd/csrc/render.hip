@@ -278,21 +278,45 @@ __device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs,
     return fmaf(dx, fmaf(Bs, dy, ux), uy * dy);
 }
 
-__device__ __forceinline__ void scatter_footprint(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2,
-                                                  int X0, int Y0) {
-    const DiscBox b = disc_box(gx, gy, r2);
-    if (!b.any) return;
-    const int xlo = (int)fmaxf((float)X0, b.xlo), xhi = (int)fminf((float)(X0 + kTile - 1), b.xhi);
-    const int ylo = (int)fmaxf((float)Y0, b.ylo), yhi = (int)fminf((float)(Y0 + kTile - 1), b.yhi);
-    uint32_t* __restrict__ wp = s_pm[i >> 5];
+// Ballot of a lane predicate as the compiler keeps it (an SGPR pair).  HIP's __ballot(int) widens the predicate to
+// 0 / 1 in a VGPR and compares it again (v_cndmask + v_cmp per call); in loops whose body is ~30 instructions that
+// round trip is 5 % of the kernel.
+__device__ __forceinline__ uint64_t lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// Phase A over a box that is already known (the backward needs the clipped box for its slot pool anyway): no second
+// disc_box (an IEEE square root), pixel offsets stepped in float.  dx, dy differ from (float)x - gx by rounding of
+// the steps only (relative 1e-7) while the disc carries 0.2 % of slack over every pixel that can reach alpha = 1/255
+// (project.hip), so the candidate set stays a superset of the contributors.
+__device__ __forceinline__ void scatter_box(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2, int X0, int Y0,
+                                            int xl, int yl, int bw, int bh) {
+    uint32_t* __restrict__ wp = s_pm[i >> 5] + yl * kTile + xl;
     const uint32_t bit = 1u << (i & 31);
-    for (int y = ylo; y <= yhi; ++y) {
-        const float dy = (float)y - gy, dy2 = dy * dy;
-        for (int x = xlo; x <= xhi; ++x) {
-            const float dx = (float)x - gx;
-            if (!(dx * dx + dy2 > r2)) atomicOr(&wp[(y - Y0) * kTile + (x - X0)], bit);
+    const float dx0 = (float)(X0 + xl) - gx;
+    float dy = (float)(Y0 + yl) - gy;
+    for (int y = 0; y < bh; ++y) {
+        const float dy2 = dy * dy;
+        float dx = dx0;
+        for (int x = 0; x < bw; ++x) {
+            if (!(fmaf(dx, dx, dy2) > r2)) atomicOr(&wp[x], bit);
+            dx += 1.f;
         }
+        dy += 1.f;
+        wp += kTile;
     }
+}
+
+// The cull disc's pixel box clipped to tile (X0, Y0): first column / row inside the tile, width, height (0: empty).
+struct TileBox { int xl, yl, bw, bh; };
+__device__ __forceinline__ TileBox clipped_box(float gx, float gy, float r2, int X0, int Y0) {
+    TileBox t = {0, 0, 0, 0};
+    const DiscBox db = disc_box_fast(gx, gy, r2);
+    if (db.any) {
+        t.xl = (int)fmaxf(db.xlo - (float)X0, 0.f);
+        t.yl = (int)fmaxf(db.ylo - (float)Y0, 0.f);
+        t.bw = max(0, (int)fminf(db.xhi - (float)X0, (float)(kTile - 1)) - t.xl + 1);
+        t.bh = max(0, (int)fminf(db.yhi - (float)Y0, (float)(kTile - 1)) - t.yl + 1);
+    }
+    return t;
 }
 
 // Lane <-> pixel assignment of the lists backward (the forward keeps the natural order: sorting its pixels by
@@ -328,8 +352,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;   // (the top bits carry the ablation code of profiling builds)
     __shared__ float4 s_p0[kStage];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
     __shared__ float4 s_p1[kStage];   // B', opacity, cull r^2, -
-    __shared__ float4 s_p2[kStage];   // r, g | b, depth
+    __shared__ float4 s_p2z[kStage + 1];   // r, g | b, depth; record 0 is all zeros (see `next` below), entry i is record i + 1
     __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
+    float4* const s_p2 = s_p2z + 1;
 
     (void)capacity;
     if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x;
+    if (tid == 0) s_p2z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int X0 = tx * kTile, Y0 = ty * kTile;
     const int px = X0 + (tid & 15), py = Y0 + (tid >> 4);
     const bool inside = px < W && py < H;
@@ -351,9 +377,12 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
 
     float Tr = 1.0f;
     v2f c01 = {0.f, 0.f}, c2d = {0.f, 0.f};      // (r, g), (b, depth) accumulators
-    uint32_t last = 0, hits = 0;
-    bool done = !inside;
-    bool wave_done = __ballot(!done) == 0;
+    uint32_t last16 = 0, hits = 0;               // 16 * (list position + 1) of the last contributor; contributors
+    // Lane predicates that live across candidates are kept as WAVE MASKS in scalar registers (`dm`: the lanes whose
+    // pixel is finished) and combined with scalar instructions; lane_ballot / inverse_ballot move between the two
+    // views for free.  As per-lane bools they cost three vector instructions per candidate.
+    uint64_t dm = lane_ballot(!inside);
+    bool wave_done = dm == ~0ull;
 
     // (candidate words: every thread keeps ITS pixel's column clear -- before the first round here, afterwards right
     // after it has consumed it -- so that staging and scatter of a round need no barrier between them)
@@ -375,62 +404,91 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
             gx = a.x; gy = a.y; r2 = b.w;
         }
-        if (!ABLATE(8) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) scatter_footprint(s_pm, tid, gx, gy, r2, X0, Y0);
+        if (!ABLATE(8) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
+            const TileBox tb = clipped_box(gx, gy, r2, X0, Y0);
+            scatter_box(s_pm, tid, gx, gy, r2, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
+        }
         __syncthreads();
         if (!wave_done && !ABLATE(8) && !ABLATE(9) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
-            int w = 0;
-            uint32_t m = done ? 0u : s_pm[0][tid];
-            // next candidate of this lane (has = false: none left; the index stays valid); lanes whose word is
-            // exhausted fetch the next word
+            const char* __restrict__ wcol = reinterpret_cast<const char*>(&s_pm[0][tid]);   // word w: wcol + 1024 w
+            uint32_t m = *reinterpret_cast<const uint32_t*>(wcol);
+            // which of the later words of this pixel's column hold a candidate at all (most are empty: a pixel has ~9
+            // candidates among the round's 256 entries); words >= nw are clear
+            uint32_t nz = 0u;
+#pragma unroll
+            for (int k = 1; k < kStage / 32; ++k)
+                nz |= min(*reinterpret_cast<const uint32_t*>(wcol + 1024 * k), 1u) << k;
+            int wb = 0;                                  // 512 * word = byte offset of entry 32 w in the staged arrays
+            // next candidate of this lane as the byte offset of its staged record.  has = false: none left -- the
+            // offset is then 16 bytes below a word's first record (v_ffbl_b32 of 0 is -1).  What is read there is only
+            // used by the colour accumulation, as colour x 0: it has to be FINITE.  It is: the record before a later
+            // word's first is an entry of this round, and in front of entry 0 s_p2 holds a record of zeros.  A refill
+            // jumps straight to the next non-empty word: no loop.
             auto next = [&](bool& has) -> int {
-                while (__ballot(m == 0u && w < nw - 1)) {
-                    if (m == 0u && w < nw - 1) {
-                        ++w;
-                        m = s_pm[w][tid];
-                    }
+                if (m == 0u && nz != 0u) {       // (a divergent `if` is skipped as a whole when no lane takes it)
+                    int w;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(w) : "v"(nz));
+                    nz &= nz - 1u;
+                    wb = w << 9;
+                    m = *reinterpret_cast<const uint32_t*>(wcol + 2 * wb);
                 }
-                has = m != 0u;
-                const int bit = has ? __builtin_ctz(m) : 0;
+                int bit;
+                asm("v_ffbl_b32 %0, %1" : "=v"(bit) : "v"(m));
+                has = bit >= 0;
                 m &= m - 1u;
-                return w * 32 + bit;
+                return wb + (bit << 4);
             };
-            auto composite = [&](bool has, int j, const float4& p0, const float4& p1, const float4& p2) {
+            const uint32_t base16 = (base + 1u) << 4;
+            // hm: the lanes that hold a candidate.  A finished pixel keeps walking its bits (its lane is masked by dm,
+            // so it neither composites nor keeps the loop alive).
+            auto composite = [&](uint64_t hm, int j, const float4& p0, const float4& p1, const float4& p2) {
                 v2f dxy;
                 const float pw = lists_power2(p0, p1.x, fxy, dxy);
                 const float alpha = fminf(kAlphaMax, p1.y * __builtin_amdgcn_exp2f(pw));
-                const bool hit = has && !done && pw <= 0.f && alpha >= kAlphaMin;
                 const float test_T = Tr * (1.f - alpha);
-                const bool stop = hit && test_T < kTMin;
-                const bool take = hit && !stop;
+                const uint64_t hitm = hm & ~dm & lane_ballot(pw <= 0.f) & lane_ballot(alpha >= kAlphaMin);
+                const uint64_t stopm = hitm & lane_ballot(test_T < kTMin);
+                dm |= stopm;
+                const bool take = __builtin_amdgcn_inverse_ballot_w64(hitm & ~stopm);
                 const float wgt = take ? alpha * Tr : 0.f;
                 const v2f ww = {wgt, wgt};
                 c01 = __builtin_elementwise_fma(v2f{p2.x, p2.y}, ww, c01);      // two v_pk_fma_f32 for (r, g | b, depth)
                 c2d = __builtin_elementwise_fma(v2f{p2.z, p2.w}, ww, c2d);
                 Tr = take ? test_T : Tr;
-                last = take ? base + (uint32_t)j + 1u : last;
-                hits += take ? 1u : 0u;
-                if (stop) { done = true; m = 0u; w = nw - 1; }
+                last16 = take ? (uint32_t)j + base16 : last16;
+                // hits += take: one add-with-carry whose carry-in is the wave mask (a select and an add otherwise)
+                uint64_t carry_out;
+                asm("v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"(hits), "=s"(carry_out) : "s"(hitm & ~stopm));
             };
+            auto rec0 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p0) + j); };
+            auto rec1 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p1) + j); };
+            auto rec2 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p2) + j); };
             // software pipeline, unrolled by two: the LDS gathers of one candidate are in flight while the other is
             // composited, and the two register sets swap roles instead of being copied
             bool ha, hb;
             int ja = next(ha), jb;
-            float4 a0 = s_p0[ja], a1 = s_p1[ja], a2 = s_p2[ja], b0, b1, b2;
+            uint64_t ma = lane_ballot(ha) & ~dm, mb;
+            float4 a0 = rec0(ja), a1 = rec1(ja), a2 = rec2(ja), b0, b1, b2;
             while (true) {
-                if (!__ballot(ha)) break;
+                if (!ma) break;
                 jb = next(hb);
-                b0 = s_p0[jb]; b1 = s_p1[jb]; b2 = s_p2[jb];
-                composite(ha, ja, a0, a1, a2);
-                if (!__ballot(hb)) break;
+                mb = lane_ballot(hb);
+                b0 = rec0(jb); b1 = rec1(jb); b2 = rec2(jb);
+                composite(ma, ja, a0, a1, a2);
+                mb &= ~dm;
+                if (!mb) break;
                 ja = next(ha);
-                a0 = s_p0[ja]; a1 = s_p1[ja]; a2 = s_p2[ja];
-                composite(hb, jb, b0, b1, b2);
+                ma = lane_ballot(ha);
+                a0 = rec0(ja); a1 = rec1(ja); a2 = rec2(ja);
+                composite(mb, jb, b0, b1, b2);
+                ma &= ~dm;
             }
-            wave_done = __ballot(!done) == 0;
+            wave_done = dm == ~0ull;
         }
         for (int w = 0; w < nw; ++w) s_pm[w][tid] = 0u;
         if (__syncthreads_and(wave_done)) break;
     }
+    const uint32_t last = last16 >> 4;
     if (inside && !(ABLATE(12) && Tr == 123.f)) {
         const float* __restrict__ bg = bg_all + 3 * r;
         const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
@@ -698,6 +756,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     __shared__ float4 s_gI[kBlock];                 // per pixel: dL/dC (rgb), dL/ddepth
     __shared__ uint32_t s_w[4];                     // per-wave scratch (max / scan totals)
     __shared__ uint32_t s_wacc[4];                  // per-wave scratch (accepted-entry counts)
+    __shared__ uint32_t s_wmax[4];                  // per-wave last contributor (read once, before the rounds)
 
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return;
@@ -763,10 +822,13 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
 
+    // (its own four words, not s_w: the first round writes s_w again with no barrier after this read, and a wave that
+    // is held up for the length of that round's gather would then take a prefix total for a list position, i.e. run
+    // with its own idea of the list's end -- seen once per ~10^6 tiles, as a barrier mismatch and a wild read)
     const uint32_t wmax = wave_max_u32(ncon);
-    if (lane == 0) s_w[wave] = wmax;
+    if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
-    const uint32_t bmax = min(n, max(max(s_w[0], s_w[1]), max(s_w[2], s_w[3])));   // (clamp: see the rows kernel)
+    const uint32_t bmax = min(n, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));   // (clamp: see the rows kernel)
     if (ABLATE(2)) { if (tail == 123.f) gpair[0] = T_final; return; }
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
         for (uint32_t idx = bmax + tid; idx < n; idx += kBlock)
@@ -790,16 +852,17 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         uint32_t gid = 0;
         int xl = 0, yl = 0, bw = 0, bh = 0;
         if (have) {
+#ifdef SPF_CHECK
+            if (hi > n || (uint64_t)beg + n > capacity) { printf("CHK stage: r %d tile %d tid %d hi %u n %u beg %u cap %llu bmax %u\n", r, tile, tid, hi, n, beg, (unsigned long long)capacity, bmax); return; }
+#endif
             gid = (uint32_t)pairs[beg + (hi - 1u - (uint32_t)tid)];
+#ifdef SPF_CHECK
+            if (gid >= (uint32_t)G) { printf("CHK gid: r %d tile %d tid %d hi %u n %u gid %u\n", r, tile, tid, hi, n, gid); return; }
+#endif
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             a = rp[0]; b = rp[1]; cc = rp[2];
-            const DiscBox db = disc_box(a.x, a.y, b.w);
-            if (db.any) {
-                xl = (int)fmaxf(db.xlo - (float)X0, 0.f);
-                yl = (int)fmaxf(db.ylo - (float)Y0, 0.f);
-                bw = max(0, (int)fminf(db.xhi - (float)X0, (float)(kTile - 1)) - xl + 1);
-                bh = max(0, (int)fminf(db.yhi - (float)Y0, (float)(kTile - 1)) - yl + 1);
-            }
+            const TileBox tb = clipped_box(a.x, a.y, b.w, X0, Y0);
+            xl = tb.xl; yl = tb.yl; bw = tb.bw; bh = tb.bh;
         }
         const uint32_t size = (uint32_t)(bw * bh);
         const uint32_t inc = wave_iscan_u32(size);      // DPP ladder: 7 VALU adds, no LDS permutes
@@ -817,13 +880,14 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
             // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + bw*ly + lx: the box width
             // and the (signed) bracket travel as integers in the two fields phase B has no other use for
-            s_p1[tid] = make_float4(kLog2e * a.w, b.y, __int_as_float(bw), b.z);
-            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, __int_as_float((int)off - yl * bw - xl));
+            // (as BYTE offsets into the pool, 8 bytes per slot: the replay then needs one v_mad_i32_i24 and one add)
+            s_p1[tid] = make_float4(kLog2e * a.w, b.y, __int_as_float(8 * bw), b.z);
+            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, __int_as_float(8 * ((int)off - yl * bw - xl)));
         }
 #pragma unroll
         for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
         // ---- phase A (the candidate words were cleared before the prefix-sum barrier above) ----
-        if (acc && !ABLATE(4)) scatter_footprint(s_pm, tid, a.x, a.y, b.w, X0, Y0);
+        if (acc && !ABLATE(4)) scatter_box(s_pm, tid, a.x, a.y, b.w, X0, Y0, xl, yl, bw, bh);
         __syncthreads();
         const int cnt = (int)(s_wacc[0] + s_wacc[1] + s_wacc[2] + s_wacc[3]);   // >= 1: one entry needs <= 256 slots
         PHASE_MARK(2);
@@ -831,29 +895,40 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         // ---- phase B: ascending bits = descending list position ----
         const int nw = (cnt + 31) >> 5;
         if (hi - (uint32_t)cnt < wmax && !ABLATE(7)) {
-            // contributors of this pixel are entries < ncon, i.e. thread indices >= hi - ncon
+            // contributors of this pixel are entries < ncon, i.e. thread indices >= hi - ncon =: jmin.  The walk starts
+            // at the word that holds bit jmin (only that word needs masking) and refills are plain loads.
             const uint32_t jmin = ncon < hi ? hi - ncon : 0u;
-            auto load_word = [&](int w) -> uint32_t {
-                const uint32_t wb = 32u * (uint32_t)w;
-                uint32_t m = s_pm[w][mypix];
-                if (jmin >= wb + 32u) m = 0u;
-                else if (jmin > wb) m &= ~((1u << (jmin - wb)) - 1u);
-                return m;
-            };
-            int w = 0;
-            uint32_t m = load_word(0);
-            auto next = [&](bool& has) -> int {      // as in the forward
-                while (__ballot(m == 0u && w < nw - 1)) {
-                    if (m == 0u && w < nw - 1) {
-                        ++w;
-                        m = load_word(w);
-                    }
+            const char* __restrict__ wcol = reinterpret_cast<const char*>(&s_pm[0][mypix]);   // word w: wcol + 1024 w
+            const int w0 = (int)min(jmin >> 5, (uint32_t)(kRoundL / 32 - 1));
+            int wb = w0 << 9;                                            // 512 * word = byte offset of entry 32 w (16 B each)
+            uint32_t m = *reinterpret_cast<const uint32_t*>(wcol + 2 * wb);
+            m = jmin < 32u * (uint32_t)nw ? m & (~0u << (jmin & 31u)) : 0u;
+            // which of the later words of this pixel's column hold a candidate at all (mean 0.7 candidates per word: most
+            // are empty); words >= nw were cleared with the rest and read as empty
+            uint32_t nz = 0u;
+#pragma unroll
+            for (int k = 1; k < kRoundL / 32; ++k)
+                nz |= min(*reinterpret_cast<const uint32_t*>(wcol + 1024 * k), 1u) << k;
+            nz &= ~1u << w0;
+            // next candidate of this lane as the byte offset of its staged record.  has = false: none left -- the
+            // offset is then 16 bytes below a word's first record (v_ffbl_b32 of 0 is -1): still inside the kernel's LDS
+            // (s_p0..2 do not start it), and what is read there is not used.  A refill jumps straight to the next
+            // non-empty word: no loop.
+            auto next = [&](bool& has) -> int {
+                if (m == 0u && nz != 0u) {       // (a divergent `if` is skipped as a whole when no lane takes it)
+                    int w;
+                    asm("v_ffbl_b32 %0, %1" : "=v"(w) : "v"(nz));
+                    nz &= nz - 1u;
+                    wb = w << 9;
+                    m = *reinterpret_cast<const uint32_t*>(wcol + 2 * wb);
                 }
-                has = m != 0u;
-                const int bit = has ? __builtin_ctz(m) : 0;
-                m &= m - 1u;
-                return w * 32 + bit;
+                int bit;
+                asm("v_ffbl_b32 %0, %1" : "=v"(bit) : "v"(m));
+                has = bit >= 0;                  // (not `m != 0`: the compiler would take that from the carry of m - 1 and
+                m &= m - 1u;                     //  then needs two more instructions to turn it into a wave mask)
+                return wb + (bit << 4);
             };
+            const int lx8 = 8 * lx;
             auto replay = [&](bool has, const float4& p0, const float4& p1, const float4& p2) {
                 const float pw = lists_power2_scalar(p0, p1.x, fx, fy);
                 const float Gv = __builtin_amdgcn_exp2f(pw);
@@ -870,22 +945,29 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                     const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));
                     const float wgt = alpha * Tr;
                     sB = fmaf(cg, wgt, sB);
-                    const int k = __mul24(__float_as_int(p1.z), ly) + (__float_as_int(p2.w) + lx);   // v_mad_i32_i24 + add
-                    s_pool[k] = make_float2(wgt, Gv * dL_dalpha_);
+                    const int k8 = __mul24(__float_as_int(p1.z), ly) + __float_as_int(p2.w) + lx8;   // v_mad_i32_i24 + add
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(s_pool) + k8) = make_float2(wgt, Gv * dL_dalpha_);
                 }
             };
+            auto rec0 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p0) + j); };
+            auto rec1 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p1) + j); };
+            auto rec2 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p2) + j); };
             // software pipeline unrolled by two (see the forward)
+            // (the loop tests are carried as wave masks -- scalar registers -- so that they cost no vector instruction)
             bool ha, hb;
             int ja = next(ha), jb;
-            float4 a0 = s_p0[ja], a1 = s_p1[ja], a2 = s_p2[ja], b0, b1, b2;
+            uint64_t ma = lane_ballot(ha), mb;
+            float4 a0 = rec0(ja), a1 = rec1(ja), a2 = rec2(ja), b0, b1, b2;
             while (true) {
-                if (!__ballot(ha)) break;
+                if (!ma) break;
                 jb = next(hb);
-                b0 = s_p0[jb]; b1 = s_p1[jb]; b2 = s_p2[jb];
+                mb = lane_ballot(hb);
+                b0 = rec0(jb); b1 = rec1(jb); b2 = rec2(jb);
                 replay(ha, a0, a1, a2);
-                if (!__ballot(hb)) break;
+                if (!mb) break;
                 ja = next(ha);
-                a0 = s_p0[ja]; a1 = s_p1[ja]; a2 = s_p2[ja];
+                ma = lane_ballot(ha);
+                a0 = rec0(ja); a1 = rec1(ja); a2 = rec2(ja);
                 replay(hb, b0, b1, b2);
             }
         }
@@ -897,8 +979,6 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             v2f c01 = {0.f, 0.f}, c2s = {0.f, 0.f};      // (dL/dr, dL/dg), (dL/db, sum u)
             v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};        // (sum u dx, sum u dy), (sum u dx^2, sum u dy^2)
             float sxy = 0.f, cd = 0.f;
-            // one flat loop over the box (row-major like its slots), software-pipelined: the two LDS reads of slot
-            // i+1 are in flight while slot i is accumulated -- the loop is latency-, not issue-bound
             const float2* __restrict__ hp = s_pool + off;
             const float4* __restrict__ gp = s_gI + yl * kTile + xl;
             // The moments are taken about a LOCAL origin -- the box pixel nearest to the centre -- and shifted to the
@@ -909,30 +989,34 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             const float oy = fminf(fmaxf(rintf(a.y), by0), by0 + (float)(bh - 1));
             const float dx0 = ox - bx0;
             v2f d = {dx0, oy - by0};
-            const int nslot = (int)size;
-            float2 hn = make_float2(0.f, 0.f);
-            float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nslot > 0) { hn = hp[0]; gn = gp[0]; }
-            int xx = 0;
-            for (int i = 0; i < nslot; ++i) {
-                const float2 h = hn;                 // (w, u) of this pixel
-                const float4 gi = gn;                // (dL/dC, dL/ddepth or 1)
-                const v2f dc = d;
-                ++xx; ++gp; d.x -= 1.f;
-                if (xx == bw) { xx = 0; gp += kTile - bw; d.x = dx0; d.y -= 1.f; }
-                if (i + 1 < nslot) { hn = hp[i + 1]; gn = *gp; }
-                const v2f hw = {h.x, h.x}, hu = {h.y, h.y}, hwu = {h.x, h.y};
-                c01 = __builtin_elementwise_fma(hw, v2f{gi.x, gi.y}, c01);
-                if (DEPTH_GRAD) {
-                    c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, 1.f}, c2s);
-                    cd = fmaf(h.x, gi.w, cd);
-                } else {
-                    c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, gi.w}, c2s);   // gi.w == 1
-                }
-                const v2f t = hu * dc;
-                s1 += t;
-                s2 = __builtin_elementwise_fma(t, dc, s2);
-                sxy = fmaf(t.x, dc.y, sxy);
+            // rows outside, columns inside: the column loop is one pointer step, one offset step and the six packed
+            // accumulations per slot (a flat loop over the box pays ~7 instructions per slot for the row wrap)
+            const float dxe = dx0 - (float)bw;
+            const int nrow = bw > 0 ? bh : 0;            // (an empty box has no column to end the inner loop on)
+            for (int y = 0; y < nrow; ++y) {
+                const float2* __restrict__ hq = hp;
+                const float4* __restrict__ gq = gp;
+                d.x = dx0;
+#pragma unroll 1
+                do {
+                    const float2 h = *hq;                // (w, u) of this pixel
+                    const float4 gi = *gq;               // (dL/dC, dL/ddepth or 1)
+                    const v2f dc = d;
+                    ++hq; ++gq; d.x -= 1.f;
+                    const v2f hw = {h.x, h.x}, hu = {h.y, h.y}, hwu = {h.x, h.y};
+                    c01 = __builtin_elementwise_fma(hw, v2f{gi.x, gi.y}, c01);
+                    if (DEPTH_GRAD) {
+                        c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, 1.f}, c2s);
+                        cd = fmaf(h.x, gi.w, cd);
+                    } else {
+                        c2s = __builtin_elementwise_fma(hwu, v2f{gi.z, gi.w}, c2s);   // gi.w == 1
+                    }
+                    const v2f t = hu * dc;
+                    s1 += t;
+                    s2 = __builtin_elementwise_fma(t, dc, s2);
+                    sxy = fmaf(t.x, dc.y, sxy);
+                } while (d.x > dxe);                     // (offsets are small integers: exact; bw >= 1 here)
+                hp += bw; gp += kTile; d.y -= 1.f;
             }
             const float o = b.y;   // [3DGS-grad] dL/dG = opacity * dL/dalpha (the 0.99 clamp is straight-through)
             // With e = origin - pixel (the loop's offsets), d0 = centre - origin, Q = conic, v = Q (d0 + e) = v0 + Q e:
@@ -951,6 +1035,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             const v2f Tt = __builtin_elementwise_fma(v0, v2f{M0, M0}, L + L);
             const float Sxx = fmaf(v0.x, Tt.x, Qx.x), Syy = fmaf(v0.y, Tt.y, Qyy);
             const float Sxy = fmaf(v0.x, fmaf(v0.y, M0, L.y), fmaf(v0.y, L.x, Qx.y));
+#ifdef SPF_CHECK
+            if (pair_slot(gid) >= capacity) { printf("CHK slot: r %d tile %d tid %d gid %u slot %u cap %llu hi %u cnt %d\n", r, tile, tid, gid, pair_slot(gid), (unsigned long long)capacity, hi, cnt); return; }
+#endif
             store_grec<DEPTH_GRAD>(gpair, pair_slot(gid), -o * S1.x, -o * S1.y, 0.5f * o * Sxx, o * Sxy, 0.5f * o * Syy,
                                    M0, c01.x, c01.y, c2s.x, cd);
         }

@@ -170,6 +170,17 @@ __device__ __forceinline__ DiscBox disc_box(float gx, float gy, float r2) {
     b.ylo = ceilf(gy - rb); b.yhi = floorf(gy + rb);
     return b;
 }
+// The same box from the hardware square root (v_sqrt_f32, 1 ulp; the IEEE-correct sqrtf costs ~15 instructions more)
+// for the render kernels, where the box only bounds a loop whose per-pixel test is exact: the 1.0001 / 1e-3 padding
+// covers the ulp.  (The projection kernel keeps disc_box: its tile rects and the binning must agree bit for bit.)
+__device__ __forceinline__ DiscBox disc_box_fast(float gx, float gy, float r2) {
+    DiscBox b;
+    b.any = r2 >= 0.f;
+    const float rb = __builtin_amdgcn_sqrtf(fmaxf(r2, 0.f)) * 1.0001f + 1e-3f;
+    b.xlo = ceilf(gx - rb); b.xhi = floorf(gx + rb);
+    b.ylo = ceilf(gy - rb); b.yhi = floorf(gy + rb);
+    return b;
+}
 // bounding-box area of the disc in pixels, capped at one tile (feeds the per-tile sparse/dense decision)
 __device__ __forceinline__ uint32_t disc_area_capped(float gx, float gy, float r2) {
     const DiscBox b = disc_box(gx, gy, r2);
