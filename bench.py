@@ -14,6 +14,11 @@ data-path collective (weak scaling: every rank gets its own 8 x 4 batch).
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- `python -m torch.distributed.run`
 on 127.0.0.1, one process per GPU, backend nccl (= RCCL) -- and rank 0 prints the line with `n_gpus: N`.
 
+Launch: one whole step is captured in a HIP graph and replayed (the step's GPU time, ~0.41 ms, is below what one
+Python thread needs to launch its kernels one by one); every 10th step of the timed region is the same step launched
+eagerly, with HIP events around the dominant kernel -- the roofline's live duration.  `--eager`: kernel-by-kernel
+launches for every step (host-bound).
+
 Timing: the `--steps` loop (EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks) is run as
 >= 25 back-to-back TRIALS adding up to >= 1 s of GPU work; `ms_per_step` / `value` are the MEDIAN trial and
 `trials_ms` keeps every trial (a single 10 ms sample was a 2 % lottery).
@@ -141,8 +146,16 @@ def parse_args(argv=None):
                          "single-GPU box together with --one-device)")
     ap.add_argument("--one-device", action="store_true", help="testing only: every rank uses cuda:0")
     ap.add_argument("--graph", action="store_true",
-                    help="capture one whole step (decoder fwd + loss + bwd) in a HIP graph and replay it "
-                         "(implies --sync-free)")
+                    help="(default now) capture one whole step (decoder fwd + loss + bwd) in a HIP graph and replay it; "
+                         "every --probe-every-th step of the timed region is launched eagerly instead, with HIP events "
+                         "around the dominant kernel")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every step kernel by kernel from Python (the default until the step's GPU time fell "
+                         "below what one Python thread needs to launch it, ~0.45 ms: eager is host-bound now); "
+                         "--exact and --allreduce imply it")
+    ap.add_argument("--probe-every", type=int, default=10,
+                    help="graph mode: every n-th step of the timed region is an eager launch with HIP events around the "
+                         "dominant kernel (the roofline's live duration); 0: none (duration from the warm-up survey)")
     ap.add_argument("--streams", type=int, default=1,
                     help="N > 1: the per-GPU batch is split by scene into N micro-batches, each captured in its own HIP "
                          "graph and replayed on its own stream, so that the latency-bound stages of one micro-batch "
@@ -227,8 +240,9 @@ def main():
 
     # the in-tree library normally travels with the tree; (re)build it if it is missing or stale (one rank per
     # node compiles, the others wait) -- a no-op when the sources' digest matches
+    # (SPF_LIB_DIR names a development variant built by hand, e.g. for tools/ab.sh: never rebuilt behind one's back)
     from spfsplatv2_amd import build as _build
-    if builder:
+    if builder and "SPF_LIB_DIR" not in os.environ:
         _build.build(verbose=False)
     if world > 1:
         dist.barrier()
@@ -254,6 +268,8 @@ def main():
         if S % args.streams or args.allreduce:
             sys.exit("bench.py: --streams N needs a scene count divisible by N (and is not combined with --allreduce)")
         args.graph = True
+    if not args.graph:          # launch mode: HIP-graph replay unless something in the step cannot be captured
+        args.graph = not (args.eager or args.exact or args.allreduce)
 
     class MicroBatch:
         """Scenes [s0, s1) of the resident batch: own leaves, own call record / pair budget, own loss share."""
@@ -325,21 +341,31 @@ def main():
         _lib.stage_timing_enable(False)
         streams = [torch.cuda.Stream(dev) for _ in micro] if len(micro) > 1 else [torch.cuda.current_stream(dev)]
         graphs = []
-        for m, st_ in zip(micro, streams):
-            for t in m.leaves.values():
-                t.grad = None
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, **({"stream": st_} if len(micro) > 1 else {})):
-                m.step()
-            graphs.append(g_)
-        if len(micro) == 1:
+        try:
+            for m, st_ in zip(micro, streams):
+                for t in m.leaves.values():
+                    t.grad = None
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, **({"stream": st_} if len(micro) > 1 else {})):
+                    m.step()
+                graphs.append(g_)
+        except Exception as e:                      # (never seen; a runtime that cannot capture still gets a number)
+            if len(micro) > 1:
+                raise
+            log(f"HIP graph capture failed ({type(e).__name__}: {e}); falling back to eager launches")
+            torch.cuda.synchronize(dev)
+            args.graph, graphs, eager_survey = False, [], None
+        if not graphs:
+            pass
+        elif len(micro) == 1:
             run = graphs[0].replay
         else:
             def run():
                 for g_, st_ in zip(graphs, streams):
                     with torch.cuda.stream(st_):
                         g_.replay()
-        log(f"step captured in {len(graphs)} HIP graph(s)")
+        if graphs:
+            log(f"step captured in {len(graphs)} HIP graph(s)")
     # warm-up doubles as the per-stage survey (HIP events around every stage); the timed region then keeps
     # events only around the dominant kernel, so the headline number is not diluted by 14 event records/step
     _lib.stage_timing_enable(True)
@@ -352,12 +378,20 @@ def main():
     dom = max(survey, key=lambda k: survey[k][0])
     _lib.stage_timing_enable(False)
 
+    # graph mode: every probe-th step is the same step launched eagerly (same kernels, same buffers' shapes, same
+    # stream) so that the library's HIP events around the dominant kernel exist inside the timed region; the host
+    # spends ~0.5 ms on it while the GPU still has the replays before it in its queue
+    probe = args.probe_every if (args.graph and len(micro) == 1 and args.probe_every > 0) else 0
+
     def trial() -> float:
         """EXACTLY --steps steps between barrier + synchronize on both sides."""
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        for i in range(args.steps):
+            if probe and i % probe == probe - 1:
+                step()
+            else:
+                run()
         barrier()
         return time.perf_counter() - t0
 
@@ -368,7 +402,8 @@ def main():
     # events around every n-th launch of the dominant kernel only (an event pair leaves the GPU idle for ~11 us):
     # at most ~1000 samples over the whole timed region (the library keeps 1024 per stage)
     _lib.stage_timing_enable([dom])
-    _lib.stage_timing_sample_every(max(4, math.ceil(n_trials * args.steps / 1000)))
+    n_event_launches = n_trials * (args.steps // probe if probe else args.steps)
+    _lib.stage_timing_sample_every(max(1 if probe else 4, math.ceil(n_event_launches / 1000)))
     trials = [trial() for _ in range(n_trials)]
     stages = _lib.stage_times()
     _lib.stage_timing_enable(False)
@@ -418,7 +453,9 @@ def main():
                        "launch": (f"{len(micro)} micro-batches of {S // len(micro)} scenes, one HIP graph and one stream "
                                   "each (kernels of the streams overlap; roofline durations are exclusive, from an "
                                   "eager survey of one micro-batch)" if len(micro) > 1 else
-                                  "hip-graph replay" if args.graph else "eager"),
+                                  (f"hip-graph replay of the whole step; every {probe}th step launched eagerly with HIP "
+                                   "events around the dominant kernel" if probe else "hip-graph replay")
+                                  if args.graph else "eager"),
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},
             "timing": {"trials": n_trials, "statistic": "median trial; each trial = exactly `steps` steps between "
