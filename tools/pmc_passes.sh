@@ -14,7 +14,7 @@ for set in "SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYC
            "SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_ACTIVE_INST_VMEM"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/p$i" -o p -- \
-      python bench.py --steps 3 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/p$i.log" 2>&1
+      python bench.py --eager --steps 3 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/p$i.log" 2>&1
 done
 CSVS=$(find "$OUT" -name '*counter_collection.csv' | sort)
 python tools/pmc_table.py $CSVS --filter "$flt" > gpurun_out/pmc_$tag.txt

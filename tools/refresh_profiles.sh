@@ -11,14 +11,14 @@ python bench.py --config C5 --no-cpu-baseline > "$OUT/bench_c5.json" 2>> "$OUT/b
 python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_ref2v.json" 2>> "$OUT/bench_c2.err"
 SPF_SH_BAND4=1 python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_ref2v_band4.json" 2>> "$OUT/bench_c2.err"
 python bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_c2_streams2.json" 2>> "$OUT/bench_c2.err"
-python bench.py --graph --no-cpu-baseline > "$OUT/bench_c2_graph.json" 2>> "$OUT/bench_c2.err"
+python bench.py --eager --no-cpu-baseline > "$OUT/bench_c2_eager.json" 2>> "$OUT/bench_c2.err"
 python tools/bench_rope.py > "$OUT/rope_bench.json" 2>> "$OUT/bench_c2.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- \
     python bench.py --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/stats.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
-    python bench.py --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
+    python bench.py --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
-    python bench.py --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+    python bench.py --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
 python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_summary.json"

@@ -142,6 +142,7 @@ def main():
 
         r_cur = rounds(192, 1536)
         replay_cost(r_cur, lambda cc: order_hits, "cur")
+        replay_cost(r_cur, lambda cc: np.arange(256), "natural")
         replay_cost(r_cur, lambda cc: np.argsort(-cc, kind="stable"), "perround")
         r_big = rounds(1 << 30, 1 << 30)
         replay_cost(r_big, lambda cc: order_hits, "whole_hits")
