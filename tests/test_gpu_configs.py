@@ -95,6 +95,38 @@ def test_full_batch_properties(hip_lib, config, S, V, min_pairs_per_render, min_
     assert bool(torch.isfinite(opac_leaf.grad).all()) and float(opac_leaf.grad.abs().max()) > 0
 
 
+def test_back_to_back_steps_are_bit_stable(hip_lib):
+    """120 planned-mode steps (decoder forward + backward) queued with no host synchronisation in between: every step
+    must reproduce the first one bit for bit.  This is what the bench's timed region does, and what exposed a
+    one-in-a-million LDS reuse race in the lists backward (a wave that ran with its own idea of the list's end: a
+    barrier mismatch, then a read of `pairs` at index -1) -- four 50-step trials out of five failed with it."""
+    import spfsplatv2_amd as spf
+    b = syn.make_batch("C2", 8, 4, seed=1000).to("cuda")
+    leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in ("means", "harmonics", "opacities", "extrinsics")}
+
+    def step(max_pairs):
+        for t in leaves.values():
+            t.grad = None
+        img, _, _ = spf.render_views(leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape,
+                                     torch.zeros(3, device="cuda"), leaves["means"], leaves["harmonics"],
+                                     leaves["opacities"], b.rotations, b.scales, enable_cov_grad=True,
+                                     enable_sh_grad=True, max_pairs=max_pairs)
+        spf.mse_loss(img, b.target).backward()
+        return img.detach(), {n: t.grad for n, t in leaves.items()}
+
+    step(None)
+    plan = spf.plan_pair_budget(spf.last_forward_stats(), check="deferred")
+    img0, g0 = step(plan)
+    last = None
+    for _ in range(120):
+        last = step(plan)
+    torch.cuda.synchronize()
+    assert spf.last_plan_flags() == 0
+    assert torch.equal(last[0], img0)
+    for n in g0:
+        assert bool(torch.isfinite(last[1][n]).all()) and torch.equal(last[1][n], g0[n]), n
+
+
 # ---- pose-only backward (test_step_align) ----------------------------------------------------------------------
 def test_pose_alignment_only_extrinsics_require_grad(hip_lib):
     """model_wrapper.py:549-588: `extrinsics = nn.Parameter(...)`, Adam(lr = test.opt_lr = 0.005), every step =
