@@ -144,6 +144,14 @@ def main():
         replay_cost(r_cur, lambda cc: order_hits, "cur")
         replay_cost(r_cur, lambda cc: np.arange(256), "natural")
         replay_cost(r_cur, lambda cc: np.argsort(-cc, kind="stable"), "perround")
+        # forward kernel: natural lane order, rounds of kStage entries front to back (no pool)
+        for KS in (256, 384, 512):
+            itf = 0
+            for lo in range(0, bmax, KS):
+                cc = candb[lo:lo + KS].sum(0)
+                for w in range(4):
+                    itf += int(cc[w * 64:(w + 1) * 64].max())
+            add(f"fwd{KS}_B", itf); add(f"fwd{KS}_rounds", (bmax + KS - 1) // KS)
         r_big = rounds(1 << 30, 1 << 30)
         replay_cost(r_big, lambda cc: order_hits, "whole_hits")
         replay_cost(r_big, lambda cc: np.argsort(-cc, kind="stable"), "whole_cand")
