@@ -193,7 +193,7 @@ def launch_ranks(args, argv: list[str]) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def valu_roofline(kernel: str, launch_ms: float, default_workload: bool):
+def valu_roofline(kernel: str, launch_ms: float, default_workload: bool, chunks: int = 1):
     """VALU-issue roofline of the dominant kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, so
     frac = wave-instructions x 4 / (CUs x SIMDs x clock x launch time).  Wave-instructions per launch come from the SQ
     counter pass committed under profiles/ (SQ_INSTS_VALU, collected on exactly the default workload)."""
@@ -201,7 +201,7 @@ def valu_roofline(kernel: str, launch_ms: float, default_workload: bool):
     if not (prof.exists() and default_workload):
         return None
     try:
-        insts = json.loads(prof.read_text())[kernel]["SQ_INSTS_VALU_per_launch"]
+        insts = json.loads(prof.read_text())[kernel]["SQ_INSTS_VALU_per_launch"] / chunks   # (counted on whole-call launches)
     except Exception:
         return None
     peak = CU_COUNT * SIMD_PER_CU * CLOCK_HZ / 4.0                 # wave-instructions / s the chip can issue
@@ -334,10 +334,12 @@ def main():
         # a replayed graph launches nothing from the host); with --streams the surveyed launches are one
         # micro-batch's, timed exclusively (in the timed region the kernels of the streams overlap)
         _lib.stage_timing_enable(True)
-        for _ in range(max(args.warmup, 3)):
+        n_survey = max(args.warmup, 3)
+        for _ in range(n_survey):
             micro[0].step()
         torch.cuda.synchronize(dev)
-        eager_survey = {k: (v[0] / v[1], 1) for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
+        # per STEP (a stage is one launch per chunk of the call, see spf_raster_chunks)
+        eager_survey = {k: (v[0] / n_survey, 1) for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
         _lib.stage_timing_enable(False)
         streams = [torch.cuda.Stream(dev) for _ in micro] if len(micro) > 1 else [torch.cuda.current_stream(dev)]
         graphs = []
@@ -420,9 +422,14 @@ def main():
         P = h * w
         renders = world * S * V
         value = renders * P * args.steps / dt / 1e6
-        dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1]
+        # the library runs a call as `chunks` launch chains of whole scenes on two streams (spf_raster_chunks): the
+        # dominant kernel is launched once per chunk, each launch processes 1/chunks of the step's units
+        lib_ = _lib.load()
+        chunk_stages = {"bin_pairs": 0, "tile_sort": 0, "render_fwd": 0, "render_bwd": 1, "project_bwd": 1}
+        chunks = lib_.spf_raster_chunks(S // len(micro), V, h, w, chunk_stages[dom]) if dom in chunk_stages else 1
+        dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1] / chunks
         # (with --streams the surveyed launch is one micro-batch's: its share of the scenes and pairs)
-        dom_bytes = stage_bytes(dom, S // len(micro), V, G, K, P, D_total // len(micro))
+        dom_bytes = stage_bytes(dom, S // len(micro), V, G, K, P, D_total // len(micro)) / chunks
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "pmc_summary.json"
@@ -464,9 +471,10 @@ def main():
             "trials_ms": [round(t * 1e3, 4) for t in trials],
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "launch_ms": round(dom_ms, 5),
+                         "traffic": None if traffic is None else traffic / chunks, "launch_ms": round(dom_ms, 5),
+                         "launches_per_step": chunks,
                          "algorithmic_bytes_per_launch": dom_bytes,
-                         "valu": valu_roofline(kernel, dom_ms, default_workload),
+                         "valu": valu_roofline(kernel, dom_ms, default_workload, chunks),
                          "path_achieved_GBs": round(A / (dt / args.steps) / 1e9, 2),
                          "path_frac_of_copy_ceiling": round(A / (dt / args.steps) / 1e9 / HBM_COPY_GBS, 5)},
             "stage_ms_per_step_warmup": {k: round(v[0] / max(args.warmup, 1), 5) for k, v in survey.items()},

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SPF_ABI_VERSION 2
+#define SPF_ABI_VERSION 3
 
 #define SPF_OK 0
 #define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
@@ -80,6 +80,13 @@ typedef struct SpfInputs {
     const float* view_scale; /* [S,V] or NULL (= 1): per-render world scale applied to means3D and scales
                                 inside the projection kernel -- the reference's scale-invariant
                                 normalisation (cuda_splatting.py:66-74) without per-view copies */
+    const double* viewmatrix64; /* [S,V,4,4] or NULL: the same world->view matrix in float64 with view_scale already
+                                folded into its first three rows, so that [p,1] @ M64 is the (rescaled) view-space
+                                position of the UNscaled mean p.  Written by spf_camera_forward / spf_decoder_prepare.
+                                The view-space position p R + t is a difference of terms ~|t| for Gaussians near the
+                                camera (after the 1/near rescale |t| is tens of units while z may be 0.2): the
+                                projection kernels form it in float64 -- from this matrix when given, else from the
+                                float32 one promoted -- and round once.  Everything else stays float32. */
 } SpfInputs;
 
 /* State written by the forward pass and read by the backward pass (owned by the caller, e.g. the
@@ -146,6 +153,7 @@ typedef struct SpfCamera {
     float* view_scale;        /* [R]     out (may be NULL): 1/near when scale_invariant else 1 */
     int32_t R;
     int32_t scale_invariant;  /* cuda_splatting.py:66-74: translation, means, scales x 1/near; near -> 1 */
+    double* viewmatrix64;     /* [R,4,4] out (may be NULL): see SpfInputs.viewmatrix64 */
 } SpfCamera;
 
 int spf_abi_version(void);
@@ -154,6 +162,15 @@ const char* spf_last_error(void);
 /* Number of tiles per render and size of the vpartial scratch. */
 int spf_raster_num_tiles(int32_t H, int32_t W);
 int spf_raster_view_partial_blocks(int32_t G);
+/* Into how many chunks of renders spf_raster_forward_render (backward = 0) / spf_raster_backward (backward = 1) split a
+ * call of S scenes x V views: after the joint tile scan the chunks run as independent launch chains alternating between
+ * the caller's stream and one auxiliary stream of the library (fork / join by events; capturable in a HIP graph), the
+ * second lane one kernel behind the first, so that the latency-bound kernels of one chunk run under the compositing
+ * kernel of another and no kernel boundary leaves the GPU idle.  Whole scenes per chunk (the backward needs that), at
+ * least 1024 tiles each, at most 4 by default; results are bit-identical to a single chain.  Environment:
+ * SPF_CHUNKS=1 disables it (exclusive per-kernel timings), SPF_CHUNKS=n forces n.  The stage timing below counts one
+ * launch per chunk. */
+int spf_raster_chunks(int32_t S, int32_t V, int32_t H, int32_t W, int32_t backward);
 
 /* Camera tensors from poses / intrinsics, and the gradient of the poses from dL/dviewmatrix
  * (dL_dviewmatrix [R,4,4] in, dL_dextrinsics [R,4,4] out; cam->viewmatrix must hold the forward result). */

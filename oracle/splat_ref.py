@@ -77,7 +77,6 @@ class Projected:
     radius_raw: Tensor  # [G] 3*sqrt(lambda_max) before ceil (for knife-edge flagging)
     rgb_raw: Tensor | None = None   # [G,3] SH colour + 0.5 BEFORE the clamp at 0 (for knife-edge flagging)
     depth_tol: Tensor | None = None  # [G] what float32 arithmetic can move `depth` by (for knife-edge flagging: order)
-    conic_tol: Tensor | None = None  # [G] RELATIVE float32 uncertainty of the conic (conditioning of a*c - b*b)
 
 
 def quat_to_rotmat(q: Tensor) -> Tensor:
@@ -232,24 +231,10 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
         # view-space z is a 4-term float32 dot product of float32 inputs with a view matrix that is itself the float32
         # inverse of the pose: good to ~1.5 ulp of the LARGEST term, not of the result
         depth_tol = 2e-7 * ((means3D.abs() @ Rv.abs())[:, 2] + tv[2].abs())
-        # the conic divides by det = a*c - b*b, which float32 (the product AND the published kernels) forms from two
-        # products of ~1e5..1e7 each for a thin splat hundreds of pixels long.  1 / det is a factor COMMON to the three
-        # conic entries, so its error scales the whole exponent: d(ln alpha) = (d det / det) * power -- measured here
-        # by forming det once more in float32 from the same Jacobian / covariance (a shadow evaluation: the product's
-        # operation order differs, hence the safety factor 4, calibrated on the three seeds)
-        conic_tol = None
-        if dt == torch.float64:
-            f32 = lambda x: x.detach().to(torch.float32)
-            M32 = f32(J) @ f32(Wcv)
-            cov32 = M32 @ f32(Sigma) @ M32.transpose(-1, -2)
-            a32, b32, c32 = cov32[:, 0, 0] + LOWPASS, cov32[:, 0, 1], cov32[:, 1, 1] + LOWPASS
-            det32 = (a32 * c32 - b32 * b32).to(dt)
-            err = (det32 / safe_det.detach() - 1.0).abs()
-            conic_tol = torch.where(ok, 4.0 * err, torch.zeros_like(err))
     return Projected(xy=xy, depth=tz, conic=conic, opacity=opacities.reshape(G),
                      rgb=rgb.to(dt), radii=radii, rect_min=rect_min, rect_max=rect_max,
                      radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw,
-                     depth_tol=depth_tol, conic_tol=conic_tol)
+                     depth_tol=depth_tol)
 
 
 def tile_lists(pr: Projected, H: int, W: int):
@@ -339,12 +324,6 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                     # their sum is ~ -5 (ln alpha moves by up to ~1e-4 there; negligible for ordinary footprints)
                     mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) \
                         + (con[None, :, 1] * dx * dy).abs()
-                    # ... and what the conic's common factor 1 / det is good to in float32 (ill-conditioned determinant of
-                    # a thin, very long splat: fuzz seeds 2135 / 2195 / 2389 of the wide family, footprints x 60 .. x 250
-                    # -- the oracle's own float32 evaluation is 4.5e-4 away from its float64 one on the first): its
-                    # relative uncertainty times the exponent (`mag` is in units of 4e-7 of the exponent)
-                    if pr.conic_tol is not None:
-                        mag = mag + (pr.conic_tol[ids][None, :] / 4e-7) * power.abs()
                     win = rel + (con[None, :, 0] * dx + con[None, :, 1] * dy).abs() * ex \
                         + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey + 4e-7 * mag
                     near_alpha = ((alpha - ALPHA_MIN).abs() < win * ALPHA_MIN) & (power <= 0)

@@ -12,7 +12,7 @@ from pathlib import Path
 
 # SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
 LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
                "project_bwd", "rope2d")
@@ -30,7 +30,7 @@ def _ptr_struct(name, fields):
 
 
 SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
-                                      "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale"])
+                                      "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
                                     "n_contrib"])
@@ -43,7 +43,8 @@ SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpai
 
 class SpfCamera(C.Structure):
     _fields_ = [(f, C.c_void_p) for f in ("extrinsics", "intrinsics", "near", "far", "viewmatrix", "projmatrix",
-                                          "tanfov", "view_scale")] + [("R", C.c_int32), ("scale_invariant", C.c_int32)]
+                                          "tanfov", "view_scale")] + [("R", C.c_int32), ("scale_invariant", C.c_int32),
+                                                                    ("viewmatrix64", C.c_void_p)]
 
 
 # Every symbol include/spfsplat_hip.h declares: name -> (restype, argtypes)
@@ -52,6 +53,7 @@ SYMBOLS = {
     "spf_last_error": (C.c_char_p, []),
     "spf_raster_num_tiles": (C.c_int, [C.c_int32, C.c_int32]),
     "spf_raster_view_partial_blocks": (C.c_int, [C.c_int32]),
+    "spf_raster_chunks": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "spf_camera_forward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p]),
     "spf_camera_backward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_void_p, C.c_void_p]),
     "spf_raster_forward_project": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),

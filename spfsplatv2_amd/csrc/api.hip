@@ -11,8 +11,8 @@ hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&,
 hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, uint64_t, hipStream_t);
 hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
-hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, hipStream_t);
-hipError_t launch_tile_sort(const SpfState&, int, uint64_t, uint32_t, hipStream_t);
+hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, uint32_t, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, int, int, uint64_t, uint32_t, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
                              uint32_t, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
@@ -84,6 +84,118 @@ struct StageScope {
     }
 };
 
+
+// ---- two lanes: one batched call as several chunks of renders on two streams ---------------------------------
+// A 32-render step of 256x256 images is a chain of ~12 dependent launches of 50-150 us each: every dependency
+// costs ~4.6 us of idle GPU, and every kernel ramps up and drains (8,192 blocks at 5 per CU).  Renders are
+// independent, so after the joint tile scan the rest of the forward (bin -> sort -> composite) and the whole backward
+// (composite backward -> projection backward) run as C chunks of whole scenes alternating between the caller's stream
+// and one auxiliary stream, the second lane one kernel behind the first: a latency-bound kernel of one chunk fills
+// the gaps and tails of the other chunk's compositing kernel.  Fork / join by events, capturable in a HIP graph;
+// every buffer is render-major, so a chunk is the same launcher on offset pointers -- results are bit-identical to
+// the single chain.  SPF_CHUNKS=1 switches it off (exclusive per-kernel timing), SPF_CHUNKS=n forces n.
+constexpr int kMaxChunks = 8;
+struct LaneSet {
+    hipStream_t s = nullptr;
+    hipEvent_t stagger = nullptr, join = nullptr;
+};
+LaneSet* lane_set() {
+    static thread_local LaneSet lanes[32];     // per (device, calling thread): see render.hip::aux_stream
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    LaneSet& a = lanes[dev];
+    if (!a.s) {
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { a.s = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&a.stagger, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamDestroy(a.s);
+            a.s = nullptr;
+            return nullptr;
+        }
+    }
+    return &a;
+}
+// Chunk boundaries in RENDERS: bounds[0..C].  Whole scenes per chunk when there are several scenes (`by_scene`),
+// else groups of views of the one scene.  A chunk keeps >= 1024 tiles.
+int plan_chunks(int S, int V, int T, int* bounds, bool* by_scene) {
+    const char* e = getenv("SPF_CHUNKS");
+    int want = e ? atoi(e) : 4;
+    if (want > kMaxChunks) want = kMaxChunks;
+    const int units = S > 1 ? S : V, per_unit = S > 1 ? V : 1;
+    *by_scene = S > 1;
+    int C = want < 1 ? 1 : want;
+    if (!e) {
+        const long tiles = (long)S * V * T;
+        while (C > 1 && tiles / C < 1024) --C;
+    }
+    if (C > units) C = units;
+    for (int c = 0; c <= C; ++c) bounds[c] = (int)(((long)units * c) / C) * per_unit;
+    return C;
+}
+struct Chunk {
+    SpfDims d;
+    SpfInputs in;
+    SpfState st;
+    SpfOutputs out;
+    SpfGrads g;
+};
+template <typename P>
+P* off(P* p, size_t n) { return p ? p + n : p; }
+// renders [r0, r1) of the batch as a call of its own.  `scene0` >= 0: the chunk is scenes [scene0, scene0 + nscene)
+// (per-scene inputs and gradients are offset too: the projection backward); < 0: tile-stage kernels only.
+Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs* out, const SpfGrads* g,
+                 int r0, int r1, int scene0, int nscene) {
+    Chunk c;
+    const size_t G = (size_t)d.G, P = (size_t)d.H * d.W;
+    const size_t T = (size_t)spf_raster_num_tiles(d.H, d.W), nblk = (size_t)spf_raster_view_partial_blocks(d.G);
+    const size_t r = (size_t)r0;
+    c.d = d;
+    if (scene0 >= 0) { c.d.S = nscene; } else { c.d.S = 1; c.d.V = r1 - r0; }
+    c.in = in;
+    c.in.viewmatrix = off(in.viewmatrix, 16 * r); c.in.projmatrix = off(in.projmatrix, 16 * r);
+    c.in.tanfov = off(in.tanfov, 2 * r); c.in.bg = off(in.bg, 3 * r); c.in.view_scale = off(in.view_scale, r);
+    c.in.viewmatrix64 = off(in.viewmatrix64, 16 * r);
+    if (scene0 >= 0) {
+        const size_t sg = (size_t)scene0 * G;
+        c.in.means3D = off(in.means3D, 3 * sg); c.in.scales = off(in.scales, 3 * sg);
+        c.in.rotations = off(in.rotations, 4 * sg); c.in.opacities = off(in.opacities, sg);
+        c.in.shs = off(in.shs, 3 * sg * (size_t)d.K); c.in.colors = off(in.colors, 3 * sg);
+    }
+    c.st = st;
+    c.st.rec = off(st.rec, r * G * spf::kRec); c.st.radii = off(st.radii, r * G); c.st.rect = off(st.rect, r * G);
+    c.st.zkey = off(st.zkey, r * G); c.st.tile_count = off(st.tile_count, r * T);
+    c.st.tile_start = off(st.tile_start, r * T); c.st.tile_fill = off(st.tile_fill, r * T);
+    c.st.tile_flags = off(st.tile_flags, r * T); c.st.pair_off = off(st.pair_off, r * G);
+    c.st.blk_total = off(st.blk_total, r * nblk); c.st.blk_base = off(st.blk_base, r * nblk);
+    c.st.final_T = off(st.final_T, r * P); c.st.n_contrib = off(st.n_contrib, 2 * r * P);
+    if (out) {
+        c.out.image = off(out->image, 3 * r * P); c.out.depth = off(out->depth, r * P);
+        c.out.alpha = off(out->alpha, r * P);
+    } else {
+        c.out = SpfOutputs{nullptr, nullptr, nullptr};
+    }
+    if (g) {
+        c.g = *g;
+        c.g.dL_dimage = off(g->dL_dimage, 3 * r * P); c.g.dL_ddepth = off(g->dL_ddepth, r * P);
+        c.g.dL_dalpha = off(g->dL_dalpha, r * P);
+        c.g.vpartial = off(g->vpartial, r * nblk * 12); c.g.dL_dviewmatrix = off(g->dL_dviewmatrix, 16 * r);
+        c.g.dL_dmeans2D = off(g->dL_dmeans2D, 3 * r * G);
+        if (scene0 >= 0) {
+            const size_t sg = (size_t)scene0 * G;
+            c.g.dL_dmeans3D = off(g->dL_dmeans3D, 3 * sg); c.g.dL_dscales = off(g->dL_dscales, 3 * sg);
+            c.g.dL_drotations = off(g->dL_drotations, 4 * sg); c.g.dL_dopacities = off(g->dL_dopacities, sg);
+            c.g.dL_dshs = off(g->dL_dshs, 3 * sg * (size_t)d.K); c.g.dL_dcolors = off(g->dL_dcolors, 3 * sg);
+        }
+    } else {
+        memset(&c.g, 0, sizeof c.g);
+    }
+    return c;
+}
+// dense-tile assumption of the whole call -> of a chunk of `rt` tiles ("none" and "all" carry over)
+uint32_t chunk_dense_hint(uint32_t hint, uint32_t RT, uint32_t rt) {
+    return hint == 0u ? 0u : (hint == RT ? rt : SPF_UNKNOWN);
+}
+
 const char* kStageKernel[SPF_STAGE_COUNT] = {
     "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_wave_kernel",
     "spf_render_fwd_lists_kernel", "spf_render_bwd_lists_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
@@ -128,6 +240,13 @@ int spf_raster_num_tiles(int32_t H, int32_t W) {
     return ((W + SPF_TILE - 1) / SPF_TILE) * ((H + SPF_TILE - 1) / SPF_TILE);
 }
 int spf_raster_view_partial_blocks(int32_t G) { return (G + spf::kBlock - 1) / spf::kBlock; }
+int spf_raster_chunks(int32_t S, int32_t V, int32_t H, int32_t W, int32_t backward) {
+    if (S < 1 || V < 1 || H < 1 || W < 1) return 1;
+    int bounds[kMaxChunks + 1];
+    bool by_scene = false;
+    const int C = plan_chunks(S, V, spf_raster_num_tiles(H, W), bounds, &by_scene);
+    return (backward && !by_scene) ? 1 : C;
+}
 
 static int check_camera(const SpfCamera* c, bool fwd) {
     if (!c) return fail(SPF_E_INVALID, "camera is null");
@@ -225,17 +344,35 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
-    {
-        StageScope t(SPF_STAGE_BIN, stream);
-        SPF_HIP(spf::launch_bin_pairs(*d, *st, capacity, T, tiles_x, max_tile_hint, dense_tiles_hint, stream));
+    int bounds[kMaxChunks + 1];
+    bool by_scene = false;
+    int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
+    LaneSet* lanes = C > 1 ? lane_set() : nullptr;
+    if (!lanes) { C = 1; bounds[0] = 0; bounds[1] = d->S * d->V; }
+    for (int c = 0; c < C; ++c) {
+        const hipStream_t cs = (c & 1) ? lanes->s : stream;
+        const Chunk ch = make_chunk(*d, *in, *st, out, nullptr, bounds[c], bounds[c + 1], -1, 0);
+        const int rt = (bounds[c + 1] - bounds[c]) * T;
+        const uint32_t dh = chunk_dense_hint(dense_tiles_hint, (uint32_t)RT, (uint32_t)rt);
+        if (c == 1) SPF_HIP(hipStreamWaitEvent(cs, lanes->stagger, 0));     // second lane: one kernel behind the first
+        {
+            StageScope t(SPF_STAGE_BIN, cs);
+            SPF_HIP(spf::launch_bin_pairs(ch.d, ch.st, capacity, T, tiles_x, max_tile_hint, dense_tiles_hint,
+                                          (uint32_t)RT, cs));
+        }
+        if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));
+        {
+            StageScope t(SPF_STAGE_SORT, cs);
+            SPF_HIP(spf::launch_tile_sort(ch.st, rt, RT, capacity, max_tile_hint, cs));
+        }
+        {
+            StageScope t(SPF_STAGE_RENDER_FWD, cs);
+            SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, dh, cs));
+        }
     }
-    {
-        StageScope t(SPF_STAGE_SORT, stream);
-        SPF_HIP(spf::launch_tile_sort(*st, RT, capacity, max_tile_hint, stream));
-    }
-    {
-        StageScope t(SPF_STAGE_RENDER_FWD, stream);
-        SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, capacity, T, tiles_x, dense_tiles_hint, stream));
+    if (C > 1) {
+        SPF_HIP(hipEventRecord(lanes->join, lanes->s));
+        SPF_HIP(hipStreamWaitEvent(stream, lanes->join, 0));
     }
     return SPF_OK;
 }
@@ -256,15 +393,35 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
-    const int T = tiles_x * tiles_y;
-    (void)capacity;   // every pair record is written exactly once by its tile: no memset of gpair
-    {
-        StageScope t(SPF_STAGE_RENDER_BWD, stream);
-        SPF_HIP(spf::launch_render_bwd(*d, *in, *st, *g, T, tiles_x, dense_tiles_hint, capacity, stream));
+    const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
+    // (every pair record is written exactly once by its tile: no memset of gpair)
+    int bounds[kMaxChunks + 1];
+    bool by_scene = false;
+    int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
+    LaneSet* lanes = (C > 1 && by_scene) ? lane_set() : nullptr;     // the projection backward owns whole scenes
+    if (!lanes) { C = 1; bounds[0] = 0; bounds[1] = d->S * d->V; }
+    for (int c = 0; c < C; ++c) {
+        const hipStream_t cs = (c & 1) ? lanes->s : stream;
+        const int s0 = bounds[c] / d->V, ns = (bounds[c + 1] - bounds[c]) / d->V;
+        const Chunk ch = C > 1 ? make_chunk(*d, *in, *st, nullptr, g, bounds[c], bounds[c + 1], s0, ns)
+                               : Chunk{*d, *in, *st, SpfOutputs{nullptr, nullptr, nullptr}, *g};
+        const int rt = (bounds[c + 1] - bounds[c]) * T;
+        const uint32_t dh = chunk_dense_hint(dense_tiles_hint, (uint32_t)RT, (uint32_t)rt);
+        if (c == 1) SPF_HIP(hipStreamWaitEvent(cs, lanes->stagger, 0));     // second lane: one kernel behind the first
+        {
+            StageScope t(SPF_STAGE_RENDER_BWD, cs);
+            SPF_HIP(spf::launch_render_bwd(ch.d, ch.in, ch.st, ch.g, T, tiles_x, dh, capacity, cs));
+        }
+        if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));
+        {
+            StageScope t(SPF_STAGE_PROJECT_BWD, cs);
+            SPF_HIP(spf::launch_project_bwd(ch.d, ch.in, ch.st, ch.g, spf_raster_view_partial_blocks(d->G), capacity,
+                                            cs));
+        }
     }
-    {
-        StageScope t(SPF_STAGE_PROJECT_BWD, stream);
-        SPF_HIP(spf::launch_project_bwd(*d, *in, *st, *g, spf_raster_view_partial_blocks(d->G), capacity, stream));
+    if (C > 1) {
+        SPF_HIP(hipEventRecord(lanes->join, lanes->s));
+        SPF_HIP(hipStreamWaitEvent(stream, lanes->join, 0));
     }
     return SPF_OK;
 }

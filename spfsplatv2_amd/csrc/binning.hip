@@ -557,20 +557,23 @@ hipError_t launch_tile_scan(const SpfState& st, int R, int T, int nblk, uint32_t
     return hipGetLastError();
 }
 
+// `dense_hint` / `RT_total`: the WHOLE call's dense-tile assumption and tile count (the plan check compares them with the
+// joint scan's census); `d` may describe a chunk of the call's renders.
 hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
-                            uint32_t max_tile_hint, uint32_t dense_hint, hipStream_t stream) {
+                            uint32_t max_tile_hint, uint32_t dense_hint, uint32_t RT_total, hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= max_lds_tiles() ? 1 : 0;
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
         st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
-        d.G, T, tiles_x, lds, max_tile_hint, dense_hint, (uint32_t)(d.S * d.V * T));
+        d.G, T, tiles_x, lds, max_tile_hint, dense_hint, RT_total);
     return hipGetLastError();
 }
 
 // Size classes: (1, 512]: one wave per tile, list in registers; (512, 1024], (1024, 2048]: one 256-thread block per tile, list in
 // registers, three LDS exchanges; (2048, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
-hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint32_t max_tile_hint,
+// `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family)
+hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t capacity, uint32_t max_tile_hint,
                             hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
@@ -579,7 +582,7 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, uint64_t capacity, uint3
     // 68 -> 60 us, 4,096 tiles of ~540 entries 69 -> 52 us with blocks; 8,192 tiles of ~540 entries 55 us with waves,
     // 65 us with blocks)
     const char* force = getenv("SPF_SORT_BLOCKS");       // (tests: "0" / "1" pin one of the two families)
-    const bool blocks = force ? force[0] == '1' : RT < 6144;
+    const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     if (mx > 1 && (mx <= 512 || blocks))  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                           capacity, 1, RT);

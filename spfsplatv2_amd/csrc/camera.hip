@@ -9,79 +9,89 @@
 
 namespace spf {
 
-__device__ __forceinline__ float det3(float a, float b, float c, float d, float e, float f, float g, float h,
-                                      float i) {
+template <typename T>
+__device__ __forceinline__ T det3(T a, T b, T c, T d, T e, T f, T g, T h, T i) {
     return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
 }
 
-// General 4x4 inverse by cofactors (row-major).  Returns false if singular.
-__device__ __forceinline__ bool inv4(const float* m, float* o) {
-    float c[16];
+// General 4x4 inverse by cofactors (row-major).  Returns false if singular.  Evaluated in float64 by the forward
+// (one lane per render: the cost is nil, and the float32 cofactor sums were only good to ~1e-6 of the translation).
+template <typename T>
+__device__ __forceinline__ bool inv4(const T* m, T* o) {
+    T c[16];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
-            float s[9];
+            T s[9];
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (i != r && j != col) s[k++] = m[4 * i + j];
-            const float minor = det3(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
+            const T minor = det3<T>(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
             c[4 * r + col] = ((r + col) & 1) ? -minor : minor;
         }
-    const float det = m[0] * c[0] + m[1] * c[1] + m[2] * c[2] + m[3] * c[3];
-    const float id = 1.0f / det;
+    const T det = m[0] * c[0] + m[1] * c[1] + m[2] * c[2] + m[3] * c[3];
+    const T id = T(1) / det;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int col = 0; col < 4; ++col) o[4 * r + col] = c[4 * col + r] * id;  // adjugate = cofactor^T
-    return det != 0.0f;
+    return det != T(0);
 }
 
-__device__ __forceinline__ void inv3(const float* m, float* o) {
-    const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-    const float id = 1.0f / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+// (float64 like the pose: tan(fov/2) scales every pixel coordinate, and a splat whose centre lies thousands of pixels
+//  outside the image -- its footprint may still cross it -- moved by 1e-3 px with the float32 acos / tan chain)
+__device__ __forceinline__ void inv3(const double* m, double* o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double id = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
     o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
     o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
     o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-__device__ __forceinline__ void unit_ray(const float* Kinv, float u, float v, float* d) {
+__device__ __forceinline__ void unit_ray(const double* Kinv, double u, double v, double* d) {
     d[0] = Kinv[0] * u + Kinv[1] * v + Kinv[2];
     d[1] = Kinv[3] * u + Kinv[4] * v + Kinv[5];
     d[2] = Kinv[6] * u + Kinv[7] * v + Kinv[8];
-    const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     d[0] /= n; d[1] /= n; d[2] /= n;
 }
 
 __device__ __forceinline__ void camera_fwd_one(const SpfCamera& c, int r) {
     float nr = c.near[r], fr = c.far[r];
     const float scale = c.scale_invariant ? 1.0f / nr : 1.0f;
-    float A[16], B[16];
+    const double scale_d = c.scale_invariant ? 1.0 / (double)nr : 1.0;
+    double A[16], B[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) A[i] = c.extrinsics[16 * r + i];
+    for (int i = 0; i < 16; ++i) A[i] = (double)c.extrinsics[16 * r + i];
     if (c.scale_invariant) {
-        A[3] *= scale; A[7] *= scale; A[11] *= scale;
+        A[3] *= scale_d; A[7] *= scale_d; A[11] *= scale_d;
         nr = nr * scale;
         fr = fr * scale;
     }
-    inv4(A, B);
+    inv4<double>(A, B);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c.viewmatrix[16 * r + 4 * i + j] = B[4 * j + i];
+        for (int j = 0; j < 4; ++j) {
+            c.viewmatrix[16 * r + 4 * i + j] = (float)B[4 * j + i];
+            // float64 copy for the projection kernels, the world scale folded into the rows that multiply the mean
+            if (c.viewmatrix64) c.viewmatrix64[16 * r + 4 * i + j] = (i < 3 ? scale_d : 1.0) * B[4 * j + i];
+        }
     // field of view from the normalised intrinsics
-    float K[9], Ki[9], l[3], rr[3], t[3], b[3];
+    double K[9], Ki[9], l[3], rr[3], t[3], b[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) K[i] = c.intrinsics[9 * r + i];
+    for (int i = 0; i < 9; ++i) K[i] = (double)c.intrinsics[9 * r + i];
     inv3(K, Ki);
-    unit_ray(Ki, 0.f, 0.5f, l); unit_ray(Ki, 1.f, 0.5f, rr);
-    unit_ray(Ki, 0.5f, 0.f, t); unit_ray(Ki, 0.5f, 1.f, b);
-    const float fov_x = acosf(l[0] * rr[0] + l[1] * rr[1] + l[2] * rr[2]);
-    const float fov_y = acosf(t[0] * b[0] + t[1] * b[1] + t[2] * b[2]);
-    const float tan_x = tanf(0.5f * fov_x), tan_y = tanf(0.5f * fov_y);
+    unit_ray(Ki, 0.0, 0.5, l); unit_ray(Ki, 1.0, 0.5, rr);
+    unit_ray(Ki, 0.5, 0.0, t); unit_ray(Ki, 0.5, 1.0, b);
+    const double fov_x = acos(l[0] * rr[0] + l[1] * rr[1] + l[2] * rr[2]);
+    const double fov_y = acos(t[0] * b[0] + t[1] * b[1] + t[2] * b[2]);
+    const double tan_xd = tan(0.5 * fov_x), tan_yd = tan(0.5 * fov_y);
+    const float tan_x = (float)tan_xd, tan_y = (float)tan_yd;
     c.tanfov[2 * r] = tan_x;
     c.tanfov[2 * r + 1] = tan_y;
     if (c.view_scale) c.view_scale[r] = scale;
@@ -90,8 +100,8 @@ __device__ __forceinline__ void camera_fwd_one(const SpfCamera& c, int r) {
     float P[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) P[i] = 0.f;
-    P[0] = 2.f * nr / (right - left);
-    P[5] = 2.f * nr / (top - bottom);
+    P[0] = (float)(1.0 / tan_xd);      // = 2 n / (right - left)
+    P[5] = (float)(1.0 / tan_yd);      // = 2 n / (top - bottom)
     P[2] = (right + left) / (right - left);
     P[6] = (top + bottom) / (top - bottom);
     P[14] = 1.f;

@@ -47,15 +47,29 @@ struct Proj {
     bool inx, iny;             // clamp inactive
     float m0[3], m1[3];        // rows of M = J * Wcv
     float J00, J02, J11, J12;
-    float a, b, c, det;        // 2-D covariance (with low-pass) and determinant
+    float a, b, c;             // 2-D covariance (with low-pass)
 };
 
-__device__ __forceinline__ void project_point(const float p[3], const float* __restrict__ Vm,
+// `p` = the mean after the per-render world scale, `p0` = before it; `M64` (may be null) = the float64 view matrix with
+// that scale folded in (SpfInputs.viewmatrix64).  The view-space position is formed in float64 and rounded once: it is
+// a difference of terms as large as the camera translation, and after the reference's 1/near rescale a Gaussian at
+// z = 0.25 sits behind a translation of tens of units -- float32 lost five digits of z there (and 1/z^2 scales the
+// whole footprint).  12 half-rate fmas per (Gaussian, view).
+__device__ __forceinline__ void project_point(const float p[3], const float p0[3], const float* __restrict__ Vm,
+                                              const double* __restrict__ M64,
                                               const float* __restrict__ Pm, float tanx, float tany,
                                               int H, int W, const Sym3& S, Proj& o) {
-    o.tx = p[0] * Vm[0] + p[1] * Vm[4] + p[2] * Vm[8] + Vm[12];
-    o.ty = p[0] * Vm[1] + p[1] * Vm[5] + p[2] * Vm[9] + Vm[13];
-    o.tz = p[0] * Vm[2] + p[1] * Vm[6] + p[2] * Vm[10] + Vm[14];
+    if (M64) {
+        const double x = p0[0], y = p0[1], z = p0[2];
+        o.tx = (float)__builtin_fma(x, M64[0], __builtin_fma(y, M64[4], __builtin_fma(z, M64[8], M64[12])));
+        o.ty = (float)__builtin_fma(x, M64[1], __builtin_fma(y, M64[5], __builtin_fma(z, M64[9], M64[13])));
+        o.tz = (float)__builtin_fma(x, M64[2], __builtin_fma(y, M64[6], __builtin_fma(z, M64[10], M64[14])));
+    } else {
+        const double x = p[0], y = p[1], z = p[2];
+        o.tx = (float)__builtin_fma(x, (double)Vm[0], __builtin_fma(y, (double)Vm[4], __builtin_fma(z, (double)Vm[8], (double)Vm[12])));
+        o.ty = (float)__builtin_fma(x, (double)Vm[1], __builtin_fma(y, (double)Vm[5], __builtin_fma(z, (double)Vm[9], (double)Vm[13])));
+        o.tz = (float)__builtin_fma(x, (double)Vm[2], __builtin_fma(y, (double)Vm[6], __builtin_fma(z, (double)Vm[10], (double)Vm[14])));
+    }
     o.homx = o.tx * Pm[0] + o.ty * Pm[4] + o.tz * Pm[8] + Pm[12];
     o.homy = o.tx * Pm[1] + o.ty * Pm[5] + o.tz * Pm[9] + Pm[13];
     const float homw = o.tx * Pm[3] + o.ty * Pm[7] + o.tz * Pm[11] + Pm[15];
@@ -91,7 +105,34 @@ __device__ __forceinline__ void project_point(const float p[3], const float* __r
     o.a = o.m0[0] * s0x + o.m0[1] * s0y + o.m0[2] * s0z + kLowPass;
     o.b = o.m0[0] * s1x + o.m0[1] * s1y + o.m0[2] * s1z;
     o.c = o.m1[0] * s1x + o.m1[1] * s1y + o.m1[2] * s1z + kLowPass;
-    o.det = o.a * o.c - o.b * o.b;
+}
+
+// det of the low-passed 2-D covariance WITHOUT the cancellation of a*c - b*b.  With N = R diag(s) the 3-D covariance
+// is N N^T, the 2-D one B B^T + 0.3 I with B = M N (2x3), and by Cauchy-Binet det(B B^T) is the sum of the squared
+// 2x2 minors of B: minor_ij(B) = s_i s_j minor_ij(M R).  Hence
+//     det = sum_{i<j} (s_i s_j minor_ij(M R))^2 + 0.3 (a0 + c0) + 0.09        (a0, c0: diagonal before the low-pass)
+// -- every term is >= 0.  For a thin splat hundreds of pixels long a*c and b*b are ~1e12 while their difference is
+// ~1e6: float32 loses the leading digits of det (any float32 evaluation of the classic expression does), and 1/det
+// scales the whole exponent of every pixel the splat touches (fuzz seeds 2135 / 2195 / 2389 of the wide family:
+// colours off by up to 2.4e-3).  This form is good to a few ulp whatever the aspect ratio.  `s*` already carry
+// scale_modifier and the per-render scale.
+__device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) {   // a*b - c*d, compensated
+    const float w = c * d;
+    const float e = fmaf(-c, d, w);
+    return fmaf(a, b, -w) + e;
+}
+__device__ __forceinline__ float stable_det(const Proj& o, const float R[9], float sx, float sy, float sz) {
+    float r0[3], r1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r0[k] = o.m0[0] * R[k] + o.m0[1] * R[3 + k] + o.m0[2] * R[6 + k];
+        r1[k] = o.m1[0] * R[k] + o.m1[1] * R[3 + k] + o.m1[2] * R[6 + k];
+    }
+    const float n01 = diff_of_products(r0[0], r1[1], r0[1], r1[0]) * (sx * sy);
+    const float n02 = diff_of_products(r0[0], r1[2], r0[2], r1[0]) * (sx * sz);
+    const float n12 = diff_of_products(r0[1], r1[2], r0[2], r1[1]) * (sy * sz);
+    const float tr0 = (o.a - kLowPass) + (o.c - kLowPass);
+    return n01 * n01 + n02 * n02 + n12 * n12 + kLowPass * tr0 + kLowPass * kLowPass;
 }
 
 // Real-SH basis function k (0..24; index n(n+1)+m, the 3DGS family's signs) at the unit direction d, optionally with
@@ -385,16 +426,18 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         const Sym3 Sg = scaled(Sg0, sc * sc);
 
         Proj pr;
-        project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
-        bool ok = live && pr.tz > kNearCull && pr.det != 0.0f;
+        project_point(p, p0, Vm, in.viewmatrix64 ? in.viewmatrix64 + 16 * r : nullptr, Pm, tanx, tany, d.H, d.W, Sg, pr);
+        const float det = stable_det(pr, R, sx * sc, sy * sc, sz * sc);
+        bool ok = live && pr.tz > kNearCull && det != 0.0f;
         float radius = 0.f;
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
         float cA = 0.f, cB = 0.f, cC = 0.f;
         if (ok) {
-            const float idet = 1.0f / pr.det;
+            const float idet = 1.0f / det;
             cA = pr.c * idet; cB = -pr.b * idet; cC = pr.a * idet;
-            const float mid = 0.5f * (pr.a + pr.c);
-            const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - pr.det));
+            // mid^2 - det = ((a - c)/2)^2 + b^2: the same quantity, again without the cancellation
+            const float mid = 0.5f * (pr.a + pr.c), hd = 0.5f * (pr.a - pr.c);
+            const float lam = mid + sqrtf(fmaxf(0.1f, hd * hd + pr.b * pr.b));
             radius = ceilf(3.0f * sqrtf(lam));
             ok = isfinite(pr.px) && isfinite(pr.py) && isfinite(radius);
             if (ok) {
@@ -707,7 +750,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 }
             }
             Proj pr;
-            project_point(p, Vm, Pm, tanx, tany, d.H, d.W, Sg, pr);
+            project_point(p, p0, Vm, in.viewmatrix64 ? in.viewmatrix64 + 16 * r : nullptr, Pm, tanx, tany, d.H, d.W, Sg, pr);
             float dt[3] = {0.f, 0.f, gdepth};  // dL/dt (view space)
 
             // ---- pixel centre -> t (through the projection matrix) ----

@@ -156,7 +156,7 @@ def _on_device_of_first_arg(fn):
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                   view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None, sh_band4=False,
-                  record=None, nothing_needs_grad=False):
+                  record=None, nothing_needs_grad=False, view64=None):
     """Launch the forward chain.  Returns (outputs, saved state tensors).  `camera` (an SpfCamera whose outputs are
     viewmatrix / projmatrix / tanfov / view_scale): the decoder fast path -- camera set-up and the clearing of the tile
     counters are one kernel."""
@@ -189,7 +189,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale))
+                         _ptr(view_scale), _ptr(view64))
     st = _state_struct(rec, radii, rect, tiles, None, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
     if camera is not None and tiles.data_ptr() % 16 == 0:
@@ -227,7 +227,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
                                              capacity, max_tile, dense, stream),
                "spf_raster_forward_render")
-    if max_pairs is not None and _plan_mode(max_pairs) == 1 and (nothing_needs_grad or not torch.is_grad_enabled()) \
+    if max_pairs is not None and _plan_mode(max_pairs) == 1 and nothing_needs_grad \
             and not torch.cuda.is_current_stream_capturing():
         # check="backward" promises that a failed plan raises -- but no backward will come (evaluation under
         # no_grad, or nothing requires grad): verify now (one host sync; eval loops should use exact mode anyway)
@@ -267,7 +267,7 @@ def _plan_mode(max_pairs) -> int:
 def _backward_impl(inputs, state, geom, grads_out, want):
     """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
     lib = _lib.load()
-    means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale = inputs
+    means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, view64 = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
     S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense, sh_layout, sh_band4 = geom
     R = S * V
@@ -296,7 +296,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     d_m2d = torch.zeros((R, G, 3), **f32) if want["means2D"] else None
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale))
+                         _ptr(view_scale), _ptr(view64))
     st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(gpair), _ptr(vpartial),
                        _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
@@ -310,19 +310,21 @@ class _RasterizeBatch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                 view_scale, H, W, sh_degree, scale_modifier, enable_cov_grad, enable_sh_grad, means2D, max_pairs,
-                sh_band4, record):
+                sh_band4, record, grad_mode):
+        # `grad_mode`: torch.is_grad_enabled() AT THE CALL SITE (inside Function.forward it is always False, and
+        # ctx.needs_input_grad stays True under no_grad): a backward will come only if both say so
         ctx.set_materialize_grads(False)
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix,
                                            projmatrix, tanfov, bg, view_scale, H, W, sh_degree, scale_modifier,
                                            max_pairs, sh_band4=sh_band4, record=record,
-                                           nothing_needs_grad=not any(ctx.needs_input_grad))
+                                           nothing_needs_grad=not (grad_mode and any(ctx.needs_input_grad)))
         S, G, _ = means3D.shape
         ctx.geom = (S, viewmatrix.shape[1], G, 0 if shs is None else shs.shape[2], sh_degree, H, W,
                     float(scale_modifier), _plan_mode(max_pairs), dense, 0, bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad))
         ctx.means2D_shape = None if means2D is None else tuple(means2D.shape)
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix,
-                              tanfov, bg, view_scale, *state)
+                              tanfov, bg, view_scale, None, *state)
         ctx.mark_non_differentiable(outs[3])
         return outs
 
@@ -334,11 +336,11 @@ class _RasterizeBatch(torch.autograd.Function):
         want = dict(scales_rot=enable_cov_grad and (need[1] or need[2]), shs=enable_sh_grad and need[4],
                     colors=need[5], view=need[6], means2D=ctx.means2D_shape is not None and need[17])
         d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, d_m2d = _backward_impl(
-            saved[:11], saved[11:], ctx.geom, (g_image, g_depth, g_alpha), want)
+            saved[:12], saved[12:], ctx.geom, (g_image, g_depth, g_alpha), want)
         if d_m2d is not None:
             d_m2d = d_m2d.view(ctx.means2D_shape)
         return (d_means, d_scales, d_rot, d_opac, d_shs, d_col, d_view, None, None, None, None,
-                None, None, None, None, None, None, d_m2d, None, None, None)
+                None, None, None, None, None, None, d_m2d, None, None, None, None)
 
 
 class _DecoderRender(torch.autograd.Function):
@@ -348,7 +350,7 @@ class _DecoderRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
                 H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout, sh_band4,
-                record):
+                record, grad_mode):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         S, V = extrinsics.shape[:2]
@@ -358,18 +360,22 @@ class _DecoderRender(torch.autograd.Function):
         proj = torch.empty((S, V, 4, 4), **f32)
         tanfov = torch.empty((S, V, 2), **f32)
         vscale = torch.empty((S, V), **f32) if scale_invariant else None
+        # the pose once more in float64, world scale folded in: the projection kernels form the view-space position
+        # from it (SpfInputs.viewmatrix64)
+        view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
-                             _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0)
+                             _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0, _ptr(view64))
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
                                            bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam,
                                            sh_band4=sh_band4, record=record,
-                                           nothing_needs_grad=not any(ctx.needs_input_grad))
+                                           nothing_needs_grad=not (grad_mode and any(ctx.needs_input_grad)),
+                                           view64=view64)
         G = means3D.shape[1]
         K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
         ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout), bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
-                              *state, near)
+                              view64, *state, near)
         ctx.mark_non_differentiable(outs[3])
         return outs
 
@@ -382,10 +388,10 @@ class _DecoderRender(torch.autograd.Function):
         want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
                     colors=need[9], view="partials" if need[0] else False, means2D=False)
         d_means, d_scales, d_rot, d_opac, d_shs, d_col, vpartial, _ = _backward_impl(
-            saved[:11], saved[11:19], ctx.geom, (g_image, g_depth, g_alpha), want)
+            saved[:12], saved[12:20], ctx.geom, (g_image, g_depth, g_alpha), want)
         d_ext = None
         if need[0]:
-            view, near = saved[6], saved[19]
+            view, near = saved[6], saved[20]
             d_ext = torch.empty_like(view)
             cam = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(view), None, None, None,
                                  view.shape[0] * view.shape[1], 1 if scale_invariant else 0)
@@ -394,7 +400,7 @@ class _DecoderRender(torch.autograd.Function):
                                                             _ptr(d_ext), _stream_ptr(view.device)),
                            "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
@@ -460,7 +466,7 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
                                 bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0,
-                                bool(sh_band4), record)
+                                bool(sh_band4), record, torch.is_grad_enabled())
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,
@@ -527,7 +533,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     return _RasterizeBatch.apply(means3D, scales, rotations, opacities, shs, colors_precomp, viewmatrix,
                                  projmatrix, tanfov, bg, view_scale, int(image_height), int(image_width),
                                  int(sh_degree), float(scale_modifier), enable_cov_grad, enable_sh_grad, means2D,
-                                 max_pairs, bool(sh_band4), record)
+                                 max_pairs, bool(sh_band4), record, torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ def test_header_symbols_all_exported(hip_lib):
 def test_struct_sizes_match_header():
     from spfsplatv2_amd import _lib
     assert C.sizeof(_lib.SpfDims) == 40
-    assert C.sizeof(_lib.SpfInputs) == 11 * 8
+    assert C.sizeof(_lib.SpfInputs) == 12 * 8
     assert C.sizeof(_lib.SpfState) == 15 * 8
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
     assert C.sizeof(_lib.SpfGrads) == 13 * 8

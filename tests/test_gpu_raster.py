@@ -254,3 +254,37 @@ def test_rasterizer_api_random_settings(hip_lib, seed):
             assert leaves[k].grad is None or float(leaves[k].grad.abs().max()) == 0.0, (k, desc)
         else:
             assert util.rel_linf(leaves[k].grad, ref_g) < 1e-3, (k, desc)
+
+
+def test_planned_backward_mode_does_not_sync_in_forward(hip_lib):
+    """`PairBudget(check="backward")` (the default) promises that the forward waits for nothing: the plan is verified
+    when the backward runs.  (torch.is_grad_enabled() is False INSIDE autograd.Function.forward, so the mode must be
+    sampled at the call site -- round 2 read it inside and synchronised on every training step.)  Under `no_grad` no
+    backward will come and the forward itself verifies the plan: there the sync is the contract."""
+    import spfsplatv2_amd as spf
+    kw, bg, si = CASES["k4_multiview"]
+    batch = syn.make_batch(**kw)
+    exact = util.run_product(batch, background=bg, scale_invariant=si)
+    plan = spf.plan_pair_budget(exact["stats"], slack=1.25, check="backward")
+    bd = batch.to("cuda")
+    d = util.product_decoder(bg, si, "cuda", plan, None)
+    from spfsplatv2_amd import decoder as dec
+    leaves = {n: getattr(bd, n).detach().clone().requires_grad_(True) for n in util.GRAD_NAMES}
+    g = dec.Gaussians(leaves["means"], bd.covariances, leaves["rotations"], leaves["scales"], leaves["harmonics"],
+                      leaves["opacities"])
+    d.forward(g, leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)      # warm-up (allocator, caches)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = d.forward(g, leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    out.color.mean().backward()                              # the plan is verified here
+    assert torch.equal(out.color.detach().cpu(), exact["color"])
+    with torch.no_grad():
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            with pytest.raises(RuntimeError):                # the verification read-back is a synchronising call
+                d.forward(g, leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")

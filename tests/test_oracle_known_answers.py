@@ -1,0 +1,57 @@
+"""The rasterizer oracle reproduces its own frozen values (tests/golden/oracle_known_answers.pt, written by
+tests/golden/make_oracle_known_answers.py).
+
+The oracle is parity-unpinned (no reference binary, no reference-held vector for this path), so what keeps the parity
+claims honest is that the checker does not move towards the kernels: any edit of oracle/splat_ref.py or
+oracle/glue_ref.py that changes a VALUE (1e-12) or a knife-edge MASK (exactly) fails here until the fixture is
+regenerated -- which then shows in the history.
+"""
+import pytest
+import torch
+
+from spfsplatv2_amd import synthetic as syn
+from tests import util
+
+FIX = "oracle_known_answers.pt"
+
+
+def load_case(golden_dir, name):
+    case = torch.load(golden_dir / FIX)[name]
+    batch = syn.Batch(image_shape=tuple(case["image_shape"]), **case["inputs"])
+    return case, batch
+
+
+CASES = ("c1", "test_k4_two_views", "test_k25_band4_nosi", "test_k16_long_splats_wide")
+
+
+def test_fixture_lists_the_cases(golden_dir):
+    assert tuple(torch.load(golden_dir / FIX).keys()) == CASES
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_its_frozen_values(golden_dir, name):
+    case, batch = load_case(golden_dir, name)
+    want = case["expect"]
+    got = util.run_oracle(batch, torch.float64, background=case["background"], scale_invariant=case["scale_invariant"],
+                          mask_fragile=True, band4=case["band4"])
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-300))
+    for k in ("color", "depth", "alpha"):
+        assert rel(got[k], want[k]) < 1e-12, (name, k)
+    assert torch.equal(got["radii"], want["radii"]), name
+    assert torch.equal(got["fragile"], want["fragile"]), (name, "a knife-edge flag changed")
+    assert torch.equal(got["radii_fragile"], want["radii_fragile"]), (name, "a radii knife-edge flag changed")
+    assert abs(got["loss"] - want["loss"]) < 1e-12 * abs(want["loss"]), name
+    for k, g in want["grads"].items():
+        assert rel(got["grads"][k], g) < 1e-11, (name, k)           # (sums over thousands of pixels: order of addition)
+
+
+def test_float32_oracle_agrees_with_the_frozen_float64_values(golden_dir):
+    """The float32 evaluation of the same restatement (what bench.py's cpu_baseline times) lands within the parity
+    tolerances of the frozen float64 values off the flagged pixels: the tolerances are achievable in float32."""
+    case, batch = load_case(golden_dir, "c1")
+    want = case["expect"]
+    got = util.run_oracle(batch, torch.float32, background=case["background"], scale_invariant=case["scale_invariant"],
+                          want_fragile=False, with_grads=False)
+    ok = ~want["fragile"]
+    assert float(((got["color"].double() - want["color"]).abs() * ok[:, :, None]).max()) < 1e-4
+    assert float(((got["alpha"].double() - want["alpha"]).abs() * ok[:, :, None]).max()) < 1e-4

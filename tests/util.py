@@ -65,10 +65,11 @@ def scalar_loss(color, depth_bvhw, alpha_bv1hw, target, wd, wa, mask=None):
 
 
 def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_invariant=True, want_fragile=True,
-               with_grads=True, mask_fragile=False, band4=False, grad_names=GRAD_NAMES):
+               with_grads=True, mask_fragile=False, band4=False, grad_names=GRAD_NAMES, pixel_mask=None):
     """`mask_fragile`: the loss ignores the pixels the oracle flags as knife-edge; the mask comes back as
     res["pixel_mask"] for `run_product(..., pixel_mask=...)`.  `grad_names`: the inputs that require grad (the others
-    are constants, e.g. only "extrinsics" for the reference's test-time pose alignment)."""
+    are constants, e.g. only "extrinsics" for the reference's test-time pose alignment).  `pixel_mask`: use THIS mask
+    in the loss (a float32 evaluation of the oracle held against the float64 one's mask: `float32_resolvable`)."""
     from oracle import glue_ref
     leaves = {n: getattr(batch, n).detach().clone().to(dtype).requires_grad_(with_grads and n in grad_names)
               for n in GRAD_NAMES}
@@ -83,7 +84,7 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
                fragile=out[4] if want_fragile else None, radii_fragile=out[5] if want_fragile else None)
     if with_grads:
         wd, wa = loss_weights(batch)
-        mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else None
+        mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else pixel_mask
         res["pixel_mask"] = mask
         loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype), mask)
         if loss.requires_grad:               # (nothing visible in any view: the loss is a constant)
@@ -179,4 +180,16 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
         if rep.get("g_" + n, 0.0) > grad_tol:
             fails.append("g_" + n)
     rep["fails"] = fails
+    return rep
+
+
+def float32_resolvable(batch, ref: dict, **kw) -> dict:
+    """Second arbiter, for cases that fail `compare`: the SAME restatement of the published algorithm evaluated in
+    float32 on the CPU (oracle/splat_ref.py is dtype-generic), held against the float64 values through the same gates
+    with the same pixel mask.  If a plain float32 evaluation of the classic formulas cannot meet the tolerances on an
+    input, a float64 oracle cannot decide parity with a float32 reference there: the case is `unresolvable`, and is
+    reported as such, with both errors -- it is not counted as agreement and no flag of the oracle is involved."""
+    f32 = run_oracle(batch, torch.float32, want_fragile=False, pixel_mask=ref.get("pixel_mask"), **kw)
+    f32["radii"] = None
+    rep = compare(f32, ref, max_fragile_frac=1.0)
     return rep

@@ -103,7 +103,7 @@ def main():
     torch.set_num_threads(min(torch.get_num_threads(), 16))
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
     t0 = time.time()
-    n = bad = vague = 0
+    n = bad = vague = unres = 0
     worst = {}
     with open(a.out, "w") as f:
         for seed in range(a.first, a.first + a.count):
@@ -124,11 +124,21 @@ def main():
             except Exception:                           # noqa: BLE001 -- a crash is a finding too
                 rep = {"fails": ["exception"], "trace": traceback.format_exc()[-1500:]}
             n += 1
+            if rep["fails"] and "exception" not in rep["fails"] and not set(rep["fails"]) <= {"fragile_frac", "radii_fragile_frac"}:
+                # second arbiter: does a plain float32 evaluation of the oracle's own formulas meet the gates here?
+                try:
+                    r32 = util.float32_resolvable(batch, ref, background=bg, scale_invariant=si, band4=band4)
+                    rep["oracle_f32"] = {k: v for k, v in r32.items() if k.startswith(("g_", "rgb", "alpha", "depth", "fails"))}
+                    rep["unresolvable"] = set(rep["fails"]) <= set(r32["fails"])      # EVERY gate the product fails
+                except Exception:                       # noqa: BLE001
+                    rep["oracle_f32"] = {"fails": ["exception"]}
             # too many knife-edge pixels for the oracle to arbitrate (tiny images under splats hundreds of pixels
             # wide): the case says nothing either way -- counted apart from real disagreements
             if rep["fails"] and set(rep["fails"]) <= {"fragile_frac", "radii_fragile_frac"}:
                 rep["inconclusive"] = True
                 vague += 1
+            elif rep.get("unresolvable"):
+                unres += 1
             else:
                 bad += bool(rep["fails"])
             for k, v in rep.items():
@@ -136,7 +146,7 @@ def main():
                     worst[k] = max(worst.get(k, 0.0), v)
             f.write(json.dumps({"seed": seed, "desc": desc, **rep}) + "\n")
             f.flush()
-        summary = {"summary": True, "cases": n, "failed": bad, "inconclusive": vague, "seconds": round(time.time() - t0, 1), "worst": worst}
+        summary = {"summary": True, "cases": n, "failed": bad, "inconclusive": vague, "float32_unresolvable": unres, "seconds": round(time.time() - t0, 1), "worst": worst}
         f.write(json.dumps(summary) + "\n")
     print(json.dumps(summary))
 
