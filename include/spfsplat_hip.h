@@ -163,13 +163,11 @@ const char* spf_last_error(void);
 int spf_raster_num_tiles(int32_t H, int32_t W);
 int spf_raster_view_partial_blocks(int32_t G);
 /* Into how many chunks of renders spf_raster_forward_render (backward = 0) / spf_raster_backward (backward = 1) split a
- * call of S scenes x V views: after the joint tile scan the chunks run as independent launch chains alternating between
- * the caller's stream and one auxiliary stream of the library (fork / join by events; capturable in a HIP graph), the
- * second lane one kernel behind the first, so that the latency-bound kernels of one chunk run under the compositing
- * kernel of another and no kernel boundary leaves the GPU idle.  Whole scenes per chunk (the backward needs that), at
- * least 1024 tiles each, at most 4 by default; results are bit-identical to a single chain.  Environment:
- * SPF_CHUNKS=1 disables it (exclusive per-kernel timings), SPF_CHUNKS=n forces n.  The stage timing below counts one
- * launch per chunk. */
+ * call of S scenes x V views.  1 unless the environment says SPF_CHUNKS=n: then, after the joint tile scan, the chunks
+ * (whole scenes each) run as independent launch chains alternating between the caller's stream and one auxiliary stream
+ * of the library (fork / join by events; capturable in a HIP graph); results are bit-identical to the single chain and
+ * the stage timing below counts one launch per chunk.  Measured slower than the single chain on MI355X (see api.hip),
+ * hence off by default. */
 int spf_raster_chunks(int32_t S, int32_t V, int32_t H, int32_t W, int32_t backward);
 
 /* Camera tensors from poses / intrinsics, and the gradient of the poses from dL/dviewmatrix

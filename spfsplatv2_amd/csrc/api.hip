@@ -85,15 +85,19 @@ struct StageScope {
 };
 
 
-// ---- two lanes: one batched call as several chunks of renders on two streams ---------------------------------
-// A 32-render step of 256x256 images is a chain of ~12 dependent launches of 50-150 us each: every dependency
-// costs ~4.6 us of idle GPU, and every kernel ramps up and drains (8,192 blocks at 5 per CU).  Renders are
-// independent, so after the joint tile scan the rest of the forward (bin -> sort -> composite) and the whole backward
-// (composite backward -> projection backward) run as C chunks of whole scenes alternating between the caller's stream
-// and one auxiliary stream, the second lane one kernel behind the first: a latency-bound kernel of one chunk fills
-// the gaps and tails of the other chunk's compositing kernel.  Fork / join by events, capturable in a HIP graph;
-// every buffer is render-major, so a chunk is the same launcher on offset pointers -- results are bit-identical to
-// the single chain.  SPF_CHUNKS=1 switches it off (exclusive per-kernel timing), SPF_CHUNKS=n forces n.
+// ---- two lanes: one batched call as several chunks of renders on two streams (OFF by default) -----------------
+// Renders are independent, so after the joint tile scan the rest of the forward (bin -> sort -> composite) and the whole
+// backward (composite backward -> projection backward) can run as C chunks of whole scenes alternating between the
+// caller's stream and one auxiliary stream, the second lane one kernel behind the first (fork / join by events,
+// capturable in a HIP graph; every buffer is render-major, so a chunk is the same launcher on offset pointers and the
+// results are bit-identical to the single chain: tests/test_gpu_configs.py).  The idea: a latency-bound kernel of one
+// chunk fills the launch gaps and tails of the other chunk's compositing kernel, as two whole-step micro-batches on two
+// streams do (bench.py --streams 2: +13 %).  MEASURED (C2, 8 x 4 renders, HIP-graph replay, same box, ms per step):
+// 1 chain 0.442 / 0.443, 2 chunks 0.472 / 0.464, 4 chunks 0.514 / 0.508, 8 chunks 0.578 / 0.568 -- it LOSES.  A call must
+// hand complete outputs to the caller's stream, so every forward and every backward ends in a join at which both lanes
+// drain, half-size launches have twice the tail, and the cross-queue event edges cost as much as the dependent
+// launches they were meant to hide; free-running micro-batches never join.  SPF_CHUNKS=n (n > 1) enables it for
+// experiments; the default is the single chain, whose per-kernel timings are exclusive.
 constexpr int kMaxChunks = 8;
 struct LaneSet {
     hipStream_t s = nullptr;
@@ -119,7 +123,7 @@ LaneSet* lane_set() {
 // else groups of views of the one scene.  A chunk keeps >= 1024 tiles.
 int plan_chunks(int S, int V, int T, int* bounds, bool* by_scene) {
     const char* e = getenv("SPF_CHUNKS");
-    int want = e ? atoi(e) : 4;
+    int want = e ? atoi(e) : 1;
     if (want > kMaxChunks) want = kMaxChunks;
     const int units = S > 1 ? S : V, per_unit = S > 1 ? V : 1;
     *by_scene = S > 1;

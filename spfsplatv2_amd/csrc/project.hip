@@ -10,9 +10,14 @@
 
 namespace spf {
 
-struct Sym3 {  // symmetric 3x3
-    float xx, xy, xz, yy, yz, zz;
-};
+// Camera tables (view / projection matrix, tan fov, scale of a render) are the same for every thread of a block and
+// were written by an EARLIER launch: read through the constant address space they become scalar loads into SGPRs.
+// Through an ordinary pointer the compiler cannot rule out that the kernel's own stores alias them and falls back to
+// per-lane vector loads -- 44 floats and 12 doubles per view in VGPRs (the float64 pose alone cost one wave per SIMD).
+typedef const float __attribute__((address_space(4))) * kfloat_p;
+typedef const double __attribute__((address_space(4))) * kdouble_p;
+__device__ __forceinline__ kfloat_p as_const(const float* p) { return (kfloat_p)(uintptr_t)p; }
+__device__ __forceinline__ kdouble_p as_const(const double* p) { return (kdouble_p)(uintptr_t)p; }
 
 __device__ __forceinline__ void quat_rot(const float4 q, float R[9]) {
     const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -21,21 +26,13 @@ __device__ __forceinline__ void quat_rot(const float4 q, float R[9]) {
     R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
 }
 
-// Sigma = R diag(s^2) R^T
-__device__ __forceinline__ Sym3 cov3d(const float R[9], float sx, float sy, float sz) {
-    const float a = sx * sx, b = sy * sy, c = sz * sz;
-    Sym3 S;
-    S.xx = R[0] * R[0] * a + R[1] * R[1] * b + R[2] * R[2] * c;
-    S.xy = R[0] * R[3] * a + R[1] * R[4] * b + R[2] * R[5] * c;
-    S.xz = R[0] * R[6] * a + R[1] * R[7] * b + R[2] * R[8] * c;
-    S.yy = R[3] * R[3] * a + R[4] * R[4] * b + R[5] * R[5] * c;
-    S.yz = R[3] * R[6] * a + R[4] * R[7] * b + R[5] * R[8] * c;
-    S.zz = R[6] * R[6] * a + R[7] * R[7] * b + R[8] * R[8] * c;
-    return S;
-}
-
-__device__ __forceinline__ Sym3 scaled(const Sym3& S, float k) {
-    return Sym3{S.xx * k, S.xy * k, S.xz * k, S.yy * k, S.yz * k, S.zz * k};
+// N = R diag(s): the 3-D covariance is N N^T and is never formed.  With M = J W (2x3) the 2-D
+// covariance is B B^T + 0.3 I, B = M N: its entries are dot products of the rows of B and its determinant is the sum of
+// the squared 2x2 minors of B plus low-pass terms (see stable_det) -- shorter rounding chains than M (N N^T) M^T, nine
+// live registers per Gaussian, and the backward accumulates dL/dN directly.
+__device__ __forceinline__ void scale_columns(const float R[9], float sx, float sy, float sz, float N[9]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { N[3 * j] = R[3 * j] * sx; N[3 * j + 1] = R[3 * j + 1] * sy; N[3 * j + 2] = R[3 * j + 2] * sz; }
 }
 
 // Everything the forward and the backward need about one (view, Gaussian) projection.
@@ -47,7 +44,8 @@ struct Proj {
     bool inx, iny;             // clamp inactive
     float m0[3], m1[3];        // rows of M = J * Wcv
     float J00, J02, J11, J12;
-    float a, b, c;             // 2-D covariance (with low-pass)
+    float b0[3], b1[3];        // rows of B = M N (N already carries the render's world scale)
+    float a, b, c;             // 2-D covariance B B^T + 0.3 I
 };
 
 // `p` = the mean after the per-render world scale, `p0` = before it; `M64` (may be null) = the float64 view matrix with
@@ -55,10 +53,9 @@ struct Proj {
 // a difference of terms as large as the camera translation, and after the reference's 1/near rescale a Gaussian at
 // z = 0.25 sits behind a translation of tens of units -- float32 lost five digits of z there (and 1/z^2 scales the
 // whole footprint).  12 half-rate fmas per (Gaussian, view).
-__device__ __forceinline__ void project_point(const float p[3], const float p0[3], const float* __restrict__ Vm,
-                                              const double* __restrict__ M64,
-                                              const float* __restrict__ Pm, float tanx, float tany,
-                                              int H, int W, const Sym3& S, Proj& o) {
+__device__ __forceinline__ void project_point(const float p[3], const float p0[3], kfloat_p Vm, kdouble_p M64,
+                                              kfloat_p Pm, float tanx, float tany,
+                                              int H, int W, const float N[9], float nscale, Proj& o) {
     if (M64) {
         const double x = p0[0], y = p0[1], z = p0[2];
         o.tx = (float)__builtin_fma(x, M64[0], __builtin_fma(y, M64[4], __builtin_fma(z, M64[8], M64[12])));
@@ -95,42 +92,32 @@ __device__ __forceinline__ void project_point(const float p[3], const float p0[3
         o.m0[j] = o.J00 * Vm[4 * j + 0] + o.J02 * Vm[4 * j + 2];
         o.m1[j] = o.J11 * Vm[4 * j + 1] + o.J12 * Vm[4 * j + 2];
     }
-    // Sigma * m^T
-    const float s0x = S.xx * o.m0[0] + S.xy * o.m0[1] + S.xz * o.m0[2];
-    const float s0y = S.xy * o.m0[0] + S.yy * o.m0[1] + S.yz * o.m0[2];
-    const float s0z = S.xz * o.m0[0] + S.yz * o.m0[1] + S.zz * o.m0[2];
-    const float s1x = S.xx * o.m1[0] + S.xy * o.m1[1] + S.xz * o.m1[2];
-    const float s1y = S.xy * o.m1[0] + S.yy * o.m1[1] + S.yz * o.m1[2];
-    const float s1z = S.xz * o.m1[0] + S.yz * o.m1[1] + S.zz * o.m1[2];
-    o.a = o.m0[0] * s0x + o.m0[1] * s0y + o.m0[2] * s0z + kLowPass;
-    o.b = o.m0[0] * s1x + o.m0[1] * s1y + o.m0[2] * s1z;
-    o.c = o.m1[0] * s1x + o.m1[1] * s1y + o.m1[2] * s1z + kLowPass;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o.b0[k] = nscale * (o.m0[0] * N[k] + o.m0[1] * N[3 + k] + o.m0[2] * N[6 + k]);
+        o.b1[k] = nscale * (o.m1[0] * N[k] + o.m1[1] * N[3 + k] + o.m1[2] * N[6 + k]);
+    }
+    o.a = o.b0[0] * o.b0[0] + o.b0[1] * o.b0[1] + o.b0[2] * o.b0[2] + kLowPass;
+    o.b = o.b0[0] * o.b1[0] + o.b0[1] * o.b1[1] + o.b0[2] * o.b1[2];
+    o.c = o.b1[0] * o.b1[0] + o.b1[1] * o.b1[1] + o.b1[2] * o.b1[2] + kLowPass;
 }
 
-// det of the low-passed 2-D covariance WITHOUT the cancellation of a*c - b*b.  With N = R diag(s) the 3-D covariance
-// is N N^T, the 2-D one B B^T + 0.3 I with B = M N (2x3), and by Cauchy-Binet det(B B^T) is the sum of the squared
-// 2x2 minors of B: minor_ij(B) = s_i s_j minor_ij(M R).  Hence
-//     det = sum_{i<j} (s_i s_j minor_ij(M R))^2 + 0.3 (a0 + c0) + 0.09        (a0, c0: diagonal before the low-pass)
+// det of the low-passed 2-D covariance WITHOUT the cancellation of a*c - b*b.  By Cauchy-Binet det(B B^T) is the sum
+// of the squared 2x2 minors of B (2x3), hence
+//     det = sum_{i<j} minor_ij(B)^2 + 0.3 (a0 + c0) + 0.09        (a0, c0: diagonal before the low-pass)
 // -- every term is >= 0.  For a thin splat hundreds of pixels long a*c and b*b are ~1e12 while their difference is
 // ~1e6: float32 loses the leading digits of det (any float32 evaluation of the classic expression does), and 1/det
-// scales the whole exponent of every pixel the splat touches (fuzz seeds 2135 / 2195 / 2389 of the wide family:
-// colours off by up to 2.4e-3).  This form is good to a few ulp whatever the aspect ratio.  `s*` already carry
-// scale_modifier and the per-render scale.
+// scales the whole exponent of every pixel the splat touches (fuzz seeds 2135 / 2195 / 2389 of round 2's wide family:
+// colours off by up to 2.4e-3).  This form is good to a few ulp whatever the aspect ratio.
 __device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) {   // a*b - c*d, compensated
     const float w = c * d;
     const float e = fmaf(-c, d, w);
     return fmaf(a, b, -w) + e;
 }
-__device__ __forceinline__ float stable_det(const Proj& o, const float R[9], float sx, float sy, float sz) {
-    float r0[3], r1[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        r0[k] = o.m0[0] * R[k] + o.m0[1] * R[3 + k] + o.m0[2] * R[6 + k];
-        r1[k] = o.m1[0] * R[k] + o.m1[1] * R[3 + k] + o.m1[2] * R[6 + k];
-    }
-    const float n01 = diff_of_products(r0[0], r1[1], r0[1], r1[0]) * (sx * sy);
-    const float n02 = diff_of_products(r0[0], r1[2], r0[2], r1[0]) * (sx * sz);
-    const float n12 = diff_of_products(r0[1], r1[2], r0[2], r1[1]) * (sy * sz);
+__device__ __forceinline__ float stable_det(const Proj& o) {
+    const float n01 = diff_of_products(o.b0[0], o.b1[1], o.b0[1], o.b1[0]);
+    const float n02 = diff_of_products(o.b0[0], o.b1[2], o.b0[2], o.b1[0]);
+    const float n12 = diff_of_products(o.b0[1], o.b1[2], o.b0[2], o.b1[1]);
     const float tr0 = (o.a - kLowPass) + (o.c - kLowPass);
     return n01 * n01 + n02 * n02 + n12 * n12 + kLowPass * tr0 + kLowPass * kLowPass;
 }
@@ -385,15 +372,31 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #ifndef SPF_PABL
 #define SPF_PABL 0      // profiling builds of the BACKWARD kernel only (-DSPF_PABL=5..9: gather / partials / stores / SH cut out)
 #endif
+// Per-tile bookkeeping of a block: one packed word per (view of the group, tile) in LDS -- pairs in the top 12 bits
+// (a block holds 256 Gaussians), footprint load (sum of cull-box areas capped at 256 each: <= 65,536) in the low 20.
+constexpr uint32_t kHistCountShift = 20u, kHistAreaMask = (1u << 20) - 1u;
+// views whose histograms fit the LDS budget at once (the loop flushes between groups)
+__host__ __device__ inline int hist_view_group(int V, int T) {
+    const int fit = (32 * 1024) / (4 * T);
+    return fit < 1 ? 1 : (fit < V ? fit : V);
+}
+__device__ __forceinline__ uint64_t lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int dpp_wave_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
+
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
-    // Per-tile counts are first accumulated in an LDS histogram of the block's render (T counters) and
-    // flushed with one global atomic per touched tile: neighbouring Gaussians of a pixel-aligned scene land
-    // in the same few tiles, so this removes most of the L2 atomic traffic.  lds_hist = 0 (T too large for
-    // LDS): straight global atomics.
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
-    __shared__ uint32_t s_wcnt[4];
+    // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
+    // Nothing in the view loop waits for another wave: the histograms and the block's pair totals are flushed once per
+    // group of views (normally: once), and a wave's 64 records leave through ITS staging buffer as full-wave contiguous
+    // 16-byte stores (a lane's own three float4 stores at a 48-byte stride touch three times the cache lines).
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    const int T = tiles_x * tiles_y;
+    const int VG = lds_hist ? hist_view_group(d.V, T) : d.V;
+    uint32_t* const s_hist = s_dyn;                                       // [VG][T]   (lds_hist only)
+    uint32_t* const s_wtot = s_dyn + (lds_hist ? VG * T : 0);             // [VG][4]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* const s_rec = reinterpret_cast<float4*>(s_wtot + ((VG * 4 + 3) & ~3)) + wave * (kWave * 3);
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     const bool live = g < d.G;
@@ -403,31 +406,34 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 sz = in.scales[3 * sg + 2] * d.scale_modifier;
     const float4 q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
     const float opac = in.opacities[sg];
-    float R[9];
-    quat_rot(q, R);
-    const Sym3 Sg0 = cov3d(R, sx, sy, sz);
+    float N0[9];
+    {
+        float R[9];
+        quat_rot(q, R);
+        scale_columns(R, sx, sy, sz, N0);
+    }
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
-    const int T = tiles_x * tiles_y;
-    uint32_t* s_area = s_hist + T;      // footprint load per tile (see tile_flags in the header)
     if (lds_hist) {
-        for (int t = threadIdx.x; t < 2 * T; t += kBlock) s_hist[t] = 0;
+        for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
     }
+    const int g_wave0 = blockIdx.x * kBlock + wave * kWave;              // first Gaussian of this wave
+    const int n_wave = min(kWave, d.G - g_wave0);                        // its live Gaussians (<= 0: none)
 
-    for (int v = 0; v < d.V; ++v) {
+    for (int v0 = 0; v0 < d.V; v0 += VG) {
+      const int vend = min(d.V, v0 + VG);
+      for (int v = v0; v < vend; ++v) {
         const int r = s * d.V + v;
-        const float* __restrict__ Vm = in.viewmatrix + 16 * r;
-        const float* __restrict__ Pm = in.projmatrix + 16 * r;
-        const float tanx = in.tanfov[2 * r], tany = in.tanfov[2 * r + 1];
+        const kfloat_p Vm = as_const(in.viewmatrix + 16 * r), Pm = as_const(in.projmatrix + 16 * r);
+        const kdouble_p M64 = in.viewmatrix64 ? as_const(in.viewmatrix64 + 16 * r) : nullptr;
+        const float tanx = as_const(in.tanfov)[2 * r], tany = as_const(in.tanfov)[2 * r + 1];
         const size_t rg = (size_t)r * d.G + (live ? g : 0);
-        float4* __restrict__ rec = reinterpret_cast<float4*>(st.rec + rg * kRec);
-        const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
+        const float sc = in.view_scale ? as_const(in.view_scale)[r] : 1.0f;
         const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
-        const Sym3 Sg = scaled(Sg0, sc * sc);
 
         Proj pr;
-        project_point(p, p0, Vm, in.viewmatrix64 ? in.viewmatrix64 + 16 * r : nullptr, Pm, tanx, tany, d.H, d.W, Sg, pr);
-        const float det = stable_det(pr, R, sx * sc, sy * sc, sz * sc);
+        project_point(p, p0, Vm, M64, Pm, tanx, tany, d.H, d.W, N0, sc, pr);
+        const float det = stable_det(pr);
         bool ok = live && pr.tz > kNearCull && det != 0.0f;
         float radius = 0.f;
         int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -449,14 +455,9 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 ok = (x1 - x0) * (y1 - y0) > 0;
             }
         }
-        if (live && !ok) {
-            st.radii[rg] = 0;
-            st.rect[rg] = 0;
-            st.zkey[rg] = 0.f;
-            rec[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rec[1] = make_float4(0.f, 0.f, 0.f, -1.f);
-            rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = make_float4(0.f, 0.f, 0.f, -1.f), rec2 = rec0;
+        uint32_t rect_w = 0u, area = 0u;
+        float zk = 0.f;
         if (ok) {
             // colour
             float col[3];
@@ -508,41 +509,84 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                     if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
                 }
             }
-            st.radii[rg] = (int)radius;
-            st.rect[rg] = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
-            st.zkey[rg] = pr.tz;
-            rec[0] = make_float4(pr.px, pr.py, cA, cB);
-            rec[1] = make_float4(cC, opac, pr.tz, cull_r2);
-            rec[2] = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
-            uint32_t* __restrict__ cnt = lds_hist ? s_hist : st.tile_count + (size_t)r * T;
-            uint32_t* __restrict__ are = lds_hist ? s_area : st.tile_flags + (size_t)r * T;
-            const uint32_t area = disc_area_capped(pr.px, pr.py, cull_r2);
+            rect_w = (uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24);
+            zk = pr.tz;
+            rec0 = make_float4(pr.px, pr.py, cA, cB);
+            rec1 = make_float4(cC, opac, pr.tz, cull_r2);
+            rec2 = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
+            area = disc_area_capped(pr.px, pr.py, cull_r2);
+        }
+        if (live) {
+            st.radii[rg] = ok ? (int)radius : 0;
+            st.rect[rg] = rect_w;
+            st.zkey[rg] = zk;
+        }
+        // ---- the wave's 64 records: own 48 bytes into LDS (conflict-free at this stride), contiguous 16-byte pieces out ----
+        s_rec[3 * lane] = rec0; s_rec[3 * lane + 1] = rec1; s_rec[3 * lane + 2] = rec2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n_wave > 0) {
+            float4* __restrict__ dst = reinterpret_cast<float4*>(st.rec + ((size_t)r * d.G + g_wave0) * kRec);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (lane + kWave * i < 3 * n_wave) dst[lane + kWave * i] = s_rec[lane + kWave * i];
+        }
+        __builtin_amdgcn_wave_barrier();                                   // (the buffer is rewritten by the next view)
+
+        // ---- per-tile counts and footprint load ----
+        const int npair = ok ? (x1 - x0) * (y1 - y0) : 0;
+        if (lds_hist) {
+            // A pixel-aligned scene puts runs of neighbouring lanes into the same tile.  Per-lane LDS atomics on one
+            // address serialise (64 lanes: 64 passes); instead every run of equal tiles adds its total once: prefix sum
+            // of the packed (1 pair, area) words over the lanes, run heads by a neighbour compare, and the last lane of
+            // a run takes (prefix at its end) - (prefix before its head).  Gaussians with several tiles go one by one.
+            uint32_t* __restrict__ hist = s_hist + (v - v0) * T;
+            const bool single = npair == 1;
+            const int tile = single ? y0 * tiles_x + x0 : -1;
+            const uint32_t val = single ? ((1u << kHistCountShift) | area) : 0u;
+            const uint32_t pre = wave_iscan_u32(val);
+            const int prev_tile = dpp_wave_shr1(tile);
+            const uint64_t heads = lane_ballot(lane == 0 || tile != prev_tile);
+            const bool is_end = lane == kWave - 1 || ((heads >> (lane + 1)) & 1ull);
+            const int head = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+            const uint32_t before = (uint32_t)__shfl((int)pre, max(head - 1, 0), kWave);
+            if (is_end && single) atomicAdd(&hist[tile], pre - (head > 0 ? before : 0u));
+            if (npair > 1) {
+                const uint32_t one = (1u << kHistCountShift) | area;
+                for (int ty = y0; ty < y1; ++ty)
+                    for (int tx = x0; tx < x1; ++tx) atomicAdd(&hist[ty * tiles_x + tx], one);
+            }
+        } else if (npair > 0) {
+            uint32_t* __restrict__ cnt = st.tile_count + (size_t)r * T;
+            uint32_t* __restrict__ are = st.tile_flags + (size_t)r * T;
             for (int ty = y0; ty < y1; ++ty)
                 for (int tx = x0; tx < x1; ++tx) {
                     atomicAdd(&cnt[ty * tiles_x + tx], 1u);
                     atomicAdd(&are[ty * tiles_x + tx], area);
                 }
         }
-        // pairs produced by this block for this render (feeds the Gaussian-major pair numbering)
-        const uint32_t wsum = wave_sum_u32(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u);
-        if ((threadIdx.x & 63) == 0) s_wcnt[threadIdx.x >> 6] = wsum;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            st.blk_total[(size_t)r * gridDim.x + blockIdx.x] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (lds_hist) {
-            uint32_t* __restrict__ gcnt = st.tile_count + (size_t)r * T;
-            uint32_t* __restrict__ gare = st.tile_flags + (size_t)r * T;
-            for (int t = threadIdx.x; t < T; t += kBlock) {
-                const uint32_t c = s_hist[t];
-                if (c) {
-                    atomicAdd(&gcnt[t], c);
-                    atomicAdd(&gare[t], s_area[t]);
-                    s_hist[t] = 0;
-                    s_area[t] = 0;
-                }
-            }
-        }
-        __syncthreads();
+        // pairs produced by this wave for this render (feeds the Gaussian-major pair numbering)
+        const uint32_t wtot = wave_iscan_u32((uint32_t)npair);
+        if (lane == kWave - 1) s_wtot[(v - v0) * 4 + wave] = wtot;
+      }
+      // ---- flush the group: block pair totals and the tiles this block touched (one global atomic pair per tile) ----
+      __syncthreads();
+      for (int i = threadIdx.x; i < vend - v0; i += kBlock)
+          st.blk_total[(size_t)(s * d.V + v0 + i) * gridDim.x + blockIdx.x] =
+              s_wtot[4 * i] + s_wtot[4 * i + 1] + s_wtot[4 * i + 2] + s_wtot[4 * i + 3];
+      if (lds_hist) {
+          for (int i = threadIdx.x; i < (vend - v0) * T; i += kBlock) {
+              const uint32_t c = s_hist[i];
+              if (c) {
+                  const int vi = i / T, t = i - vi * T;
+                  const size_t rt = (size_t)(s * d.V + v0 + vi) * T + t;
+                  atomicAdd(&st.tile_count[rt], c >> kHistCountShift);
+                  atomicAdd(&st.tile_flags[rt], c & kHistAreaMask);
+                  s_hist[i] = 0;
+              }
+          }
+      }
+      if (vend < d.V) __syncthreads();
     }
 }
 
@@ -597,14 +641,15 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         opac = in.opacities[sg];
     }
     (void)opac;
-    float R[9];
+    float R[9], N0[9];
     quat_rot(q, R);
-    const Sym3 Sg0 = cov3d(R, sx, sy, sz);
+    scale_columns(R, sx, sy, sz, N0);
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
 
     float dp0[3] = {0.f, 0.f, 0.f};          // dL/dmean3D
-    float dS0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // dL/dSigma as full-matrix partials, symmetrised:
-                                             // xx, xy(+yx), xz(+zx), yy, yz(+zy), zz
+    float dN0[9];                            // dL/dN, N = R diag(s) (summed over the views)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dN0[k] = 0.f;
     float dopac = 0.f;
     float dcol[3] = {0.f, 0.f, 0.f};        // colours given directly
 
@@ -646,9 +691,9 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
 
     for (int v = 0; v < d.V; ++v) {
         const int r = s * d.V + v;
-        const float* __restrict__ Vm = in.viewmatrix + 16 * r;
-        const float* __restrict__ Pm = in.projmatrix + 16 * r;
-        const float tanx = in.tanfov[2 * r], tany = in.tanfov[2 * r + 1];
+        const kfloat_p Vm = as_const(in.viewmatrix + 16 * r), Pm = as_const(in.projmatrix + 16 * r);
+        const kdouble_p M64 = in.viewmatrix64 ? as_const(in.viewmatrix64 + 16 * r) : nullptr;
+        const float tanx = as_const(in.tanfov)[2 * r], tany = as_const(in.tanfov)[2 * r + 1];
         const size_t rg = (size_t)r * d.G + (live ? g : 0);
         float dV[12];  // dL/dVm[4i+j] for i<3 (index 3i+j) and dL/dVm[12+j] (index 9+j)
 #pragma unroll
@@ -685,11 +730,9 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                     if (gs == 10) g2.y += gp[gs * i + 9];
                 }
             }
-            const float sc = in.view_scale ? in.view_scale[r] : 1.0f;
+            const float sc = in.view_scale ? as_const(in.view_scale)[r] : 1.0f;
             const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
-            const Sym3 Sg = scaled(Sg0, sc * sc);
             float dp[3] = {0.f, 0.f, 0.f};
-            float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // (fields 2..4 are dL/d(a, b, c) of the 2-D covariance itself: the render backward forms them per pixel
             //  from v = conic * offset, see spf_common.h -- no conic -> covariance step here)
             const float gx = g0.x, gy = g0.y, da = g0.z, db = g0.w, dc = g1.x;
@@ -750,7 +793,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 }
             }
             Proj pr;
-            project_point(p, p0, Vm, in.viewmatrix64 ? in.viewmatrix64 + 16 * r : nullptr, Pm, tanx, tany, d.H, d.W, Sg, pr);
+            project_point(p, p0, Vm, M64, Pm, tanx, tany, d.H, d.W, N0, sc, pr);
             float dt[3] = {0.f, 0.f, gdepth};  // dL/dt (view space)
 
             // ---- pixel centre -> t (through the projection matrix) ----
@@ -761,26 +804,20 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
 #pragma unroll
                 for (int i = 0; i < 3; ++i) dt[i] += Pm[4 * i] * dhx + Pm[4 * i + 1] * dhy + Pm[4 * i + 3] * dhw;
             }
-            // ---- cov2D = M Sigma M^T ----
+            // ---- cov2D = B B^T + 0.3 I, B = M (sc N0): a = b0.b0, b = b0.b1, c = b1.b1 ----
             const float* m0 = pr.m0; const float* m1 = pr.m1;
-            dS[0] += da * m0[0] * m0[0] + db * m0[0] * m1[0] + dc * m1[0] * m1[0];
-            dS[3] += da * m0[1] * m0[1] + db * m0[1] * m1[1] + dc * m1[1] * m1[1];
-            dS[5] += da * m0[2] * m0[2] + db * m0[2] * m1[2] + dc * m1[2] * m1[2];
-            dS[1] += 2.f * da * m0[0] * m0[1] + db * (m0[0] * m1[1] + m0[1] * m1[0]) + 2.f * dc * m1[0] * m1[1];
-            dS[2] += 2.f * da * m0[0] * m0[2] + db * (m0[0] * m1[2] + m0[2] * m1[0]) + 2.f * dc * m1[0] * m1[2];
-            dS[4] += 2.f * da * m0[1] * m0[2] + db * (m0[1] * m1[2] + m0[2] * m1[1]) + 2.f * dc * m1[1] * m1[2];
-            float Sm0[3], Sm1[3];
-            Sm0[0] = Sg.xx * m0[0] + Sg.xy * m0[1] + Sg.xz * m0[2];
-            Sm0[1] = Sg.xy * m0[0] + Sg.yy * m0[1] + Sg.yz * m0[2];
-            Sm0[2] = Sg.xz * m0[0] + Sg.yz * m0[1] + Sg.zz * m0[2];
-            Sm1[0] = Sg.xx * m1[0] + Sg.xy * m1[1] + Sg.xz * m1[2];
-            Sm1[1] = Sg.xy * m1[0] + Sg.yy * m1[1] + Sg.yz * m1[2];
-            Sm1[2] = Sg.xz * m1[0] + Sg.yz * m1[1] + Sg.zz * m1[2];
-            float dm0[3], dm1[3];
+            float db0[3], db1[3], dm0[3], dm1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                db0[k] = sc * (2.f * da * pr.b0[k] + db * pr.b1[k]);       // (dL/db0, dL/db1) x the render's scale
+                db1[k] = sc * (2.f * dc * pr.b1[k] + db * pr.b0[k]);
+            }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                dm0[j] = 2.f * da * Sm0[j] + db * Sm1[j];
-                dm1[j] = 2.f * dc * Sm1[j] + db * Sm0[j];
+                dm0[j] = db0[0] * N0[3 * j] + db0[1] * N0[3 * j + 1] + db0[2] * N0[3 * j + 2];
+                dm1[j] = db1[0] * N0[3 * j] + db1[1] * N0[3 * j + 1] + db1[2] * N0[3 * j + 2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dN0[3 * j + k] += m0[j] * db0[k] + m1[j] * db1[k];
             }
             // M = J Wcv, Wcv[i][j] = Vm[4j+i]:  m0[j] = J00 Vm[4j] + J02 Vm[4j+2], m1[j] = J11 Vm[4j+1] + J12 Vm[4j+2]
             float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
@@ -812,8 +849,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) dp0[i] += sc * dp[i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) dS0[i] += sc * sc * dS[i];
         }
         if (kPark && want_dsh) {
             // park this view's direction and colour gradient (zeros when the Gaussian is not visible in it); every
@@ -898,25 +933,14 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         }
     }
     if (gr.dL_dscales && gr.dL_drotations) {
-        // Sigma = Rm diag(s^2) Rm^T.  G = symmetric gradient matrix with G_ij = dL/dSigma_ij (full partials).
-        // dS holds xx, (xy+yx), (xz+zx), yy, (yz+zy), zz  ->  Gs = (G + G^T) has entries:
-        const float* dS = dS0;
-        const float Gs[9] = {2.f * dS[0], dS[1], dS[2], dS[1], 2.f * dS[3], dS[4], dS[2], dS[4], 2.f * dS[5]};
-        // Sigma = N N^T with N = Rm diag(s):  dL/dN = Gs N
-        const float sv[3] = {sx, sy, sz};
-        float dN[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                dN[3 * i + k] = (Gs[3 * i] * R[k] + Gs[3 * i + 1] * R[3 + k] + Gs[3 * i + 2] * R[6 + k]) * sv[k];
         // N[i][k] = R[i][k] s_k
+        const float sv[3] = {sx, sy, sz};
         float ds[3], dR[9];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            ds[k] = (dN[k] * R[k] + dN[3 + k] * R[3 + k] + dN[6 + k] * R[6 + k]) * d.scale_modifier;
+            ds[k] = (dN0[k] * R[k] + dN0[3 + k] * R[3 + k] + dN0[6 + k] * R[6 + k]) * d.scale_modifier;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN[3 * i + k] * sv[k];
+            for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN0[3 * i + k] * sv[k];
         }
         gr.dL_dscales[3 * sg] = ds[0]; gr.dL_dscales[3 * sg + 1] = ds[1]; gr.dL_dscales[3 * sg + 2] = ds[2];
         const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -1011,7 +1035,11 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
     const int lds = T <= max_lds_tiles() ? 1 : 0;
-    const size_t sm = lds ? 2 * sizeof(uint32_t) * T : 0;
+    const int VG = lds ? hist_view_group(d.V, T) : d.V;
+    // packed tile histograms of a group of views | per-wave pair totals | record staging (4 waves x 64 x 48 bytes)
+    const size_t sm = sizeof(uint32_t) * ((lds ? (size_t)VG * T : 0) + (((size_t)VG * 4 + 3) & ~(size_t)3)) +
+                      (size_t)kBlock * kRec * sizeof(float);
+    if (sm > 64 * 1024) return hipErrorInvalidValue;     // (V > ~3,000 views per scene without LDS histograms)
     SPF_DISPATCH_DEG(project_fwd_t, grid, sm, stream, d, in, st, tiles_x, tiles_y, lds)
     return hipGetLastError();
 }

@@ -241,3 +241,40 @@ def test_failed_plan_is_nan_everywhere_and_raises_without_backward(hip_lib):
                 util.run_product(batch, max_pairs=plan._replace(check="backward"), with_grads=False)
     ok = util.run_product(batch, max_pairs=good)
     assert spf.plan_flags(ok["decoder"].last_call) == 0 and torch.equal(ok["color"], exact["color"])
+
+
+@pytest.mark.parametrize("config,S,V,chunks", [("C2", 8, 4, 4), ("C2", 3, 2, 2), ("C5", 1, 4, 2)])
+def test_chunked_two_lane_chains_are_bit_identical(hip_lib, config, S, V, chunks, monkeypatch):
+    """SPF_CHUNKS=n (spf_raster_chunks; off by default: measured slower) runs a call as n chunks of renders on two
+    streams.  Same launchers on offset pointers: images and every gradient equal the single chain bit for bit, with
+    whole scenes per chunk (backward chunked too), a scene count that does not divide evenly, and a single scene
+    (forward chunked by views, backward as one chain)."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import _lib
+    b = syn.make_batch(config, S, V, seed=77).to("cuda")
+    names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
+
+    def run():
+        leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in names}
+        img, dep, alp = spf.render_views(leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape,
+                                         torch.zeros(3, device="cuda"), leaves["means"], leaves["harmonics"],
+                                         leaves["opacities"], leaves["rotations"], leaves["scales"],
+                                         enable_cov_grad=True, enable_sh_grad=True)
+        (spf.mse_loss(img, b.target) + 0.01 * dep.mean() + 0.1 * alp.mean()).backward()
+        return img.detach(), dep.detach(), {n: t.grad for n, t in leaves.items()}
+
+    monkeypatch.delenv("SPF_CHUNKS", raising=False)
+    h, w = b.image_shape
+    assert _lib.load().spf_raster_chunks(S, V, h, w, 0) == 1
+    img1, dep1, g1 = run()
+    _, _, g1b = run()
+    # (dense tiles -- C5 has a few -- sum their partial gradients with LDS float atomics: run-to-run ~1e-7)
+    deterministic = all(torch.equal(g1[n], g1b[n]) for n in names)
+    monkeypatch.setenv("SPF_CHUNKS", str(chunks))
+    assert _lib.load().spf_raster_chunks(S, V, h, w, 0) == chunks
+    assert _lib.load().spf_raster_chunks(S, V, h, w, 1) == (chunks if S > 1 else 1)
+    img2, dep2, g2 = run()
+    torch.cuda.synchronize()
+    assert torch.equal(img1, img2) and torch.equal(dep1, dep2)
+    for n in names:
+        assert torch.equal(g1[n], g2[n]) if deterministic else util.rel_linf(g2[n], g1[n]) < 1e-5, n
