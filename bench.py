@@ -161,6 +161,12 @@ def parse_args(argv=None):
                          "graph and replayed on its own stream, so that the latency-bound stages of one micro-batch "
                          "(projection, binning, sort) run under the VALU-bound compositing of another (implies --graph; "
                          "same renders, same loss -- each micro-batch weighs 1/N --, same backward)")
+    ap.add_argument("--api", default="batched", choices=["batched", "per-view"],
+                    help="per-view: the step is the REFERENCE's own glue, unchanged -- `repeat` of every Gaussian tensor "
+                         "per view (decoder_splatting_cuda.py:59-64), torch camera preamble, then b*v sequential "
+                         "`GaussianRasterizer(settings)(...)` calls with `.item()` host syncs (cuda_splatting.py:96-143) "
+                         "-- on this library's drop-in `diff_gauss_pose` surface (eager; what a caller gets with zero "
+                         "source changes).  batched (default): one `DecoderSplattingCUDA`-style call for all renders")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -232,7 +238,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # a launcher (WORLD_SIZE set) gets a process group even for a world of one: `torch.distributed.run
+    # --nproc-per-node=1` is the pre-flight of the RCCL path on a single-GPU box (init with device_id, barrier,
+    # flat-bucket all-reduce on device tensors)
+    launched = "WORLD_SIZE" in os.environ
+    if launched:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -244,7 +254,7 @@ def main():
     from spfsplatv2_amd import build as _build
     if builder and "SPF_LIB_DIR" not in os.environ:
         _build.build(verbose=False)
-    if world > 1:
+    if launched:
         dist.barrier()
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
@@ -268,6 +278,10 @@ def main():
         if S % args.streams or args.allreduce:
             sys.exit("bench.py: --streams N needs a scene count divisible by N (and is not combined with --allreduce)")
         args.graph = True
+    if args.api == "per-view":
+        if args.streams > 1 or args.allreduce:
+            sys.exit("bench.py: --api per-view is a single-stream, single-rank-style step")
+        args.eager, args.exact, args.graph = True, True, False      # host syncs inside the step: nothing to capture
     if not args.graph:          # launch mode: HIP-graph replay unless something in the step cannot be captured
         args.graph = not (args.eager or args.exact or args.allreduce)
 
@@ -281,10 +295,56 @@ def main():
             self.record = spf.CallRecord()
             self.max_pairs = None
 
+        def render_per_view(self):
+            """The reference's decoder + render_cuda, statement for statement, on the drop-in rasterizer surface."""
+            from math import isqrt
+            from spfsplatv2_amd import decoder as dec
+            L, sl = self.leaves, self.sl
+            bb, vv = L["extrinsics"].shape[:2]
+            rep = lambda t: t[:, None].expand(bb, vv, *t.shape[1:]).reshape(bb * vv, *t.shape[1:])   # `repeat`
+            ext = L["extrinsics"].reshape(bb * vv, 4, 4)
+            near, far = b.near[sl].reshape(-1), b.far[sl].reshape(-1)
+            means, scales_, rot = rep(L["means"]), rep(L["scales"]), rep(L["rotations"])
+            harm, opac = rep(L["harmonics"]), rep(L["opacities"])
+            scale = 1 / near                                                    # cuda_splatting.py:66-74
+            ext = ext.clone()
+            ext[..., :3, 3] = ext[..., :3, 3] * scale[:, None]
+            means = means * scale[:, None, None]
+            scales_ = scales_ * scale[:, None, None]
+            near, far = near * scale, far * scale
+            degree = isqrt(harm.shape[-1]) - 1
+            shs = harm.transpose(-1, -2).contiguous()                           # "b g xyz n -> b g n xyz"
+            fov_x, fov_y = dec.get_fov(b.intrinsics[sl].reshape(bb * vv, 3, 3)).unbind(dim=-1)
+            tan_x, tan_y = (0.5 * fov_x).tan(), (0.5 * fov_y).tan()
+            proj = dec.get_projection_matrix(near, far, fov_x, fov_y).transpose(-1, -2)
+            view = ext.inverse().transpose(-1, -2)
+            images = []
+            for i in range(bb * vv):                                            # cuda_splatting.py:96-143
+                mean_gradients = torch.zeros_like(means[i], requires_grad=True)
+                settings = spf.GaussianRasterizationSettings(
+                    image_height=h, image_width=w, tanfovx=tan_x[i].item(), tanfovy=tan_y[i].item(), bg=bg,
+                    scale_modifier=1.0, projmatrix=proj[i], sh_degree=degree, prefiltered=False, debug=False,
+                    enable_cov_grad=True, enable_sh_grad=True)
+                image, _depth, _norm, _alpha, _radii, _extra = spf.GaussianRasterizer(settings)(
+                    means3D=means[i], means2D=mean_gradients, shs=shs[i], colors_precomp=None,
+                    opacities=opac[i, ..., None], scales=scales_[i], rotations=rot[i], viewmatrix=view[i])
+                images.append(image)
+            return torch.stack(images).reshape(bb, vv, 3, h, w)
+
         def step(self):
             L, sl = self.leaves, self.sl
             for t in L.values():
                 t.grad = None
+            if args.api == "per-view":
+                color = self.render_per_view()
+                if self.record.get("num_pairs") is None:        # (statistics for the byte model: one batched call)
+                    with torch.no_grad():
+                        spf.render_views(L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg,
+                                         L["means"], L["harmonics"], L["opacities"], L["rotations"], L["scales"],
+                                         record=self.record)
+                loss = spf.mse_loss(color, b.target[sl], self.weight)
+                loss.backward(gradient=one)
+                return loss
             color, depth, _alpha = spf.render_views(
                 L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
                 L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
@@ -295,7 +355,7 @@ def main():
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
             loss.backward(gradient=one)          # (a cached dL/dloss = 1 saves autograd's fill kernel)
             if args.allreduce:
-                shard.allreduce_gaussian_grads([L[n].grad for n in names[:5]])
+                shard.allreduce_gaussian_grads([L[n].grad for n in names[:5]], skip_single=False)
             return loss
 
     per = S // args.streams
@@ -306,7 +366,7 @@ def main():
             m.step()
 
     def barrier():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -322,7 +382,7 @@ def main():
     torch.cuda.synchronize(dev)
     D_total = sum(m.record["num_pairs"] for m in micro)
     log(f"first step done: D={D_total}, max tile list={max(m.record['max_tile_list'] for m in micro)}")
-    if not args.exact or args.graph:
+    if (not args.exact or args.graph) and args.api == "batched":
         for m in micro:
             m.max_pairs = spf.plan_pair_budget(m.record, slack=1.25, check="deferred")
         log(f"planned budget: {micro[0].max_pairs}" + (f" x {len(micro)} micro-batches" if len(micro) > 1 else ""))
@@ -430,6 +490,8 @@ def main():
         dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1] / chunks
         # (with --streams the surveyed launch is one micro-batch's: its share of the scenes and pairs)
         dom_bytes = stage_bytes(dom, S // len(micro), V, G, K, P, D_total // len(micro)) / chunks
+        if args.api == "per-view":          # one launch per render
+            dom_bytes = stage_bytes(dom, 1, 1, G, K, P, D_total // (S * V))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         prof = ROOT / "profiles" / "pmc_summary.json"
@@ -463,6 +525,10 @@ def main():
                                   (f"hip-graph replay of the whole step; every {probe}th step launched eagerly with HIP "
                                    "events around the dominant kernel" if probe else "hip-graph replay")
                                   if args.graph else "eager"),
+                       "process_group": (dist.get_backend() if launched else None),
+                       "api": ("per-view: the reference's own glue (repeat + torch camera preamble + b*v sequential "
+                               "GaussianRasterizer calls with .item() syncs) on the drop-in surface"
+                               if args.api == "per-view" else "batched: one decoder call for all renders"),
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
                                     if args.allreduce else "scene-first, no data-path collective")},
             "timing": {"trials": n_trials, "statistic": "median trial; each trial = exactly `steps` steps between "
@@ -482,7 +548,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, batch_cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

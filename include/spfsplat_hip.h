@@ -243,6 +243,12 @@ int spf_mse_backward(const float* prediction, const float* image, int64_t n, flo
 int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
                int64_t stride_b, int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base,
                float fwd, void* stream);
+/* The same rotation applied to TWO tensors of identical shape, strides, dtype and positions in one launch (the angles
+ * are evaluated once): q and k of an attention layer, which the reference rotates with two calls
+ * (src/model/encoder/backbone/croco/blocks.py:102-104). */
+int spf_rope2d_pair(void* tokens, void* tokens2, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                    int64_t stride_b, int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base,
+                    float fwd, void* stream);
 
 /* Per-stage device timing with HIP events recorded on the launch stream around every kernel
  * stage.  spf_stage_timing_enable(mask) clears the log and starts recording the stages whose bit

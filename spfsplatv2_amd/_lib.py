@@ -76,6 +76,9 @@ SYMBOLS = {
     "spf_rope2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
                              C.c_void_p]),
+    "spf_rope2d_pair": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                  C.c_void_p]),
     "spf_stage_timing_enable": (C.c_int, [C.c_int32]),
     "spf_stage_timing_sample_every": (C.c_int, [C.c_int32]),
     "spf_stage_times_ms": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

@@ -27,8 +27,8 @@ hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
 hipError_t launch_camera_fwd_zero(const SpfCamera&, void*, uint64_t, hipStream_t);
 hipError_t launch_camera_bwd_reduce(const SpfCamera&, const float*, int, float*, hipStream_t);
-hipError_t launch_rope2d(void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float, float,
-                         hipStream_t);
+hipError_t launch_rope2d(void*, void*, const int64_t*, int, int, int, int, int64_t, int64_t, int64_t, int, int, float,
+                         float, hipStream_t);
 }  // namespace spf
 
 namespace {
@@ -476,9 +476,9 @@ int spf_mse_backward(const float* prediction, const float* image, int64_t n, flo
     return SPF_OK;
 }
 
-int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D, int64_t stride_b,
-               int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base, float fwd,
-               void* stream_) {
+static int rope2d_impl(void* tokens, void* tokens2, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                       int64_t stride_b, int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base,
+                       float fwd, void* stream_) {
     if (!tokens || !positions) return fail(SPF_E_INVALID, "tokens / positions is null");
     if (B < 0 || N < 0 || H < 0 || D <= 0) return fail(SPF_E_INVALID, "negative size");
     if (D % 4 != 0) return fail(SPF_E_INVALID, "token dim must be multiple of 4");
@@ -488,9 +488,24 @@ int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int
     if ((size_t)B * N * H == 0) return SPF_OK;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     StageScope t(SPF_STAGE_ROPE, stream);
-    SPF_HIP(spf::launch_rope2d(tokens, positions, B, N, H, D, stride_b, stride_n, stride_h, pos_div, dtype, base, fwd,
-                               stream));
+    SPF_HIP(spf::launch_rope2d(tokens, tokens2, positions, B, N, H, D, stride_b, stride_n, stride_h, pos_div, dtype, base,
+                               fwd, stream));
     return SPF_OK;
+}
+
+int spf_rope2d(void* tokens, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D, int64_t stride_b,
+               int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base, float fwd,
+               void* stream_) {
+    return rope2d_impl(tokens, nullptr, positions, B, N, H, D, stride_b, stride_n, stride_h, pos_div, dtype, base, fwd,
+                       stream_);
+}
+
+int spf_rope2d_pair(void* tokens, void* tokens2, const int64_t* positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                    int64_t stride_b, int64_t stride_n, int64_t stride_h, int32_t pos_div, int32_t dtype, float base,
+                    float fwd, void* stream_) {
+    if (!tokens2) return fail(SPF_E_INVALID, "tokens2 is null");
+    return rope2d_impl(tokens, tokens2, positions, B, N, H, D, stride_b, stride_n, stride_h, pos_div, dtype, base, fwd,
+                       stream_);
 }
 
 int spf_stage_timing_enable(int32_t mask) {

@@ -6,9 +6,9 @@
 // and every (u,v) pair with frequency index q is rotated by  angle = pos * fwd / base^(q/Q)
 // where pos is the token's y position for the first half and its x position for the second.
 //
-// Mapping: one lane owns 4 consecutive frequencies of one (token, head, half): two 16-byte
-// loads + two 16-byte stores (8-byte for half types); consecutive lanes walk q, then the half, then
-// the head, so a wave touches whole contiguous head rows.  The Q inverse frequencies are computed
+// Mapping: one lane owns 16 bytes of consecutive frequencies (4 floats, 8 halves) of one (token, half) and walks four
+// heads with them (the angle does not depend on the head: one sincosf per four head rows); consecutive lanes walk q,
+// then the half, so a group of lanes covers whole contiguous head rows.  The Q inverse frequencies are computed
 // on the host with libm powf (exactly what the reference's CPU path evaluates,
 // curope/curope.cpp:35) and travel in the kernel-argument segment -- no device powf, no table in HBM.
 #include <hip/hip_bf16.h>
@@ -22,39 +22,6 @@ struct RopeFreq {
     float inv[64];  // fwd / base^(q/Q), q < Q <= 64
 };
 
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-    using type = float4;
-    static __device__ __forceinline__ void unpack(const type& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
-    static __device__ __forceinline__ type pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
-};
-template <> struct Vec4<__half> {
-    struct __attribute__((aligned(8))) type { __half h[4]; };
-    static __device__ __forceinline__ void unpack(const type& v, float* f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = __half2float(v.h[i]);
-    }
-    static __device__ __forceinline__ type pack(const float* f) {
-        type v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v.h[i] = __float2half(f[i]);
-        return v;
-    }
-};
-template <> struct Vec4<__hip_bfloat16> {
-    struct __attribute__((aligned(8))) type { __hip_bfloat16 h[4]; };
-    static __device__ __forceinline__ void unpack(const type& v, float* f) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = __bfloat162float(v.h[i]);
-    }
-    static __device__ __forceinline__ type pack(const float* f) {
-        type v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v.h[i] = __float2bfloat16(f[i]);
-        return v;
-    }
-};
-
 template <typename T>
 __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
@@ -66,43 +33,93 @@ template <> __device__ __forceinline__ float from_f<float>(float v) { return v; 
 template <> __device__ __forceinline__ __half from_f<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ __hip_bfloat16 from_f<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
-// Vector path: Q % 4 == 0 and every row 4-element aligned.
+// 16 bytes per lane whatever the type: 4 floats, 8 halves / bfloat16s.
+template <typename T> struct Wide;
+template <> struct Wide<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* f) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* f) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+    }
+};
+template <typename H> struct WideHalf {
+    static constexpr int N = 8;
+    struct __attribute__((aligned(16))) Pack { H h[8]; };
+    static __device__ __forceinline__ void load(const H* p, float* f) {
+        const Pack v = *reinterpret_cast<const Pack*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = to_f<H>(v.h[i]);
+    }
+    static __device__ __forceinline__ void store(H* p, const float* f) {
+        Pack v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v.h[i] = from_f<H>(f[i]);
+        *reinterpret_cast<Pack*>(p) = v;
+    }
+};
+template <> struct Wide<__half> : WideHalf<__half> {};
+template <> struct Wide<__hip_bfloat16> : WideHalf<__hip_bfloat16> {};
+
+// Vector path.  One lane owns EPL = 16 bytes / sizeof(T) consecutive frequencies of one (token, half) and walks kHeads
+// heads with them: the rotation angle depends on (token, half, frequency) only, so its sincosf -- which made the half
+// types compute-bound at one evaluation per element pair (fp16 took as long as fp32 for half the bytes) -- is
+// evaluated once per kHeads head rows.  Consecutive lanes walk the frequencies, then the half, so at every step of the
+// head loop a group of 2*Q/EPL lanes covers one contiguous head row.  `tokens2` (may be null): a second tensor of the
+// same shape / strides / positions rotated in the same launch with the same angles (q and k of one attention layer,
+// croco/blocks.py:102-104).
+constexpr int kRopeHeads = 4;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ tokens,
+__global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ tokens, T* __restrict__ tokens2,
                                                                 const int64_t* __restrict__ pos, int N, int H, int D,
                                                                 int64_t stride_b, int64_t stride_n, int64_t stride_h, int pos_div,
                                                                 RopeFreq f, size_t total) {
-    using V = Vec4<T>;
+    using W = Wide<T>;
+    constexpr int EPL = W::N;
     const size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (item >= total) return;
-    const int Q = D >> 2, per_head = D >> 3, q4n = Q >> 2;
-    const int per_tok = H * per_head;
+    const int Q = D >> 2, QG = Q / EPL, per_chunk = 2 * QG;
+    const int nchunk = (H + kRopeHeads - 1) / kRopeHeads;
+    const int per_tok = nchunk * per_chunk;
     const size_t token = item / per_tok;
     const int rem = (int)(item - token * per_tok);
-    const int h = rem / per_head, e = rem - h * per_head;
-    const int x = e / q4n, q0 = (e - x * q4n) * 4;
+    const int hc = rem / per_chunk, e = rem - hc * per_chunk;
+    const int x = e / QG, q0 = (e - x * QG) * EPL;
     const size_t b = token / N, n = token - b * N;
     const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
-    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q0;
-    typename V::type uv = *reinterpret_cast<const typename V::type*>(up);
-    typename V::type vv = *reinterpret_cast<const typename V::type*>(up + Q);
-    float u[4], v[4], uo[4], vo[4];
-    V::unpack(uv, u);
-    V::unpack(vv, v);
+    float sn[EPL], cs[EPL];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float s, c;
-        sincosf(p * f.inv[q0 + k], &s, &c);
-        uo[k] = u[k] * c - v[k] * s;
-        vo[k] = v[k] * c + u[k] * s;
+    for (int k = 0; k < EPL; ++k) sincosf(p * f.inv[q0 + k], &sn[k], &cs[k]);
+    const int h0 = hc * kRopeHeads;
+    const size_t base = b * stride_b + n * stride_n + (size_t)h0 * stride_h + x * 2 * Q + q0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        T* __restrict__ t = pass == 0 ? tokens : tokens2;
+        if (!t) break;
+        float u[kRopeHeads][EPL], v[kRopeHeads][EPL];
+#pragma unroll
+        for (int j = 0; j < kRopeHeads; ++j)
+            if (h0 + j < H) { W::load(t + base + j * stride_h, u[j]); W::load(t + base + j * stride_h + Q, v[j]); }
+#pragma unroll
+        for (int j = 0; j < kRopeHeads; ++j)
+            if (h0 + j < H) {
+                float uo[EPL], vo[EPL];
+#pragma unroll
+                for (int k = 0; k < EPL; ++k) {
+                    uo[k] = u[j][k] * cs[k] - v[j][k] * sn[k];
+                    vo[k] = v[j][k] * cs[k] + u[j][k] * sn[k];
+                }
+                W::store(t + base + j * stride_h, uo);
+                W::store(t + base + j * stride_h + Q, vo);
+            }
     }
-    *reinterpret_cast<typename V::type*>(up) = V::pack(uo);
-    *reinterpret_cast<typename V::type*>(up + Q) = V::pack(vo);
 }
 
 // Scalar path: any D % 4 == 0, any alignment.  One lane per (token, head, half, q).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict__ tokens,
+__global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict__ tokens, T* __restrict__ tokens2,
                                                                    const int64_t* __restrict__ pos, int N, int H,
                                                                    int D, int64_t stride_b, int64_t stride_n, int64_t stride_h,
                                                                    int pos_div, RopeFreq f, size_t total) {
@@ -116,42 +133,48 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict
     const int x = e / Q, q = e - x * Q;
     const size_t b = token / N, n = token - b * N;
     const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
-    T* __restrict__ up = tokens + b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q;
-    const float u = to_f<T>(up[0]), v = to_f<T>(up[Q]);
     float s, c;
     sincosf(p * f.inv[q], &s, &c);
-    up[0] = from_f<T>(u * c - v * s);
-    up[Q] = from_f<T>(v * c + u * s);
+    const size_t o = b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q;
+    for (int pass = 0; pass < 2; ++pass) {
+        T* __restrict__ up = (pass == 0 ? tokens : tokens2);
+        if (!up) break;
+        up += o;
+        const float u = to_f<T>(up[0]), v = to_f<T>(up[Q]);
+        up[0] = from_f<T>(u * c - v * s);
+        up[Q] = from_f<T>(v * c + u * s);
+    }
 }
 
 template <typename T>
-static hipError_t launch_rope_t(void* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
-                                int64_t sh, int pos_div, const RopeFreq& f, hipStream_t stream) {
+static hipError_t launch_rope_t(void* tokens, void* tokens2, const int64_t* pos, int B, int N, int H, int D, int64_t sb,
+                                int64_t sn, int64_t sh, int pos_div, const RopeFreq& f, hipStream_t stream) {
     const int Q = D / 4;
-    const size_t align = 4 * sizeof(T);
-    const bool vec = (Q % 4 == 0) && (reinterpret_cast<uintptr_t>(tokens) % align == 0) && (sb % 4 == 0) &&
-                     (sn % 4 == 0) && (sh % 4 == 0);
+    constexpr int EPL = Wide<T>::N;
+    const bool vec = (Q % EPL == 0) && (reinterpret_cast<uintptr_t>(tokens) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(tokens2) % 16 == 0) && (sb % EPL == 0) && (sn % EPL == 0) &&
+                     (sh % EPL == 0);
     if (vec) {
-        const size_t total = (size_t)B * N * H * (D / 8);
+        const size_t total = (size_t)B * N * ((H + kRopeHeads - 1) / kRopeHeads) * 2 * (Q / EPL);
         spf_rope2d_vec_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            static_cast<T*>(tokens), pos, N, H, D, sb, sn, sh, pos_div, f, total);
+            static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, total);
     } else {
         const size_t total = (size_t)B * N * H * 2 * Q;
         spf_rope2d_scalar_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            static_cast<T*>(tokens), pos, N, H, D, sb, sn, sh, pos_div, f, total);
+            static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, total);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_rope2d(void* tokens, const int64_t* pos, int B, int N, int H, int D, int64_t sb, int64_t sn,
-                         int64_t sh, int pos_div, int dtype, float base, float fwd, hipStream_t stream) {
+hipError_t launch_rope2d(void* tokens, void* tokens2, const int64_t* pos, int B, int N, int H, int D, int64_t sb,
+                         int64_t sn, int64_t sh, int pos_div, int dtype, float base, float fwd, hipStream_t stream) {
     RopeFreq f;
     const int Q = D / 4;
     for (int q = 0; q < 64; ++q) f.inv[q] = q < Q ? fwd / powf(base, q / float(Q)) : 0.f;
     switch (dtype) {
-        case 0: return launch_rope_t<float>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
-        case 1: return launch_rope_t<__half>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
-        default: return launch_rope_t<__hip_bfloat16>(tokens, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        case 0: return launch_rope_t<float>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        case 1: return launch_rope_t<__half>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        default: return launch_rope_t<__hip_bfloat16>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
     }
 }
 

@@ -137,6 +137,22 @@ def _background(bg: Tensor, S: int, V: int) -> Tensor:
     return out
 
 
+_tanfov_cache: dict = {}
+
+
+def _tanfov_tensor(tx: float, ty: float, device) -> Tensor:
+    """[1,1,2] device tensor of a settings object's two Python floats.  The reference builds its settings from
+    `.item()` values once per view (cuda_splatting.py:108-109) and a training run sees the same few cameras' values
+    again and again: the host->device copy (a synchronising call from pageable memory) is paid once per value pair."""
+    key = (tx, ty, device)
+    t = _tanfov_cache.get(key)
+    if t is None:
+        if len(_tanfov_cache) >= 4096:
+            _tanfov_cache.clear()
+        t = _tanfov_cache[key] = torch.tensor([[[tx, ty]]], dtype=torch.float32, device=device)
+    return t
+
+
 def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -601,7 +617,7 @@ class GaussianRasterizer(torch.nn.Module):
         if viewmatrix is None:
             raise Exception("viewmatrix is a forward argument of this rasterizer (cuda_splatting.py:137)")
         dev = means3D.device
-        tanfov = torch.tensor([[[float(s.tanfovx), float(s.tanfovy)]]], dtype=torch.float32, device=dev)
+        tanfov = _tanfov_tensor(float(s.tanfovx), float(s.tanfovy), dev)
 
         def render(shs_, colors_, bg, m2d=None):
             return rasterize_batch(

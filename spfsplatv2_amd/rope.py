@@ -24,8 +24,8 @@ from . import _lib
 _DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
-def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
-    """In-place RoPE-2D on ``tokens`` (B,N,H,D); ``fwd`` = +F0 forward, -F0 backward."""
+def _check(tokens: torch.Tensor, positions: torch.Tensor) -> None:
+    """The reference's argument checks (curope.cpp:54-59, kernels.cu:91-94), same messages."""
     if tokens.dim() != 4:
         raise RuntimeError("tokens must have 4 dimensions")
     if positions.dim() != 3:
@@ -41,7 +41,7 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
     if not tokens.is_cuda:
         raise RuntimeError("rope_2d: tokens are on the CPU; this build only runs on a HIP device "
                            "(no CPU fallback)")
-    B, N, H, D = tokens.shape
+    D = tokens.shape[3]
     if not (tokens.stride(3) == 1 and tokens.stride(2) == D):
         raise RuntimeError("tokens are not contiguous")
     if not positions.is_contiguous():
@@ -52,7 +52,31 @@ def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: flo
         raise RuntimeError("token dim must be multiple of 4")
     if tokens.dtype not in _DTYPES:
         raise RuntimeError(f"rope_2d: unsupported dtype {tokens.dtype}")
+
+
+def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """In-place RoPE-2D on ``tokens`` (B,N,H,D); ``fwd`` = +F0 forward, -F0 backward."""
+    _check(tokens, positions)
+    B, N, H, D = tokens.shape
     _launch(tokens, positions, B, N, H, D, tokens.stride(0), tokens.stride(1), D, 1, base, fwd)
+
+
+def rope_2d_pair(q: torch.Tensor, k: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
+    """``rope_2d`` on two tensors of the same shape, strides and dtype in ONE launch -- q and k of an attention layer,
+    typically two views of one qkv buffer (croco/blocks.py:97-104 rotates them with two calls): the angles are
+    evaluated once.  Falls back to two calls when the layouts differ."""
+    if q.shape != k.shape or q.stride() != k.stride() or q.dtype != k.dtype or q.device != k.device:
+        rope_2d(q, positions, base, fwd)
+        rope_2d(k, positions, base, fwd)
+        return
+    _check(q, positions)
+    B, N, H, D = q.shape
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        stream = C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+        _lib.check(lib.spf_rope2d_pair(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()),
+                                       C.c_void_p(positions.data_ptr()), B, N, H, D, q.stride(0), q.stride(1), D, 1,
+                                       _DTYPES[q.dtype], float(base), float(fwd), stream), "spf_rope2d_pair")
 
 
 def _launch(tokens, positions, B, N, H, D, sb, sn, sh, pos_div, base, fwd) -> None:

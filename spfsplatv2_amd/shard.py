@@ -32,9 +32,12 @@ def view_shard(n_views: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_views, world))
 
 
-def allreduce_gaussian_grads(grads: Sequence[torch.Tensor | None], group=None) -> None:
-    """In-place SUM all-reduce of a list of gradient tensors through one flat bucket."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+def allreduce_gaussian_grads(grads: Sequence[torch.Tensor | None], group=None, skip_single: bool = True) -> None:
+    """In-place SUM all-reduce of a list of gradient tensors through one flat bucket.  `skip_single=False` runs the
+    bucket through the backend even in a world of one (a pre-flight of the RCCL path on a single-GPU box)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    if skip_single and dist.get_world_size(group) == 1:
         return
     live = [g for g in grads if g is not None]
     if not live:

@@ -141,3 +141,54 @@ def test_bench_streams2_micro_batches(hip_lib):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["renders_per_step"] == 4 and "2 micro-batches" in out["config"]["launch"]
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_rccl_preflight_world_of_one(hip_lib):
+    """The first 8-GPU run must not be the first time RCCL executes: under the driver's own launcher form
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 ...`, /root/reference/src/main.py:141-145 is what it
+    stands in for) bench.py initialises the `nccl` (= RCCL) process group with `device_id`, synchronises its ranks with
+    RCCL barriers, and -- with --allreduce -- sums the Gaussian gradients through the flat bucket ON THE DEVICE (no host
+    staging); the line it prints is a normal single-GPU line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+            "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3",
+            "--warmup", "1", "--min-trials", "2", "--min-seconds", "0", "--scenes", "2", "--views", "2",
+            "--no-cpu-baseline"]
+    for extra in ([], ["--allreduce"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["process_group"] == "nccl"
+        if extra:
+            assert "all-reduce" in out["config"]["sharding"]
+
+
+def _nccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from spfsplatv2_amd import shard
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        gen = torch.Generator().manual_seed(3)
+        grads = [torch.randn(4, 1000, 3, generator=gen).cuda(), None, torch.randn(4, 1000, generator=gen).cuda(),
+                 torch.randn(4, 1000, 3, 4, generator=gen).cuda()]
+        want = [None if g is None else g.clone() for g in grads]
+        shard.allreduce_gaussian_grads(grads, skip_single=False)        # device bucket through RCCL, world of one
+        torch.cuda.synchronize()
+        q.put(all(w is None or torch.equal(g, w) for g, w in zip(grads, want)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_bucket_on_device_through_rccl(hip_lib):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    assert q.get(timeout=10) is True

@@ -130,3 +130,26 @@ def test_random_shapes_vs_c_oracle(hip_lib, seed):
     # round pos * inv_freq before reducing it -- the gate scales with that, 1e-5 at the model's positions (<= 40)
     tol = TOL if pmax <= 40 else 1.5e-7 * pmax * float(want.abs().max()) + TOL
     assert float((got - want).abs().max()) <= tol, (B, N, H, D, base, fwd, pmax, strided)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("H", [1, 3, 4, 12, 16])
+def test_head_loop_and_pair_launch(hip_lib, dtype, tol, H):
+    """Every head-count remainder of the four-heads-per-lane loop, 16 bytes per lane for every dtype, and q and k of one
+    qkv buffer rotated in ONE launch (`rope_2d_pair`) -- against the C oracle (curope.cpp:11-47 restated) on the values
+    the tensors actually hold."""
+    import spfsplatv2_amd as spf
+    gen = torch.Generator().manual_seed(5 + H)
+    B, N, D = 2, 37, 64
+    qkv = torch.randn(B, N, 3, H, D, generator=gen).to(dtype)
+    pos = torch.randint(0, 18, (B, N, 2), generator=gen)
+    want_q = util.rope_oracle(qkv[:, :, 0].float(), pos, 100.0, 1.0)
+    want_k = util.rope_oracle(qkv[:, :, 1].float(), pos, 100.0, 1.0)
+    dq = qkv.to("cuda")
+    spf.rope_2d_pair(dq[:, :, 0], dq[:, :, 1], pos.to("cuda"), 100.0, 1.0)
+    assert float((dq[:, :, 0].float().cpu() - want_q).abs().max()) < tol * max(1.0, float(want_q.abs().max()))
+    assert float((dq[:, :, 1].float().cpu() - want_k).abs().max()) < tol * max(1.0, float(want_k.abs().max()))
+    assert torch.equal(dq[:, :, 2].cpu(), qkv[:, :, 2])                     # v untouched
+    single = qkv.to("cuda")
+    spf.rope_2d(single[:, :, 0], pos.to("cuda"), 100.0, 1.0)
+    assert torch.equal(single[:, :, 0], dq[:, :, 0])                        # pair launch == single launch, bit for bit
