@@ -380,8 +380,6 @@ __host__ __device__ inline int hist_view_group(int V, int T) {
     const int fit = (32 * 1024) / (4 * T);
     return fit < 1 ? 1 : (fit < V ? fit : V);
 }
-__device__ __forceinline__ uint64_t lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ int dpp_wave_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
 
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
@@ -546,7 +544,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             const uint32_t val = single ? ((1u << kHistCountShift) | area) : 0u;
             const uint32_t pre = wave_iscan_u32(val);
             const int prev_tile = dpp_wave_shr1(tile);
-            const uint64_t heads = lane_ballot(lane == 0 || tile != prev_tile);
+            const uint64_t heads = lane_ballot(tile != prev_tile) | 1ull;   // (no short-circuit around the DPP move:
+                                                                            //  it must run with every lane active)
             const bool is_end = lane == kWave - 1 || ((heads >> (lane + 1)) & 1ull);
             const int head = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
             const uint32_t before = (uint32_t)__shfl((int)pre, max(head - 1, 0), kWave);
@@ -641,9 +640,12 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         opac = in.opacities[sg];
     }
     (void)opac;
-    float R[9], N0[9];
-    quat_rot(q, R);
-    scale_columns(R, sx, sy, sz, N0);
+    float N0[9];
+    {
+        float R[9];
+        quat_rot(q, R);
+        scale_columns(R, sx, sy, sz, N0);
+    }
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
 
     float dp0[3] = {0.f, 0.f, 0.f};          // dL/dmean3D
@@ -933,7 +935,12 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         }
     }
     if (gr.dL_dscales && gr.dL_drotations) {
-        // N[i][k] = R[i][k] s_k
+        // N[i][k] = R[i][k] s_k.  R is rebuilt from the quaternion here rather than carried through the view loop (nine
+        // registers; the compiler would otherwise keep the copy it made for N0 alive: hence the opaque quaternion)
+        float4 q2 = q;
+        asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+        float R[9];
+        quat_rot(q2, R);
         const float sv[3] = {sx, sy, sz};
         float ds[3], dR[9];
 #pragma unroll

@@ -281,7 +281,6 @@ __device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs,
 // Ballot of a lane predicate as the compiler keeps it (an SGPR pair).  HIP's __ballot(int) widens the predicate to
 // 0 / 1 in a VGPR and compares it again (v_cndmask + v_cmp per call); in loops whose body is ~30 instructions that
 // round trip is 5 % of the kernel.
-__device__ __forceinline__ uint64_t lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // Phase A over a box that is already known (the backward needs the clipped box for its slot pool anyway): no second
 // disc_box (an IEEE square root), pixel offsets stepped in float.  dx, dy differ from (float)x - gx by rounding of

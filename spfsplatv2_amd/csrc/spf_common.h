@@ -135,6 +135,29 @@ __device__ __forceinline__ uint32_t wave_iscan_u32(uint32_t x) {
     return t;
 }
 
+// Ballot of a lane predicate as the compiler keeps it (an SGPR pair).  HIP's __ballot(int) widens the predicate to
+// 0 / 1 in a VGPR and compares it again (v_cndmask + v_cmp per call).
+__device__ __forceinline__ uint64_t lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// value of the previous lane (lane 0 receives 0): DPP wave_shr:1
+__device__ __forceinline__ int dpp_wave_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
+
+// Runs of neighbouring lanes with equal keys (a pixel-aligned scene puts whole runs of a wave's Gaussians into the same
+// tile).  Per-lane LDS atomics on one address serialise -- 64 lanes, 64 passes --, so a run acts through its first lane:
+// `head` = first lane of the calling lane's run, `len` (valid in head lanes) = its length.  Keys < 0 never merge with
+// a neighbour's into something that matters: callers ignore runs of negative keys.
+struct LaneRun { int head, len; };
+__device__ __forceinline__ LaneRun lane_runs(int key, int lane) {
+    // (the DPP move must run with every lane active: `lane == 0 || key != dpp(key)` short-circuits it under a partial
+    //  exec mask and lane 1 then reads an inactive lane 0)
+    const int prev = dpp_wave_shr1(key);
+    const uint64_t heads = lane_ballot(key != prev) | 1ull;
+    LaneRun r;
+    r.head = 63 - __builtin_clzll(heads & (~0ull >> (63 - lane)));
+    const uint64_t above = lane < 63 ? heads >> (lane + 1) : 0ull;
+    r.len = (above ? lane + 1 + __builtin_ctzll(above) : kWave) - lane;
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
