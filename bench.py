@@ -130,7 +130,9 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--s-mult", type=float, default=1.0)
     ap.add_argument("--min-trials", type=int, default=25, help="back-to-back repetitions of the --steps loop")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="GPU work the trials must add up to")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="GPU work the trials must add up to (3 s: longer than the sampling period of an outside GPU "
+                         "activity monitor)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle time to spend")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact", action="store_true",
@@ -199,12 +201,13 @@ def launch_ranks(args, argv: list[str]) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def valu_roofline(kernel: str, launch_ms: float, default_workload: bool, chunks: int = 1):
+def valu_roofline(kernel: str, launch_ms: float, default_workload, chunks: int = 1):
     """VALU-issue roofline of the dominant kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, so
     frac = wave-instructions x 4 / (CUs x SIMDs x clock x launch time).  Wave-instructions per launch come from the SQ
-    counter pass committed under profiles/ (SQ_INSTS_VALU, collected on exactly the default workload)."""
-    prof = ROOT / "profiles" / "sq_summary.json"
-    if not (prof.exists() and default_workload):
+    counter pass committed under profiles/ (SQ_INSTS_VALU in sq_summary_<config>.json, collected on exactly that config's
+    default workload; `default_workload` = the config's name, or None when the run is not that workload)."""
+    prof = ROOT / "profiles" / f"sq_summary_{default_workload}.json"
+    if not (default_workload and prof.exists()):
         return None
     try:
         insts = json.loads(prof.read_text())[kernel]["SQ_INSTS_VALU_per_launch"] / chunks   # (counted on whole-call launches)
@@ -494,9 +497,10 @@ def main():
             dom_bytes = stage_bytes(dom, 1, 1, G, K, P, D_total // (S * V))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
-        prof = ROOT / "profiles" / "pmc_summary.json"
-        default_workload = (args.config == "C2" and S == 8 and V == 4 and args.s_mult == 1.0 and not args.allreduce
-                            and len(micro) == 1)
+        # the counter passes under profiles/ (tools/refresh_profiles.sh) were collected per config on its default batch
+        default_workload = args.config if ((S, V) == WORKLOADS[args.config] and args.s_mult == 1.0 and
+                                           not args.allreduce and len(micro) == 1 and args.api == "batched") else None
+        prof = ROOT / "profiles" / f"pmc_summary_{args.config}.json"
         kernel = _lib.stage_kernel_name(dom)
         if prof.exists() and default_workload:      # the PMC passes were collected on exactly this workload
             try:

@@ -185,14 +185,17 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
  *                                   Pass ONE buffer laid out tile_count | tile_flags | tile_start (R*T+1) | tile_fill |
  *                                   counters (4) [| padding] and clear all of it (16*R*T + 20 bytes rounded up to 16;
  *                                   16-byte aligned);
- *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing; because tile_fill and
- *                                   the counters arrive zeroed as well, the tile scan runs with one block per render
- *                                   instead of a single block;
+ *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing.  `cleared_bytes` says how
+ *                                   much of that buffer (from tile_count on) the caller cleared: all of it -> the tile scan
+ *                                   runs with one block per render instead of a single block; only the first 8*R*T bytes
+ *                                   (the two count arrays) or a buffer laid out differently -> the self-initialising
+ *                                   single-block scan; less -> the call clears the counts itself.  Nothing is assumed;
  *   spf_camera_backward_partials  = the deterministic sum of g->vpartial [R,nblk,12] (as written by spf_raster_backward
  *                                   when g->vpartial != NULL; pass g->dL_dviewmatrix = NULL to skip its own reduction)
  *                                   AND spf_camera_backward, in ONE kernel. */
 int spf_decoder_prepare(const SpfCamera* cam, void* zero, uint64_t zero_bytes, void* stream);
-int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream);
+int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, uint64_t cleared_bytes,
+                                        void* stream);
 int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, int32_t nblk, float* dL_dextrinsics,
                                  void* stream);
 

@@ -64,7 +64,7 @@ SYMBOLS = {
                                       C.POINTER(SpfGrads), C.c_uint64, C.c_uint32, C.c_void_p]),
     "spf_decoder_prepare": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_uint64, C.c_void_p]),
     "spf_raster_forward_project_prepared": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),
-                                                      C.c_void_p]),
+                                                      C.c_uint64, C.c_void_p]),
     "spf_camera_backward_partials": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "spf_mse_partial_blocks": (C.c_int, []),
     "spf_mse_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -276,7 +276,8 @@ int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float
     return SPF_OK;
 }
 
-static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, bool tiles_cleared, void* stream_) {
+// tiles_cleared: 0 = nothing (this call clears the counts), 1 = tile_count | tile_flags, 2 = all the tile bookkeeping
+static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, int tiles_cleared, void* stream_) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -302,17 +303,27 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     {
         StageScope t(SPF_STAGE_SCAN, stream);
         SPF_HIP(spf::launch_tile_scan(*st, d->S * d->V, tiles_x * tiles_y, spf_raster_view_partial_blocks(d->G),
-                                      spf::dense_threshold(), tiles_cleared, stream));
+                                      spf::dense_threshold(), tiles_cleared == 2, stream));
     }
     return SPF_OK;
 }
 
 int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
-    return forward_project(d, in, st, false, stream_);
+    return forward_project(d, in, st, 0, stream_);
 }
 
-int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, void* stream_) {
-    return forward_project(d, in, st, true, stream_);
+int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, SpfState* st, uint64_t cleared_bytes,
+                                        void* stream_) {
+    // `cleared_bytes`: how much of tile_count | tile_flags | tile_start | tile_fill | counters (one buffer, in this order)
+    // the caller cleared.  All of it: one-block-per-render scan.  Only the two count arrays (the older contract): the
+    // self-initialising single-block scan.  Less than that: this call clears the counts itself.
+    if (!d || !st) return fail(SPF_E_INVALID, "dims / state is null");
+    const uint64_t RT = (uint64_t)d->S * d->V * spf_raster_num_tiles(d->H, d->W);
+    const bool laid_out = st->tile_count && st->tile_flags == st->tile_count + RT && st->tile_start == st->tile_flags + RT &&
+                          st->tile_fill == st->tile_start + RT + 1 && st->counters == st->tile_fill + RT;
+    if (laid_out && cleared_bytes >= 4 * (4 * RT + 5)) return forward_project(d, in, st, 2, stream_);
+    if (laid_out && cleared_bytes >= 8 * RT) return forward_project(d, in, st, 1, stream_);
+    return forward_project(d, in, st, 0, stream_);
 }
 
 int spf_decoder_prepare(const SpfCamera* cam, void* zero, uint64_t zero_bytes, void* stream_) {

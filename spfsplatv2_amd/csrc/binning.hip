@@ -10,6 +10,8 @@
 // Result contract (Appendix B #10): every tile's list is ordered by (depth bits, Gaussian index)
 // ascending.  Keys are unique, so the result does not depend on the (non-deterministic) order in
 // which the atomics fill a bin.
+#include <atomic>
+
 #include "spf_common.h"
 
 namespace spf {
@@ -612,16 +614,16 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {
         // the opt-in to 128 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device
-        static bool attr_set[64] = {};
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev]) {
+        static std::atomic<bool> attr_set[64];          // (zero-initialised; the attribute is idempotent, so two host
+        int dev = 0;                                      //  threads racing here at worst both set it)
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_lds_kernel<1024>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e != hipSuccess) return e;
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_sort_tiles_big_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
             if (e != hipSuccess) return e;
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 8192, 16384);
     }

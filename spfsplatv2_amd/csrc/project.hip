@@ -6,6 +6,8 @@
 // its rasterizer (/root/reference/src/model/decoder/decoder_splatting_cuda.py:59-64).
 //
 // Semantics: SURVEY.md Appendix B #1-#9 (restated in oracle/splat_ref.py::project).
+#include <atomic>
+
 #include "spf_common.h"
 
 namespace spf {
@@ -620,7 +622,12 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         if (gr.vpartial)
             for (int i = threadIdx.x; i < d.V * 12; i += kBlock)
                 gr.vpartial[((size_t)(s * d.V + i / 12) * nblk + blockIdx.x) * 12 + i % 12] = nan;
+        else if (gr.dL_dviewmatrix)       // (a caller that reduces the partials itself: poison the result directly)
+            for (int i = threadIdx.x; i < d.V * 16; i += kBlock) gr.dL_dviewmatrix[(size_t)s * d.V * 16 + i] = nan;
         if (!live) return;
+        if (gr.dL_dmeans2D)
+            for (int v = 0; v < d.V; ++v)
+                for (int k = 0; k < 3; ++k) gr.dL_dmeans2D[((size_t)(s * d.V + v) * d.G + g) * 3 + k] = nan;
         for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * sg + k] = nan;
         gr.dL_dopacities[sg] = nan;
         if (gr.dL_dcolors) for (int k = 0; k < 3; ++k) gr.dL_dcolors[3 * sg + k] = nan;
@@ -1009,12 +1016,12 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
         if (sh_stage_out(d.V, d.K)) lds += (size_t)128 * 3 * d.K * sizeof(float);   // staged dL/dsh, half a block at a time
         if (lds > 64 * 1024) {
             // more than the default 64 KB of dynamic LDS: opt in, once per device and instantiation
-            static bool attr_set[64] = {};
+            static std::atomic<bool> attr_set[64];      // (per instantiation; idempotent attribute, see binning.hip)
             int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev]) {
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_project_bwd_kernel<DEG, NATIVE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (dev >= 0 && dev < 64) attr_set[dev] = true;
+                if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
             }
         }
     }

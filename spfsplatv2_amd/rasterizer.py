@@ -41,6 +41,24 @@ class CallRecord(dict):
 _last = CallRecord()
 
 
+_warned_band4 = False
+
+
+def _note_band4_not_evaluated(sh_degree: int, sh_band4: bool) -> None:
+    """One warning per process when a d_sh = 25 model (sh_degree 4: the reference's shipped configuration,
+    config/model/encoder/spfsplatv2.yaml:20) is rendered WITHOUT band 4 because nobody chose: whether the `pose` fork
+    evaluates band 4 cannot be checked offline (oracle/PINNING.md row 9b) -- an open parity risk, not a settled
+    default; `SPF_SH_BAND4=1` / `decoder.sh_band4 = True` / `settings.sh_band4` evaluate it."""
+    global _warned_band4
+    if sh_degree == 4 and not sh_band4 and not _warned_band4 and "SPF_SH_BAND4" not in os.environ:
+        _warned_band4 = True
+        import warnings
+        warnings.warn("spfsplatv2_amd: sh_degree 4 (25 SH coefficients) is evaluated to degree 3 like the published 3DGS "
+                      "kernels; whether the reference's rasterizer fork evaluates band 4 is unknown (oracle/PINNING.md). "
+                      "Set SPF_SH_BAND4=1 (or sh_band4=True) to evaluate it, SPF_SH_BAND4=0 to silence this note.",
+                      stacklevel=3)
+
+
 def sh_band4_default() -> bool:
     """Whether SH band 4 of a d_sh = 25 model is evaluated when the caller does not say: the ``SPF_SH_BAND4``
     environment variable ("1" = yes).  Default off: the published 3DGS kernels stop at degree 3 and only carry the
@@ -213,7 +231,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         # pass: see spf_tile_scan_render_kernel)
         _lib.check(lib.spf_decoder_prepare(C.byref(camera), _ptr(tiles), 4 * tiles.numel(), stream),
                    "spf_decoder_prepare")
-        _lib.check(lib.spf_raster_forward_project_prepared(C.byref(dims), C.byref(inp), C.byref(st), stream),
+        _lib.check(lib.spf_raster_forward_project_prepared(C.byref(dims), C.byref(inp), C.byref(st),
+                                                           4 * tiles.numel(), stream),
                    "spf_raster_forward_project_prepared")
     else:
         if camera is not None:
@@ -469,6 +488,7 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     native = sh_layout == "g3k"
     if sh_band4 is None:
         sh_band4 = sh_band4_default()
+        _note_band4_not_evaluated(sh_degree, sh_band4)
     if shs is not None:
         K = shs.shape[3 if native else 2]
         if K < (min(sh_degree, 4 if sh_band4 else 3) + 1) ** 2:
@@ -520,6 +540,7 @@ def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacitie
     S, G, _ = means3D.shape
     if sh_band4 is None:
         sh_band4 = sh_band4_default()
+        _note_band4_not_evaluated(sh_degree, sh_band4)
     if viewmatrix.dim() != 4:
         raise RuntimeError(f"viewmatrix must be [S,V,4,4], got {tuple(viewmatrix.shape)}")
     V = viewmatrix.shape[1]

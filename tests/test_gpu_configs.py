@@ -23,6 +23,8 @@ SH_C0 = 0.28209479177387814
 
 
 # ---- oracle parity at full size --------------------------------------------------------------------------------
+# knife-edge budget: the measured fraction of flagged pixels (profiles/r03_parity_reports.jsonl) + one point
+FRAGILE_CAP = {"C3": 0.06, "C5": 0.06}
 @pytest.mark.parametrize("config,min_pairs,min_list", [("C3", 250000, 1025), ("C5", 400000, 513)])
 def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
     """BASELINE configs 3 and 5 at FULL size, forward and every gradient, one (scene, view) each: 320,000 Gaussians at
@@ -32,8 +34,10 @@ def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
     ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
     prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
     # lists of >1000 entries per pixel: proportionally more pixels sit next to an alpha / transmittance threshold
-    rep = util.compare(prod, ref, max_fragile_frac=0.06)
+    rep = util.compare(prod, ref, max_fragile_frac=FRAGILE_CAP[config])
     rep.update(num_pairs=prod["stats"]["num_pairs"], max_tile_list=prod["stats"]["max_tile_list"])
+    from tests.test_gpu_raster import _report
+    _report(f"{config.lower()}_full_size", rep)
     assert not rep["fails"], rep
     assert prod["stats"]["num_pairs"] >= min_pairs and prod["stats"]["max_tile_list"] >= min_list, prod["stats"]
     if config == "C5":

@@ -1,32 +1,40 @@
 #!/bin/bash
 # Regenerate everything under profiles/ on a GPU box (run from the repo root).  Outputs go to gpurun_out/refresh/;
-# copy them into profiles/ afterwards (see profiles/README.md for the names).
+# copy them into profiles/ afterwards (tools/install_profiles.sh r03).   CONFIGS="C2 REF2V" limits the per-config part.
 set -u
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/refresh
-mkdir -p "$OUT"
-python bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
-python bench.py --config C3 --no-cpu-baseline > "$OUT/bench_c3.json" 2>> "$OUT/bench_c2.err"
-python bench.py --config C5 --no-cpu-baseline > "$OUT/bench_c5.json" 2>> "$OUT/bench_c2.err"
-python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_ref2v.json" 2>> "$OUT/bench_c2.err"
-SPF_SH_BAND4=1 python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_ref2v_band4.json" 2>> "$OUT/bench_c2.err"
-python bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_c2_streams2.json" 2>> "$OUT/bench_c2.err"
-python bench.py --eager --no-cpu-baseline > "$OUT/bench_c2_eager.json" 2>> "$OUT/bench_c2.err"
-python tools/bench_rope.py > "$OUT/rope_bench.json" 2>> "$OUT/bench_c2.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- \
-    python bench.py --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- \
-    python bench.py --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- \
-    python bench.py --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
-F=$(find "$OUT/pmc_fetch" -name '*counter_collection.csv' | head -1)
-W=$(find "$OUT/pmc_write" -name '*counter_collection.csv' | head -1)
-python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_summary.json"
-find "$OUT/stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_bench_c2.csv" \;
-tools/pmc_passes.sh refresh spf_ > "$OUT/sq_passes.log" 2>&1
-cp gpurun_out/pmc_refresh.txt "$OUT/sq_counters.txt"; cp gpurun_out/sq_summary_refresh.json "$OUT/sq_summary.json"
-# keep the merge-back small
-find "$OUT" -name '*kernel_trace.csv' -delete
-find "$OUT" -name '*counter_collection.csv' -delete
-find "$OUT" -name '*agent_info.csv' -delete
+rm -rf "$OUT"; mkdir -p "$OUT"
+ERR="$OUT/bench.err"
+for cfg in ${CONFIGS:-C2 REF2V C3 C5}; do
+  extra=""; [ "$cfg" != "C2" ] && extra="--no-cpu-baseline"
+  # the bench line itself (graph replay, default batch of the config)
+  python bench.py --config $cfg $extra > "$OUT/bench_$cfg.json" 2>> "$ERR"
+  # per-kernel durations of THE SAME command
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$cfg" -o stats -- \
+      python bench.py --config $cfg --no-cpu-baseline > "$OUT/stats_$cfg.log" 2>&1
+  find "$OUT/stats_$cfg" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$cfg.csv" \;
+  # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (eager launches: counters serialise the kernels anyway)
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$cfg" -o fetch -- \
+      python bench.py --config $cfg --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_fetch_$cfg.log" 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$cfg" -o write -- \
+      python bench.py --config $cfg --eager --steps 5 --warmup 2 --min-trials 1 --min-seconds 0 --no-cpu-baseline > "$OUT/pmc_write_$cfg.log" 2>&1
+  F=$(find "$OUT/pmc_fetch_$cfg" -name '*counter_collection.csv' | head -1)
+  W=$(find "$OUT/pmc_write_$cfg" -name '*counter_collection.csv' | head -1)
+  python tools/pmc_summary.py "$F" "$W" "$OUT/pmc_summary_$cfg.json" > "$OUT/pmc_summary_$cfg.txt"
+  # SQ counters (issue, LDS, waits), five passes
+  PMC_ARGS="--config $cfg" tools/pmc_passes.sh refresh_$cfg spf_ > "$OUT/sq_passes_$cfg.log" 2>&1
+  cp gpurun_out/pmc_refresh_$cfg.txt "$OUT/sq_counters_$cfg.txt"; cp gpurun_out/sq_summary_refresh_$cfg.json "$OUT/sq_summary_$cfg.json"
+  rm -rf "$OUT/stats_$cfg" "$OUT/pmc_fetch_$cfg" "$OUT/pmc_write_$cfg"
+done
+if [ -z "${CONFIGS:-}" ]; then
+  SPF_SH_BAND4=1 python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_REF2V_band4.json" 2>> "$ERR"
+  python bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_C2_streams2.json" 2>> "$ERR"
+  python bench.py --eager --no-cpu-baseline > "$OUT/bench_C2_eager.json" 2>> "$ERR"
+  python bench.py --scenes 64 --views 4 --no-cpu-baseline > "$OUT/bench_C2_64x4.json" 2>> "$ERR"
+  python bench.py --api per-view --no-cpu-baseline --steps 5 --warmup 2 --min-trials 5 --min-seconds 0 > "$OUT/bench_perview.json" 2>> "$ERR"
+  for c in 2 4; do SPF_CHUNKS=$c python bench.py --no-cpu-baseline > "$OUT/bench_C2_chunks$c.json" 2>> "$ERR"; done
+  python tools/bench_rope.py > "$OUT/rope_bench.txt" 2>> "$ERR"; cp gpurun_out/rope_bench.json "$OUT/rope_bench.json"
+fi
+find "$OUT" -name '*.log' -size +200k -delete
 ls -la "$OUT"
