@@ -24,7 +24,7 @@ SH_C0 = 0.28209479177387814
 
 # ---- oracle parity at full size --------------------------------------------------------------------------------
 # knife-edge budget: the measured fraction of flagged pixels (profiles/r03_parity_reports.jsonl) + one point
-FRAGILE_CAP = {"C3": 0.06, "C5": 0.06}
+FRAGILE_CAP = {"C3": 0.05, "C5": 0.035}       # measured 0.037 / 0.021
 @pytest.mark.parametrize("config,min_pairs,min_list", [("C3", 250000, 1025), ("C5", 400000, 513)])
 def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
     """BASELINE configs 3 and 5 at FULL size, forward and every gradient, one (scene, view) each: 320,000 Gaussians at
