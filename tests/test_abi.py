@@ -69,3 +69,18 @@ def test_product_refuses_cpu_tensors(hip_lib):
         spf.rasterize_batch(torch.zeros(1, G, 3), torch.ones(1, G, 3), torch.ones(1, G, 4), torch.ones(1, G),
                             torch.zeros(1, G, 1, 3), None, torch.eye(4)[None, None], torch.eye(4)[None, None],
                             torch.ones(1, 1, 2), torch.zeros(3), 16, 16, 0)
+
+
+def test_chunk_planning_is_off_by_default_and_whole_scenes(hip_lib, monkeypatch):
+    """spf_raster_chunks: 1 unless SPF_CHUNKS asks; whole scenes per chunk (the backward needs that), single scenes
+    split by views in the forward only, never more chunks than units."""
+    monkeypatch.delenv("SPF_CHUNKS", raising=False)
+    assert hip_lib.spf_raster_chunks(8, 4, 256, 256, 0) == 1 and hip_lib.spf_raster_chunks(8, 4, 256, 256, 1) == 1
+    monkeypatch.setenv("SPF_CHUNKS", "4")
+    assert hip_lib.spf_raster_chunks(8, 4, 256, 256, 0) == 4 and hip_lib.spf_raster_chunks(8, 4, 256, 256, 1) == 4
+    assert hip_lib.spf_raster_chunks(3, 2, 256, 256, 0) == 3                  # never more chunks than scenes
+    assert hip_lib.spf_raster_chunks(1, 8, 512, 512, 0) == 4                  # one scene: by views, forward only
+    assert hip_lib.spf_raster_chunks(1, 8, 512, 512, 1) == 1
+    monkeypatch.setenv("SPF_CHUNKS", "1")
+    assert hip_lib.spf_raster_chunks(8, 4, 256, 256, 0) == 1
+    assert hip_lib.spf_raster_chunks(0, 4, 256, 256, 0) == 1                  # nonsense sizes: one chain

@@ -55,3 +55,16 @@ def test_float32_oracle_agrees_with_the_frozen_float64_values(golden_dir):
     ok = ~want["fragile"]
     assert float(((got["color"].double() - want["color"]).abs() * ok[:, :, None]).max()) < 1e-4
     assert float(((got["alpha"].double() - want["alpha"]).abs() * ok[:, :, None]).max()) < 1e-4
+
+
+def test_float32_arbiter_passes_where_float32_suffices(golden_dir):
+    """`util.float32_resolvable` (the second arbiter of the fuzz harness: the oracle's own float32 evaluation through
+    the same gates and mask) finds nothing to complain about on an ordinary case -- it only ever excuses inputs on
+    which a plain float32 evaluation of the published formulas cannot meet the tolerances itself."""
+    case, batch = load_case(golden_dir, "test_k4_two_views")
+    ref = util.run_oracle(batch, torch.float64, background=case["background"], scale_invariant=case["scale_invariant"],
+                          mask_fragile=True, band4=case["band4"])
+    rep = util.float32_resolvable(batch, ref, background=case["background"], scale_invariant=case["scale_invariant"],
+                                  band4=case["band4"])
+    assert rep["fails"] == [], rep
+    assert rep["rgb_max"] < 2e-5 and max(v for k, v in rep.items() if k.startswith("g_")) < 1e-4
