@@ -46,6 +46,7 @@ struct Proj {
     bool inx, iny;             // clamp inactive
     float m0[3], m1[3];        // rows of M = J * Wcv
     float J00, J02, J11, J12;
+    float fx, fy, itz;         // focal lengths in pixels, 1 / t.z
     float b0[3], b1[3];        // rows of B = M N (N already carries the render's world scale)
     float a, b, c;             // 2-D covariance B B^T + 0.3 I
 };
@@ -56,7 +57,7 @@ struct Proj {
 // z = 0.25 sits behind a translation of tens of units -- float32 lost five digits of z there (and 1/z^2 scales the
 // whole footprint).  12 half-rate fmas per (Gaussian, view).
 __device__ __forceinline__ void project_point(const float p[3], const float p0[3], kfloat_p Vm, kdouble_p M64,
-                                              kfloat_p Pm, float tanx, float tany,
+                                              kfloat_p Pm, float tanx, float tany, float fx, float fy,
                                               int H, int W, const float N[9], float nscale, Proj& o) {
     if (M64) {
         const double x = p0[0], y = p0[1], z = p0[2];
@@ -76,14 +77,20 @@ __device__ __forceinline__ void project_point(const float p[3], const float p0[3
     o.px = ((o.homx * o.pw + 1.0f) * W - 1.0f) * 0.5f;
     o.py = ((o.homy * o.pw + 1.0f) * H - 1.0f) * 0.5f;
 
-    const float fx = W / (2.0f * tanx), fy = H / (2.0f * tany);
-    const float limx = kFovClamp * tanx, limy = kFovClamp * tany;
-    const float txz = o.tx / o.tz, tyz = o.ty / o.tz;
-    o.inx = fabsf(txz) <= limx;
-    o.iny = fabsf(tyz) <= limy;
-    o.tcx = o.inx ? o.tx : fminf(limx, fmaxf(-limx, txz)) * o.tz;
-    o.tcy = o.iny ? o.ty : fminf(limy, fmaxf(-limy, tyz)) * o.tz;
+    // `fx`, `fy` = W / (2 tan fov_x), H / (2 tan fov_y): the same for every Gaussian of a view, so the two IEEE divisions
+    // are done once per block and view (view_focal), not once per (Gaussian, view).
+    o.fx = fx; o.fy = fy;
+    // Frustum clamp: t.x / t.z is held inside +-1.3 tan fov.  |t.x / t.z| <= lim is decided as
+    // |t.x| <= lim * t.z (t.z > 0 for every Gaussian that is kept) and a clamped t.x is +-lim * t.z outright: two IEEE
+    // divisions per (Gaussian, view) less.  Value and gradient are continuous across the boundary, so the one-ulp
+    // difference between the two forms of the test moves nothing.
+    const float limx = kFovClamp * tanx * o.tz, limy = kFovClamp * tany * o.tz;
+    o.inx = fabsf(o.tx) <= limx;
+    o.iny = fabsf(o.ty) <= limy;
+    o.tcx = o.inx ? o.tx : copysignf(limx, o.tx);
+    o.tcy = o.iny ? o.ty : copysignf(limy, o.ty);
     const float itz = 1.0f / o.tz;
+    o.itz = itz;
     o.J00 = fx * itz;
     o.J11 = fy * itz;
     o.J02 = -fx * o.tcx * itz * itz;
@@ -102,6 +109,29 @@ __device__ __forceinline__ void project_point(const float p[3], const float p0[3
     o.a = o.b0[0] * o.b0[0] + o.b0[1] * o.b0[1] + o.b0[2] * o.b0[2] + kLowPass;
     o.b = o.b0[0] * o.b1[0] + o.b0[1] * o.b1[1] + o.b0[2] * o.b1[2];
     o.c = o.b1[0] * o.b1[0] + o.b1[1] * o.b1[1] + o.b1[2] * o.b1[2] + kLowPass;
+}
+
+// Focal lengths of the scene's views, one view per LANE (lane v holds view v's pair; V <= 64): the view loop then
+// fetches them with v_readlane (the view index is uniform).  Scenes with more views fall back to the division per view.
+struct LaneFocal { float fx, fy; };
+__device__ __forceinline__ LaneFocal lane_focal(const float* __restrict__ tanfov, int s, int V, int H, int W, int lane) {
+    LaneFocal f = {0.f, 0.f};
+    if (V <= kWave && lane < V) {
+        const float tanx = tanfov[2 * (s * V + lane)], tany = tanfov[2 * (s * V + lane) + 1];
+        f.fx = W / (2.0f * tanx);
+        f.fy = H / (2.0f * tany);
+    }
+    return f;
+}
+__device__ __forceinline__ void view_focal(const LaneFocal& f, int V, int v, float tanx, float tany, int H, int W,
+                                           float& fx, float& fy) {
+    if (V <= kWave) {
+        fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.fx), v));
+        fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.fy), v));
+    } else {
+        fx = W / (2.0f * tanx);
+        fy = H / (2.0f * tany);
+    }
 }
 
 // det of the low-passed 2-D covariance WITHOUT the cancellation of a*c - b*b.  By Cauchy-Binet det(B B^T) is the sum
@@ -417,6 +447,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
     }
+    const LaneFocal lf = lane_focal(in.tanfov, s, d.V, d.H, d.W, lane);
     const int g_wave0 = blockIdx.x * kBlock + wave * kWave;              // first Gaussian of this wave
     const int n_wave = min(kWave, d.G - g_wave0);                        // its live Gaussians (<= 0: none)
 
@@ -432,7 +463,9 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
 
         Proj pr;
-        project_point(p, p0, Vm, M64, Pm, tanx, tany, d.H, d.W, N0, sc, pr);
+        float fx, fy;
+        view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
+        project_point(p, p0, Vm, M64, Pm, tanx, tany, fx, fy, d.H, d.W, N0, sc, pr);
         const float det = stable_det(pr);
         bool ok = live && pr.tz > kNearCull && det != 0.0f;
         float radius = 0.f;
@@ -487,9 +520,10 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             // opacity * exp(-q/2) < 1/255, i.e. when q > 2 ln(255 * opacity).
             float cull_r2;
             const float thr = 2.0f * __logf(255.0f * opac);
-            const float mu = 0.5f * (cA + cC) - sqrtf(0.25f * (cA - cC) * (cA - cC) + cB * cB);
+            // (hardware square root and reciprocal, 1 ulp each: the 0.1 % slack below is four orders above that)
+            const float mu = 0.5f * (cA + cC) - __builtin_amdgcn_sqrtf(0.25f * (cA - cC) * (cA - cC) + cB * cB);
             if (!(255.0f * opac > 1.0f)) cull_r2 = -1.0f;                       // never reaches 1/255
-            else if (mu > 0.f) cull_r2 = (thr * 1.001f + 1e-3f) / mu * 1.001f;  // slack for rounding
+            else if (mu > 0.f) cull_r2 = (thr * 1.001f + 1e-3f) * __builtin_amdgcn_rcpf(mu) * 1.001f;  // slack for rounding
             else cull_r2 = 3.0e38f;
             if (!(cull_r2 == cull_r2)) cull_r2 = 3.0e38f;
 
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             // could only have held pixels whose alpha is < 1/255, i.e. pairs that contribute nothing (the 3-sigma
             // rect above stays what `radii` reports).
             {
-                const DiscBox db = disc_box(pr.px, pr.py, cull_r2);
+                const DiscBox db = disc_box_fast(pr.px, pr.py, cull_r2);
                 if (!db.any) {
                     x1 = x0; y1 = y0;
                 } else {
@@ -514,12 +548,15 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             rec0 = make_float4(pr.px, pr.py, cA, cB);
             rec1 = make_float4(cC, opac, pr.tz, cull_r2);
             rec2 = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
-            area = disc_area_capped(pr.px, pr.py, cull_r2);
+            area = disc_area_capped_fast(pr.px, pr.py, cull_r2);
         }
         if (live) {
-            st.radii[rg] = ok ? (int)radius : 0;
-            st.rect[rg] = rect_w;
-            st.zkey[rg] = zk;
+            // (uniform per-render base + the lane's 32-bit index: scalar base, one 32-bit offset register for all three)
+            const size_t rbase = (size_t)r * d.G;
+            const uint32_t gl = (uint32_t)g;
+            (st.radii + rbase)[gl] = ok ? (int)radius : 0;
+            (st.rect + rbase)[gl] = rect_w;
+            (st.zkey + rbase)[gl] = zk;
         }
         // ---- the wave's 64 records: own 48 bytes into LDS (conflict-free at this stride), contiguous 16-byte pieces out ----
         s_rec[3 * lane] = rec0; s_rec[3 * lane + 1] = rec1; s_rec[3 * lane + 2] = rec2;
@@ -664,6 +701,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
 
     extern __shared__ float s_part[];        // [min(V, kViewChunk)][4 waves][12]: viewmatrix partials of a chunk of views
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const LaneFocal lf = lane_focal(in.tanfov, s, d.V, d.H, d.W, lane);
     // SH only: six floats per view that every thread parks for ITSELF (no barrier): see sh_grad_from_parked
     float* __restrict__ s_park = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + threadIdx.x;
     constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
@@ -802,7 +840,9 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 }
             }
             Proj pr;
-            project_point(p, p0, Vm, M64, Pm, tanx, tany, d.H, d.W, N0, sc, pr);
+            float fx, fy;
+            view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
+            project_point(p, p0, Vm, M64, Pm, tanx, tany, fx, fy, d.H, d.W, N0, sc, pr);
             float dt[3] = {0.f, 0.f, gdepth};  // dL/dt (view space)
 
             // ---- pixel centre -> t (through the projection matrix) ----
@@ -841,8 +881,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 dV[3 * j + 2] += dm0[j] * pr.J02 + dm1[j] * pr.J12;
             }
             {
-                const float fx = d.W / (2.0f * tanx), fy = d.H / (2.0f * tany);
-                const float itz = 1.0f / pr.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+                const float itz = pr.itz, itz2 = itz * itz, itz3 = itz2 * itz;
                 if (pr.inx) dt[0] += -fx * itz2 * dJ02;
                 if (pr.iny) dt[1] += -fy * itz2 * dJ12;
                 dt[2] += -fx * itz2 * dJ00 - fy * itz2 * dJ11 + 2.f * fx * pr.tcx * itz3 * dJ02 +

@@ -16,6 +16,7 @@
 // would have skipped anyway, so results are identical to the un-culled loop.
 //
 // Semantics: SURVEY.md Appendix B #10/#11 (restated in oracle/splat_ref.py::composite).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "spf_common.h"
@@ -259,6 +260,9 @@ static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-thr
 // C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
 // spelled out so that the forward and the backward replay evaluate it identically (same hit decisions).
 typedef float v2f __attribute__((ext_vector_type(2)));
+#ifdef SPF_PHASE_CLOCKS
+__device__ unsigned long long g_cand_count[2];      // forward lists kernel: candidates (bits set) of live pixels, hits
+#endif
 
 constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
 constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
@@ -412,6 +416,13 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             scatter_box(s_pm, tid, gx, gy, r2, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
         }
         __syncthreads();
+#ifdef SPF_PHASE_CLOCKS
+        if (inside) {
+            unsigned c_ = 0;
+            for (int w = 0; w < kStage / 32; ++w) c_ += __popc(s_pm[w][pid]);
+            atomicAdd(&g_cand_count[0], (unsigned long long)c_);
+        }
+#endif
         if (!wave_done && !ABLATE(8) && !ABLATE(9) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
             const char* __restrict__ wcol = reinterpret_cast<const char*>(&s_pm[0][pid]);   // word w: wcol + 1024 w
             uint32_t m = *reinterpret_cast<const uint32_t*>(wcol);
@@ -492,6 +503,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         if (__syncthreads_and(wave_done)) break;
     }
     const uint32_t last = last16 >> 4;
+#ifdef SPF_PHASE_CLOCKS
+    if (inside) atomicAdd(&g_cand_count[1], (unsigned long long)hits);
+#endif
     if (inside && !(ABLATE(12) && Tr == 123.f)) {
         const float* __restrict__ bg = bg_all + 3 * r;
         const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
@@ -721,11 +735,13 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
 #ifdef SPF_PHASE_CLOCKS
-// profiling build only (SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS): shader-clock cycles per phase, summed over waves
-__device__ unsigned long long g_phase_cycles[8];
+// profiling build only (SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS): shader-clock cycles per phase; every wave stores its own
+// eight words (no atomics: 260k same-address atomics per launch made the kernel ten times slower and the numbers useless)
+constexpr int kPhaseWaves = 32768;
+__device__ unsigned long long g_phase_buf[kPhaseWaves * 8];
 #define PHASE_INIT() long long ph_t = clock64(); const long long ph_w0 = wall_clock64(); unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}
 #define PHASE_MARK(i) do { const long long t_ = clock64(); ph_acc[i] += (unsigned long long)(t_ - ph_t); ph_t = t_; } while (0)
-#define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&spf::g_phase_cycles[i_], ph_acc[i_]); atomicAdd(&spf::g_phase_cycles[6], (unsigned long long)(wall_clock64() - ph_w0)); atomicAdd(&spf::g_phase_cycles[7], 1ull); } } while (0)
+#define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long* o_ = spf::g_phase_buf + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % spf::kPhaseWaves) * 8; for (int i_ = 0; i_ < 6; ++i_) o_[i_] += ph_acc[i_]; o_[6] += (unsigned long long)(wall_clock64() - ph_w0); o_[7] += 1ull; } } while (0)
 #else
 #define PHASE_INIT()
 #define PHASE_MARK(i)
@@ -872,6 +888,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         // (the barrier that closed the previous round makes s_w / s_wacc / s_pool / s_p* reusable here)
         if (lane == kWave - 1) s_w[wave] = inc;
         __syncthreads();
+        PHASE_MARK(1);
         uint32_t off = inc - size;
         for (int w = 0; w < wave; ++w) off += s_w[w];
         // accepted = a prefix of the threads: thread t is in iff the slot demand of threads 0..t fits the pool; the
@@ -1060,10 +1077,20 @@ extern "C" int spf_debug_set_ablate(int v) {
 #ifdef SPF_PHASE_CLOCKS
 extern "C" int spf_debug_phase_cycles(unsigned long long* out8, int reset) {
     (void)hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(spf::g_phase_cycles), sizeof(g_phase_cycles)) != hipSuccess) return 1;
+    static unsigned long long h[spf::kPhaseWaves * 8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(spf::g_phase_buf), sizeof(h)) != hipSuccess) return 1;
+    {
+        unsigned long long cc[2] = {0, 0}, zz[2] = {0, 0};
+        (void)hipMemcpyFromSymbol(cc, HIP_SYMBOL(spf::g_cand_count), sizeof(cc));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(spf::g_cand_count), zz, sizeof(zz));
+        fprintf(stderr, "forward lists kernel since the last call: %llu candidates, %llu hits\n", cc[0], cc[1]);
+    }
+    for (int j = 0; j < 8; ++j) out8[j] = 0;
+    for (int i = 0; i < spf::kPhaseWaves; ++i)
+        for (int j = 0; j < 8; ++j) out8[j] += h[i * 8 + j];
     if (reset) {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(spf::g_phase_cycles), z, sizeof(z)) != hipSuccess) return 1;
+        static unsigned long long z[spf::kPhaseWaves * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(spf::g_phase_buf), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
 }

@@ -195,7 +195,7 @@ __device__ __forceinline__ DiscBox disc_box(float gx, float gy, float r2) {
 }
 // The same box from the hardware square root (v_sqrt_f32, 1 ulp; the IEEE-correct sqrtf costs ~15 instructions more)
 // for the render kernels, where the box only bounds a loop whose per-pixel test is exact: the 1.0001 / 1e-3 padding
-// covers the ulp.  (The projection kernel keeps disc_box: its tile rects and the binning must agree bit for bit.)
+// covers the ulp.  (The projection kernel uses it too since round 3: the binning reads the rect the projection stored.)
 __device__ __forceinline__ DiscBox disc_box_fast(float gx, float gy, float r2) {
     DiscBox b;
     b.any = r2 >= 0.f;
@@ -207,6 +207,12 @@ __device__ __forceinline__ DiscBox disc_box_fast(float gx, float gy, float r2) {
 // bounding-box area of the disc in pixels, capped at one tile (feeds the per-tile sparse/dense decision)
 __device__ __forceinline__ uint32_t disc_area_capped(float gx, float gy, float r2) {
     const DiscBox b = disc_box(gx, gy, r2);
+    if (!b.any) return 0u;
+    const float w = fminf(fmaxf(b.xhi - b.xlo + 1.f, 0.f), (float)kTile), h = fminf(fmaxf(b.yhi - b.ylo + 1.f, 0.f), (float)kTile);
+    return (uint32_t)(w * h);
+}
+__device__ __forceinline__ uint32_t disc_area_capped_fast(float gx, float gy, float r2) {
+    const DiscBox b = disc_box_fast(gx, gy, r2);
     if (!b.any) return 0u;
     const float w = fminf(fmaxf(b.xhi - b.xlo + 1.f, 0.f), (float)kTile), h = fminf(fmaxf(b.yhi - b.ylo + 1.f, 0.f), (float)kTile);
     return (uint32_t)(w * h);
