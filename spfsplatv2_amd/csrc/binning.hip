@@ -185,26 +185,38 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     if (counters[0] > capacity) return;
     const bool live = g < G;
     const size_t rg = (size_t)r * G + (live ? g : 0);
+    const size_t tb = (size_t)r * T;
+    // The block is a latency chain (65 % of its wave-cycles were spent waiting), so every global read is issued up
+    // front -- the Gaussian's rect and depth key, the block's pair base, and the start of EVERY tile this thread may have
+    // to reserve a range in later (tiles t = tid, tid + 256, ...: up to four per thread, i.e. T <= 1024; 256 x 256 px
+    // is one) -- and the pair numbering shares its barrier with the clearing of the tile counters.
     const uint32_t rc = live ? rect[rg] : 0u;
+    const float zk = live ? zkey[rg] : 0.f;
+    const uint32_t bbase = blk_base[(size_t)r * gridDim.x + blockIdx.x];
+    constexpr int kPre = 4;
+    uint32_t ts_pre[kPre] = {0u, 0u, 0u, 0u};
+    const bool pre = lds && T <= kPre * kBlock;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k)
+            if (threadIdx.x + k * kBlock < T) ts_pre[k] = tile_start[tb + threadIdx.x + k * kBlock];
+    }
     const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
     const bool any = x1 > x0 && y1 > y0;
-    {   // Gaussian-major pair numbering: exclusive scan of pairs-per-Gaussian inside the block + block base
-        const uint32_t cnt = any ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)inc, o, kWave);
-            if (lane >= o) inc += y;
-        }
-        if (lane == kWave - 1) s_wtot[wave] = inc;
-        __syncthreads();
-        uint32_t off = blk_base[(size_t)r * gridDim.x + blockIdx.x] + inc - cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Gaussian-major pair numbering: exclusive scan of pairs-per-Gaussian inside the block + block base
+    const uint32_t cnt = any ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+    const uint32_t inc = wave_iscan_u32(cnt);
+    if (lane == kWave - 1) s_wtot[wave] = inc;
+    if (lds)
+        for (int t = threadIdx.x; t < T; t += kBlock) s_cnt[t] = 0;
+    __syncthreads();
+    {
+        uint32_t off = bbase + inc - cnt;
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
         if (live) pair_off[rg] = off;
     }
-    const uint64_t key = any ? (((uint64_t)__float_as_uint(zkey[rg]) << 32) | (uint32_t)g) : 0ull;
-    const size_t tb = (size_t)r * T;
+    const uint64_t key = any ? (((uint64_t)__float_as_uint(zk) << 32) | (uint32_t)g) : 0ull;
     if (!lds) {
         if (any)
             for (int ty = y0; ty < y1; ++ty)
@@ -214,12 +226,9 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
                 }
         return;
     }
-    for (int t = threadIdx.x; t < T; t += kBlock) s_cnt[t] = 0;
-    __syncthreads();
     // Gaussians with exactly one tile (93 % of a pixel-aligned scene) act run-wise, through the first lane of every run
     // of neighbouring lanes in the same tile: one LDS atomic per run instead of one per lane on the same address.
-    const int lane = threadIdx.x & 63;
-    const bool single = any && (x1 - x0) * (y1 - y0) == 1;
+    const bool single = any && cnt == 1u;
     const int stile = single ? y0 * tiles_x + x0 : -1;
     const LaneRun run = lane_runs(stile, lane);
     const bool run_head = single && run.head == lane;
@@ -228,11 +237,25 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
         for (int ty = y0; ty < y1; ++ty)
             for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1u);
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += kBlock) {
-        const uint32_t c = s_cnt[t];
-        if (c) {
-            s_base[t] = tile_start[tb + t] + atomicAdd(&tile_fill[tb + t], c);
-            s_cnt[t] = 0;
+    if (pre) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+            const int t = threadIdx.x + k * kBlock;
+            if (t < T) {
+                const uint32_t c = s_cnt[t];
+                if (c) {
+                    s_base[t] = ts_pre[k] + atomicAdd(&tile_fill[tb + t], c);
+                    s_cnt[t] = 0;
+                }
+            }
+        }
+    } else {
+        for (int t = threadIdx.x; t < T; t += kBlock) {
+            const uint32_t c = s_cnt[t];
+            if (c) {
+                s_base[t] = tile_start[tb + t] + atomicAdd(&tile_fill[tb + t], c);
+                s_cnt[t] = 0;
+            }
         }
     }
     __syncthreads();

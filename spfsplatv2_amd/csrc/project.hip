@@ -121,6 +121,10 @@ __device__ __forceinline__ LaneFocal lane_focal(const float* __restrict__ tanfov
         f.fx = W / (2.0f * tanx);
         f.fy = H / (2.0f * tany);
     }
+    // The values are read ACROSS lanes later (v_readlane).  The compiler does not know that: left free, it sinks the two
+    // divisions into the divergent region that holds their only "use" (the backward's `if (vis)`), where the lane that
+    // owns a view's pair may be inactive -- degree 4 of the backward did exactly that.  Opaque here, in uniform flow.
+    asm volatile("" : "+v"(f.fx), "+v"(f.fy));
     return f;
 }
 __device__ __forceinline__ void view_focal(const LaneFocal& f, int V, int v, float tanx, float tany, int H, int W,
@@ -458,7 +462,6 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         const kfloat_p Vm = as_const(in.viewmatrix + 16 * r), Pm = as_const(in.projmatrix + 16 * r);
         const kdouble_p M64 = in.viewmatrix64 ? as_const(in.viewmatrix64 + 16 * r) : nullptr;
         const float tanx = as_const(in.tanfov)[2 * r], tany = as_const(in.tanfov)[2 * r + 1];
-        const size_t rg = (size_t)r * d.G + (live ? g : 0);
         const float sc = in.view_scale ? as_const(in.view_scale)[r] : 1.0f;
         const float p[3] = {p0[0] * sc, p0[1] * sc, p0[2] * sc};
 
@@ -742,6 +745,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         const kdouble_p M64 = in.viewmatrix64 ? as_const(in.viewmatrix64 + 16 * r) : nullptr;
         const float tanx = as_const(in.tanfov)[2 * r], tany = as_const(in.tanfov)[2 * r + 1];
         const size_t rg = (size_t)r * d.G + (live ? g : 0);
+        float fx, fy;                                  // (cross-lane read: in uniform control flow, see lane_focal)
+        view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
         float dV[12];  // dL/dVm[4i+j] for i<3 (index 3i+j) and dL/dVm[12+j] (index 9+j)
 #pragma unroll
         for (int k = 0; k < 12; ++k) dV[k] = 0.f;
@@ -840,8 +845,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
                 }
             }
             Proj pr;
-            float fx, fy;
-            view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
             project_point(p, p0, Vm, M64, Pm, tanx, tany, fx, fy, d.H, d.W, N0, sc, pr);
             float dt[3] = {0.f, 0.f, gdepth};  // dL/dt (view space)
 
