@@ -116,6 +116,32 @@ def load() -> C.CDLL:
     return lib
 
 
+_fast = False          # False: not tried yet; None: not available
+
+
+def fast():
+    """The compiled host binding (csrc/torch_binding.cpp -> _spf_torch.so next to the HIP library), or None when it has
+    not been built or SPF_NO_FAST=1.  It drives the same C ABI of the same library -- only the interpreter time of a
+    call differs (rasterizer.py keeps the ctypes path for that case)."""
+    global _fast
+    if _fast is False:
+        _fast = None
+        path = LIB_PATH.parent / "_spf_torch.so"
+        if os.environ.get("SPF_NO_FAST", "0") != "1" and path.exists():
+            load()                                   # the HIP library first (and its ABI check)
+            import importlib.util
+            try:
+                spec = importlib.util.spec_from_file_location("_spf_torch", str(path))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                if mod.abi_version() == ABI_VERSION:
+                    _fast = mod
+            except (ImportError, OSError) as e:      # e.g. built against another torch: fall back, but say so once
+                import warnings
+                warnings.warn(f"spfsplatv2_amd: {path} could not be loaded ({e}); using the ctypes binding")
+    return _fast
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().spf_last_error().decode(errors="replace")

@@ -65,5 +65,40 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     return LIB
 
 
+BINDING_SRC = CSRC / "torch_binding.cpp"
+BINDING = OUT_DIR / "_spf_torch.so"
+
+
+def build_binding(force: bool = False, verbose: bool = True) -> Path:
+    """The compiled host binding for PyTorch callers (csrc/torch_binding.cpp -> _spf_torch.so next to the library):
+    plain g++ against the installed torch's headers -- host code only, no device code, no hipify.  Optional at run time
+    (rasterizer.py falls back to its ctypes path), so a failure here is reported by the caller, not hidden."""
+    import sysconfig
+
+    import torch
+    tdir = Path(torch.__file__).resolve().parent
+    stamp = OUT_DIR / "binding.sha256"
+    h = hashlib.sha256()
+    for p in (BINDING_SRC, HEADERS[1]):
+        h.update(p.read_bytes())
+    h.update(torch.__version__.encode())
+    dig = h.hexdigest()
+    if not force and BINDING.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        return BINDING
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", str(BINDING_SRC), "-o", str(BINDING),
+           f"-I{HEADERS[1].parent}", f"-I{tdir / 'include'}", f"-I{tdir / 'include' / 'torch' / 'csrc' / 'api' / 'include'}",
+           f"-I{sysconfig.get_paths()['include']}", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_spf_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", "-w",
+           f"-L{tdir / 'lib'}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python",
+           f"-L{OUT_DIR}", "-lspfsplat_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir / 'lib'}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    stamp.write_text(dig)
+    return BINDING
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_binding(force="--force" in sys.argv))

@@ -199,11 +199,36 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     V = viewmatrix.shape[1]
     R = S * V
     dev = means3D.device
+    rec_out = _last if record is None else record
+    fast = _lib.fast() if camera is None else None
+    if fast is not None:
+        # the same chain through the compiled binding (csrc/torch_binding.cpp): allocation, structs, launches and the
+        # exact-mode read-back in C++ -- what a per-view caller of the drop-in surface pays b*v times per step
+        if max_pairs is None:
+            capacity, max_tile, dense = -1, 0, 0
+        else:
+            capacity, max_tile, dense = _plan_numbers(max_pairs, R * lib.spf_raster_num_tiles(H, W))
+        with _spf_errors():
+            ts, (D, max_tile, dense, RT) = fast.raster_forward(
+                means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale,
+                view64, H, W, sh_degree, float(scale_modifier), int(sh_layout), bool(sh_band4), capacity, max_tile, dense)
+        image, depth, alpha, radii_v, rec, rect, tiles, pairs, pair_idx, final_T, n_contrib = ts
+        counters = tiles[4 * RT + 1:4 * RT + 5]
+        if max_pairs is None:
+            rec_out.update(num_pairs=D, max_tile_list=max_tile, dense_tiles=dense, tiles=RT, counters=None)
+            if rec_out is not _last:
+                _last.update(rec_out)
+        else:
+            rec_out["counters"] = counters
+            _last["counters"] = counters
+            if _plan_mode(max_pairs) == 1 and nothing_needs_grad and not torch.cuda.is_current_stream_capturing():
+                _raise_if_plan_failed(counters, pairs.numel())
+        return ((image, depth, alpha, radii_v),
+                (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
     K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)))
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
-    rec_out = _last if record is None else record
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -249,11 +274,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         if rec_out is not _last:
             _last.update(rec_out)
     else:
-        plan = max_pairs if isinstance(max_pairs, PairBudget) else PairBudget(int(max_pairs))
-        capacity, max_tile = int(plan.capacity), int(plan.max_tile_list)
-        dense = 0xFFFFFFFF if plan.dense_tiles is None else (R * T if plan.dense_tiles < 0 else int(plan.dense_tiles))
-        if 0 < dense < R * T:
-            dense = 0xFFFFFFFF      # only "none" and "all" are assumptions the device can check
+        capacity, max_tile, dense = _plan_numbers(max_pairs, R * T)
         rec_out["counters"] = counters
         _last["counters"] = counters
     pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
@@ -269,6 +290,28 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         _raise_if_plan_failed(counters, pairs.numel())
     return ((image, depth, alpha, radii.view(S, V, G)),
             (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
+
+
+def _plan_numbers(max_pairs, RT: int):
+    """(capacity, longest-list hint, dense-tile hint) of a planned call as spf_raster_forward_render takes them."""
+    plan = max_pairs if isinstance(max_pairs, PairBudget) else PairBudget(int(max_pairs))
+    dense = 0xFFFFFFFF if plan.dense_tiles is None else (RT if plan.dense_tiles < 0 else int(plan.dense_tiles))
+    if 0 < dense < RT:
+        dense = 0xFFFFFFFF      # only "none" and "all" are assumptions the device can check
+    return int(plan.capacity), int(plan.max_tile_list), dense
+
+
+class _spf_errors:
+    """Library failures raised inside the compiled binding arrive as RuntimeError("SPF: ..."): re-raise them as the
+    SpfError the ctypes path raises (everything else -- out of memory, a bad tensor -- passes through unchanged)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is RuntimeError and str(ev).startswith("SPF: "):
+            raise _lib.SpfError(str(ev)[5:]) from None
+        return False
 
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
@@ -312,6 +355,17 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     # with `pair_buffer_overflowed` after a replay)
     if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
         _raise_if_plan_failed(tiles[4 * R * T + 1:], pairs.numel())
+    fast = _lib.fast()
+    if fast is not None:
+        wv = want["view"]
+        with _spf_errors():
+            out = fast.raster_backward(
+                means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale,
+                view64, rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, H, W, sh_degree,
+                float(scale_modifier), int(sh_layout), bool(sh_band4), int(dense), grads_out[0], grads_out[1],
+                grads_out[2], bool(want["scales_rot"]), bool(want["shs"]), bool(want["colors"]),
+                2 if wv == "partials" else (1 if wv else 0), bool(want["means2D"]))
+        return tuple(out)
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout), int(sh_band4))
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)

@@ -84,3 +84,29 @@ def test_chunk_planning_is_off_by_default_and_whole_scenes(hip_lib, monkeypatch)
     monkeypatch.setenv("SPF_CHUNKS", "1")
     assert hip_lib.spf_raster_chunks(8, 4, 256, 256, 0) == 1
     assert hip_lib.spf_raster_chunks(0, 4, 256, 256, 0) == 1                  # nonsense sizes: one chain
+
+
+def test_compiled_host_binding_loads_and_can_be_switched_off(hip_lib, monkeypatch):
+    """csrc/torch_binding.cpp -> _spf_torch.so: the same C ABI driven from C++ (no compute here).  It is optional at
+    run time: absent or SPF_NO_FAST=1, rasterizer.py keeps its ctypes path."""
+    import pytest
+
+    from spfsplatv2_amd import _lib, build
+    try:
+        build.build_binding(verbose=False)
+    except Exception as e:  # noqa: BLE001  (no g++ / torch headers: nothing to test)
+        pytest.skip(f"binding does not build here: {e}")
+    monkeypatch.setattr(_lib, "_fast", False)
+    monkeypatch.delenv("SPF_NO_FAST", raising=False)
+    mod = _lib.fast()
+    assert mod is not None and mod.abi_version() == _lib.ABI_VERSION
+    assert callable(mod.raster_forward) and callable(mod.raster_backward)
+    import torch
+    with pytest.raises(Exception):                      # CPU tensors never reach a launch
+        mod.raster_forward(torch.zeros(1, 4, 3), torch.ones(1, 4, 3), torch.ones(1, 4, 4), torch.ones(1, 4), None,
+                           torch.zeros(1, 4, 3), torch.eye(4)[None, None], torch.eye(4)[None, None],
+                           torch.ones(1, 1, 2), torch.zeros(1, 1, 3), None, None, 16, 16, 0, 1.0, 0, False, -1, 0, 0)
+    monkeypatch.setattr(_lib, "_fast", False)
+    monkeypatch.setenv("SPF_NO_FAST", "1")
+    assert _lib.fast() is None
+    monkeypatch.setattr(_lib, "_fast", False)
