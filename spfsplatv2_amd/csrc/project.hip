@@ -127,9 +127,12 @@ __device__ __forceinline__ LaneFocal lane_focal(const float* __restrict__ tanfov
     asm volatile("" : "+v"(f.fx), "+v"(f.fy));
     return f;
 }
+// LANES = false (degree >= 2: the kernels are bound by the coefficient traffic and short of registers, measured 2 - 4 %
+// slower with the per-lane pair and its early wait): the plain division per view.
+template <bool LANES>
 __device__ __forceinline__ void view_focal(const LaneFocal& f, int V, int v, float tanx, float tany, int H, int W,
                                            float& fx, float& fy) {
-    if (V <= kWave) {
+    if (LANES && V <= kWave) {
         fx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.fx), v));
         fy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f.fy), v));
     } else {
@@ -451,7 +454,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
     }
-    const LaneFocal lf = lane_focal(in.tanfov, s, d.V, d.H, d.W, lane);
+    constexpr bool kLaneFocal = DEG <= 1;
+    const LaneFocal lf = kLaneFocal ? lane_focal(in.tanfov, s, d.V, d.H, d.W, lane) : LaneFocal{0.f, 0.f};
     const int g_wave0 = blockIdx.x * kBlock + wave * kWave;              // first Gaussian of this wave
     const int n_wave = min(kWave, d.G - g_wave0);                        // its live Gaussians (<= 0: none)
 
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
 
         Proj pr;
         float fx, fy;
-        view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
+        view_focal<kLaneFocal>(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
         project_point(p, p0, Vm, M64, Pm, tanx, tany, fx, fy, d.H, d.W, N0, sc, pr);
         const float det = stable_det(pr);
         bool ok = live && pr.tz > kNearCull && det != 0.0f;
@@ -554,12 +558,10 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             area = disc_area_capped_fast(pr.px, pr.py, cull_r2);
         }
         if (live) {
-            // (uniform per-render base + the lane's 32-bit index: scalar base, one 32-bit offset register for all three)
-            const size_t rbase = (size_t)r * d.G;
-            const uint32_t gl = (uint32_t)g;
-            (st.radii + rbase)[gl] = ok ? (int)radius : 0;
-            (st.rect + rbase)[gl] = rect_w;
-            (st.zkey + rbase)[gl] = zk;
+            // (per-lane 64-bit index as is: a scalar per-render base plus a 32-bit lane offset saves a few address
+            //  instructions but measured 10 % SLOWER on the SH-heavy forwards -- K = 16: 139 -> 152 us, K = 25: 167 -> 187)
+            const size_t rg_ = (size_t)r * d.G + g;
+            st.radii[rg_] = ok ? (int)radius : 0; st.rect[rg_] = rect_w; st.zkey[rg_] = zk;
         }
         // ---- the wave's 64 records: own 48 bytes into LDS (conflict-free at this stride), contiguous 16-byte pieces out ----
         s_rec[3 * lane] = rec0; s_rec[3 * lane + 1] = rec1; s_rec[3 * lane + 2] = rec2;
@@ -704,7 +706,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
 
     extern __shared__ float s_part[];        // [min(V, kViewChunk)][4 waves][12]: viewmatrix partials of a chunk of views
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const LaneFocal lf = lane_focal(in.tanfov, s, d.V, d.H, d.W, lane);
+    constexpr bool kLaneFocal = DEG <= 1;
+    const LaneFocal lf = kLaneFocal ? lane_focal(in.tanfov, s, d.V, d.H, d.W, lane) : LaneFocal{0.f, 0.f};
     // SH only: six floats per view that every thread parks for ITSELF (no barrier): see sh_grad_from_parked
     float* __restrict__ s_park = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + threadIdx.x;
     constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         const float tanx = as_const(in.tanfov)[2 * r], tany = as_const(in.tanfov)[2 * r + 1];
         const size_t rg = (size_t)r * d.G + (live ? g : 0);
         float fx, fy;                                  // (cross-lane read: in uniform control flow, see lane_focal)
-        view_focal(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
+        view_focal<kLaneFocal>(lf, d.V, v, tanx, tany, d.H, d.W, fx, fy);
         float dV[12];  // dL/dVm[4i+j] for i<3 (index 3i+j) and dL/dVm[12+j] (index 9+j)
 #pragma unroll
         for (int k = 0; k < 12; ++k) dV[k] = 0.f;

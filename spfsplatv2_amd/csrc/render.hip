@@ -290,12 +290,35 @@ __device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs,
 // disc_box (an IEEE square root), pixel offsets stepped in float.  dx, dy differ from (float)x - gx by rounding of
 // the steps only (relative 1e-7) while the disc carries 0.2 % of slack over every pixel that can reach alpha = 1/255
 // (project.hip), so the candidate set stays a superset of the contributors.
+#ifndef SPF_SCATTER4
+#define SPF_SCATTER4 1
+#endif
 __device__ __forceinline__ void scatter_box(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2, int X0, int Y0,
                                             int xl, int yl, int bw, int bh) {
     uint32_t* __restrict__ wp = s_pm[i >> 5] + yl * kTile + xl;
     const uint32_t bit = 1u << (i & 31);
     const float dx0 = (float)(X0 + xl) - gx;
     float dy = (float)(Y0 + yl) - gy;
+#if SPF_SCATTER4
+    // Rows outside, FOUR columns per trip inside: a pixel-aligned footprint is 2 - 4 pixels wide, so the column loop of
+    // the plain form ran once or twice per row and paid two branches and half a dozen scalar instructions per pixel for
+    // it (divergent loops are waterfalls of exec-mask bookkeeping); unrolled, a pixel is its test and a predicated LDS OR.
+    for (int y = 0; y < bh; ++y) {
+        const float dy2 = dy * dy;
+        float dx = dx0;
+        for (int x = 0; x < bw; x += 4) {
+            const int left = bw - x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = dx + (float)k;
+                if (k < left && !(fmaf(d, d, dy2) > r2)) atomicOr(&wp[x + k], bit);
+            }
+            dx += 4.f;
+        }
+        dy += 1.f;
+        wp += kTile;
+    }
+#else
     for (int y = 0; y < bh; ++y) {
         const float dy2 = dy * dy;
         float dx = dx0;
@@ -306,6 +329,7 @@ __device__ __forceinline__ void scatter_box(uint32_t (*s_pm)[kStage], int i, flo
         dy += 1.f;
         wp += kTile;
     }
+#endif
 }
 
 // The cull disc's pixel box clipped to tile (X0, Y0): first column / row inside the tile, width, height (0: empty).
