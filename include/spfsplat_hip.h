@@ -238,6 +238,13 @@ int spf_mse_forward(const float* prediction, const float* image, int64_t n, floa
                     float* loss, void* stream);
 int spf_mse_backward(const float* prediction, const float* image, int64_t n, float weight, const float* dL_dloss,
                      float* dL_dprediction, void* stream);
+/* The same forward that ALSO writes dL_dprediction_unit[i] = (2 * weight / n) * (prediction[i] - image[i]) -- the gradient
+ * for dL_dloss = 1 -- so that the backward is spf_mse_scale_grad: dL_dprediction[i] *= dL_dloss[0] in place, which returns
+ * after one scalar read when dL_dloss[0] is exactly 1 (what `loss.backward()` passes): the backward of the loss costs a
+ * launch instead of a pass over prediction, image and gradient. */
+int spf_mse_forward_grad(const float* prediction, const float* image, int64_t n, float weight, float* partial,
+                         float* loss, float* dL_dprediction_unit, void* stream);
+int spf_mse_scale_grad(float* dL_dprediction, int64_t n, const float* dL_dloss, void* stream);
 
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n, stride_h) and
  * stride(D) == 1; dtype: 0 = float32, 1 = float16, 2 = bfloat16.  positions[B / pos_div, N, 2] int64 contiguous

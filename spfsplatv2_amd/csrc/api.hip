@@ -21,7 +21,8 @@ hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, f
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
 int mse_partial_blocks();
-hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, hipStream_t);
+hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, float, float*, hipStream_t);
+hipError_t launch_mse_scale(float*, int64_t, const float*, hipStream_t);
 hipError_t launch_mse_bwd(const float*, const float*, int64_t, float, const float*, float*, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
 hipError_t launch_camera_bwd(const SpfCamera&, const float*, float*, hipStream_t);
@@ -470,8 +471,28 @@ int spf_mse_forward(const float* prediction, const float* image, int64_t n, floa
     if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
     if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image)) & 15)
         return fail(SPF_E_INVALID, "mse: prediction / image must be 16-byte aligned");
-    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss,
+    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss, 0.f, nullptr,
                                 static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_mse_forward_grad(const float* prediction, const float* image, int64_t n, float weight, float* partial,
+                         float* loss, float* dL_dprediction_unit, void* stream_) {
+    if (!prediction || !image || !partial || !loss || !dL_dprediction_unit) return fail(SPF_E_INVALID, "mse: null pointer");
+    if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
+    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image) |
+         reinterpret_cast<uintptr_t>(dL_dprediction_unit)) & 15)
+        return fail(SPF_E_INVALID, "mse: tensors must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss, 2.0f * weight / (float)n,
+                                dL_dprediction_unit, static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
+}
+
+int spf_mse_scale_grad(float* dL_dprediction, int64_t n, const float* dL_dloss, void* stream_) {
+    if (!dL_dprediction || !dL_dloss) return fail(SPF_E_INVALID, "mse: null pointer");
+    if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
+    if (reinterpret_cast<uintptr_t>(dL_dprediction) & 15) return fail(SPF_E_INVALID, "mse: tensors must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_scale(dL_dprediction, n, dL_dloss, static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 

@@ -58,13 +58,23 @@ class _Mse(torch.autograd.Function):
         # losses at the same time never share it
         partial = torch.empty(lib.spf_mse_partial_blocks(), dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
+        # when a backward will come, the forward pass also writes the gradient for dL/dloss = 1 (what
+        # `loss.backward()` passes): the backward is then one scalar look at the upstream gradient
+        unit = torch.empty_like(p) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.spf_mse_forward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
-                                           float(weight), C.c_void_p(partial.data_ptr()),
-                                           C.c_void_p(loss.data_ptr()), stream),
-                       "spf_mse_forward")
+            if unit is not None:
+                _lib.check(lib.spf_mse_forward_grad(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
+                                                    float(weight), C.c_void_p(partial.data_ptr()),
+                                                    C.c_void_p(loss.data_ptr()), C.c_void_p(unit.data_ptr()), stream),
+                           "spf_mse_forward_grad")
+            else:
+                _lib.check(lib.spf_mse_forward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
+                                               float(weight), C.c_void_p(partial.data_ptr()),
+                                               C.c_void_p(loss.data_ptr()), stream),
+                           "spf_mse_forward")
         ctx.save_for_backward(p, t)
+        ctx.unit = unit
         ctx.weight = float(weight)
         ctx.shape = prediction.shape
         return loss
@@ -75,12 +85,20 @@ class _Mse(torch.autograd.Function):
         lib = _lib.load()
         dev = p.device
         g = g.to(torch.float32).contiguous()
-        gp = torch.empty_like(p)
+        unit, ctx.unit = ctx.unit, None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.spf_mse_backward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(), ctx.weight,
-                                            C.c_void_p(g.data_ptr()), C.c_void_p(gp.data_ptr()), stream),
-                       "spf_mse_backward")
+            if unit is not None:
+                # first backward through this node: the forward's unit gradient, scaled in place by dL/dloss (a no-op
+                # launch when that is 1).  The buffer is handed to autograd; a second backward (retain_graph) recomputes.
+                gp = unit
+                _lib.check(lib.spf_mse_scale_grad(C.c_void_p(gp.data_ptr()), gp.numel(), C.c_void_p(g.data_ptr()), stream),
+                           "spf_mse_scale_grad")
+            else:
+                gp = torch.empty_like(p)
+                _lib.check(lib.spf_mse_backward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
+                                                ctx.weight, C.c_void_p(g.data_ptr()), C.c_void_p(gp.data_ptr()), stream),
+                           "spf_mse_backward")
         gp = gp.view(ctx.shape)
         gi = -gp if ctx.needs_input_grad[1] else None
         return gp, gi, None

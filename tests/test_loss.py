@@ -112,3 +112,30 @@ def test_hip_loss_accepts_what_the_reference_expression_accepts(hip_lib):
     torch.cuda.synchronize()
     assert all(torch.equal(x, l1[0]) for x in l1) and all(torch.equal(x, l2[0]) for x in l2)
     assert _rel(l1[0], want) < 2e-6
+
+
+@pytest.mark.gpu
+def test_hip_loss_unit_gradient_from_the_forward_and_second_backward(hip_lib):
+    """The forward writes the gradient for dL/dloss = 1; the first backward scales that buffer in place (a no-op launch
+    for 1), a second backward through the same node (retain_graph) recomputes from the inputs."""
+    from spfsplatv2_amd import loss as L
+    gen = torch.Generator().manual_seed(11)
+    a = torch.rand(2, 2, 3, 33, 31, generator=gen).cuda().requires_grad_(True)       # 12,276 floats: n % 4 == 0; tail below
+    b = torch.rand(2, 2, 3, 33, 31, generator=gen).cuda()
+    want = 0.5 * 2.0 / a.numel() * (a.detach() - b)
+    l = L.mse_loss(a, b, 0.5)
+    l.backward(retain_graph=True)
+    g1 = a.grad.clone()
+    assert float((g1 - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    a.grad = None
+    (2.0 * l).backward()                                  # second time through the node, upstream 2
+    assert float((a.grad - 2.0 * g1).abs().max()) <= 2e-6 * float(want.abs().max())
+    # upstream != 1 on the FIRST backward: the in-place scaling pass; odd element count: the tail
+    a2 = torch.rand(7, 5, 3, generator=gen).cuda().requires_grad_(True)               # 105 floats
+    b2 = torch.rand(7, 5, 3, generator=gen).cuda()
+    (L.mse_loss(a2, b2) * 0.125).backward()
+    want2 = 0.125 * 2.0 / 105 * (a2.detach() - b2)
+    assert float((a2.grad - want2).abs().max()) <= 1e-6 * float(want2.abs().max())
+    # no backward coming: nothing extra is written, the value is the same
+    with torch.no_grad():
+        assert torch.equal(L.mse_loss(a, b, 0.5), l.detach())
