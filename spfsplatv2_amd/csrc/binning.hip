@@ -455,16 +455,7 @@ __device__ __forceinline__ void block_step(uint64_t (&r)[E], uint64_t* __restric
 }
 
 template <int E>
-__global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint32_t* __restrict__ tile_start,
-                                                                      const uint32_t* __restrict__ counters,
-                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                      uint32_t lo) {
-    __shared__ uint64_t s_x[E * kBlock];
-    if (counters[0] > capacity) return;
-    const uint32_t b = tile_start[blockIdx.x];
-    const uint32_t n = tile_start[blockIdx.x + 1] - b;
-    if (n <= lo || n > (uint32_t)(kBlock * E)) return;
-    uint64_t* __restrict__ p = pairs + b;
+__device__ __forceinline__ void sort_tile_in_block(uint64_t* __restrict__ p, uint32_t n, uint64_t* __restrict__ s_x) {
     const int t = threadIdx.x, lane = t & (kWave - 1);
     uint64_t r[E];
 #pragma unroll
@@ -486,6 +477,49 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint
         const uint32_t e = (uint32_t)(E * t + k);
         if (e < n) p[e] = r[k];
     }
+}
+
+template <int E>
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint32_t* __restrict__ tile_start,
+                                                                      const uint32_t* __restrict__ counters,
+                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                      uint32_t lo) {
+    __shared__ uint64_t s_x[E * kBlock];
+    if (counters[0] > capacity) return;
+    const uint32_t b = tile_start[blockIdx.x];
+    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    if (n <= lo || n > (uint32_t)(kBlock * E)) return;
+    sort_tile_in_block<E>(pairs + b, n, s_x);
+}
+
+// The three size classes of the "few tiles, long lists" family in ONE launch (lists of 2 .. 2048 entries): blocks
+// 0 .. RT-1 take one tile each when its list has 513 .. 2048 entries (four waves on one list: 4 or 8 keys per thread),
+// blocks RT .. RT + ceil(RT/4) - 1 take four tiles each, one per wave, when their lists have 2 .. 512 entries.  The
+// classes touch disjoint tiles, and each alone is a one-round kernel that leaves most of the chip idle (REF2V: 4,096
+// tiles -- 30 % short lists, 70 % of 513 .. 1024, a handful longer: 15 + 23 + 12 us back to back); the long lists are
+// dispatched first.  Same networks, same lists bit for bit.
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(const uint32_t* __restrict__ tile_start,
+                                                                      const uint32_t* __restrict__ counters,
+                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                      int RT) {
+    __shared__ uint64_t s_x[8 * kBlock];
+    if (counters[0] > capacity) return;
+    if ((int)blockIdx.x < RT) {
+        const uint32_t b = tile_start[blockIdx.x];
+        const uint32_t n = tile_start[blockIdx.x + 1] - b;
+        if (n <= 512u || n > 2048u) return;
+        if (n <= 1024u) sort_tile_in_block<4>(pairs + b, n, s_x);
+        else sort_tile_in_block<8>(pairs + b, n, s_x);
+        return;
+    }
+    const int tile = ((int)blockIdx.x - RT) * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (tile >= RT) return;
+    const uint32_t b = tile_start[tile];
+    const uint32_t n = tile_start[tile + 1] - b;
+    if (n <= 1u || n > 512u) return;
+    if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
+    else if (n <= 4u * kWave) sort_tile_in_wave<4>(pairs + b, n);
+    else sort_tile_in_wave<8>(pairs + b, n);
 }
 
 // Lists longer than the LDS classes (> 16384 entries: degenerate scenes where one tile holds a large part of the
@@ -620,7 +654,10 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
     // 65 us with blocks)
     const char* force = getenv("SPF_SORT_BLOCKS");       // (tests: "0" / "1" pin one of the two families)
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
-    if (mx > 1 && (mx <= 512 || blocks))  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
+    const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
+    if (mixed)
+        spf_sort_tiles_mixed_kernel<<<RT + wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, RT);
+    if (mx > 1 && (mx <= 512 || blocks) && !mixed)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                           capacity, 1, RT);
     if (mx > 512 && !blocks)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
@@ -629,9 +666,9 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                             capacity, 1024, RT);
-    if (mx > 512 && blocks)      // 513 .. 1024: one block per tile, 4 keys per thread
+    if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 512);
-    if (mx > 1024 && blocks)     // 1025 .. 2048: 8 keys per thread
+    if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread
         spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1024);
     if (mx > 2048)
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
