@@ -492,6 +492,64 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint
     sort_tile_in_block<E>(pairs + b, n, s_x);
 }
 
+// ---- per-tile sort, one PAIR of waves per tile (many tiles, lists up to 1024) --------------------------------------
+// A launch of one wave per tile is a single round of waves (eight per SIMD on the 32-render bench step), and a SIMD
+// then runs as long as the SUM of the lists it happened to get: 570 instructions for a 256-slot network, 1,320 for 512
+// slots, ~3,000 for 1,024 -- the unluckiest SIMD carries +40 %.  Here a list of more than 256 entries is shared by the
+// two waves of a 128-thread block (each sorts its half exactly as before, the last merge starts with one exchange
+// through LDS), so every wave of the launch carries about the same load; shorter lists use the first wave only.
+template <int E, bool MIRROR>
+__device__ __forceinline__ void pair_step(uint64_t (&r)[E], uint64_t* __restrict__ s, int t, int tmask) {
+    constexpr int NT = 2 * kWave;
+#pragma unroll
+    for (int k = 0; k < E; ++k) s[k * NT + t] = r[k];
+    __syncthreads();
+    const int pt = t ^ tmask;
+    const bool lower = (t & (MIRROR ? (tmask + 1) >> 1 : tmask)) == 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint64_t o = s[(MIRROR ? E - 1 - k : k) * NT + pt];
+        r[k] = ((o < r[k]) == lower) ? o : r[k];
+    }
+}
+template <int E>
+__device__ __forceinline__ void sort_tile_in_pair(uint64_t* __restrict__ p, uint32_t n, uint64_t* __restrict__ s_x) {
+    const int t = threadIdx.x, lane = t & (kWave - 1);
+    uint64_t r[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint32_t e = (uint32_t)(E * t + k);
+        r[k] = e < n ? p[e] : ~0ull;
+    }
+    merges_inside<E, 2>(r);
+    merges_across<E, 2 * E>(r, lane);                 // each wave: its 64*E keys sorted
+    pair_step<E, true>(r, s_x, t, 127);               // merge of 128*E: mirror step across the two waves ...
+    lane_steps_down<E, 32 * E>(r, lane);              // ... the rest inside the wave
+    thread_steps_down<E, E / 2>(r);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const uint32_t e = (uint32_t)(E * t + k);
+        if (e < n) p[e] = r[k];
+    }
+}
+__global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(const uint32_t* __restrict__ tile_start,
+                                                                        const uint32_t* __restrict__ counters,
+                                                                        uint64_t* __restrict__ pairs, uint64_t capacity) {
+    __shared__ uint64_t s_x[8 * 2 * kWave];
+    if (counters[0] > capacity) return;
+    const uint32_t b = tile_start[blockIdx.x];
+    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    if (n <= 1u || n > 1024u) return;
+    if (n <= 4u * kWave) {                            // one wave is enough (and as fast): the second leaves
+        if (threadIdx.x >= kWave) return;
+        if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
+        else sort_tile_in_wave<4>(pairs + b, n);
+        return;
+    }
+    if (n <= 8u * kWave) sort_tile_in_pair<4>(pairs + b, n, s_x);
+    else sort_tile_in_pair<8>(pairs + b, n, s_x);
+}
+
 // The three size classes of the "few tiles, long lists" family in ONE launch (lists of 2 .. 2048 entries): blocks
 // 0 .. RT-1 take one tile each when its list has 513 .. 2048 entries (four waves on one list: 4 or 8 keys per thread),
 // blocks RT .. RT + ceil(RT/4) - 1 take four tiles each, one per wave, when their lists have 2 .. 512 entries.  The
@@ -657,10 +715,14 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (mixed)
         spf_sort_tiles_mixed_kernel<<<RT + wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, RT);
-    if (mx > 1 && (mx <= 512 || blocks) && !mixed)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
+    // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
+    const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE");
+    if (pairsk)
+        spf_sort_tiles_pair_kernel<<<RT, 2 * kWave, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity);
+    if (mx > 1 && (mx <= 512 || blocks) && !mixed && !pairsk)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                           capacity, 1, RT);
-    if (mx > 512 && !blocks)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
+    if (mx > 512 && !blocks && !pairsk)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
         spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
                                                                            capacity, 1, RT);
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)

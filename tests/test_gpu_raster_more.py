@@ -359,6 +359,33 @@ def test_both_sort_families_give_the_same_lists(hip_lib, monkeypatch):
             assert torch.equal(a["grads"][n], b["grads"][n]), n
 
 
+def test_wave_pair_sort_gives_the_same_lists_as_single_waves(hip_lib, monkeypatch):
+    """Many-tiles family, lists of 257 .. 1024 entries: two waves share a list (`spf_sort_tiles_pair_kernel`, the default)
+    or one wave takes it whole (`SPF_SORT_SINGLE=1`): same unique order, so bit-equal images and gradients -- for both
+    pair classes (4 and 8 keys per thread)."""
+    monkeypatch.setenv("SPF_SORT_BLOCKS", "0")
+    outs, seen = [], set()
+    for single in ("", "1"):
+        if single:
+            monkeypatch.setenv("SPF_SORT_SINGLE", single)
+        else:
+            monkeypatch.delenv("SPF_SORT_SINGLE", raising=False)
+        per = []
+        for G in (800, 1600, 1800, 2200):                        # longest lists: 400, 466, 721, 989
+            batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G)
+            batch.opacities = batch.opacities * 0.03
+            p = util.run_product(batch)
+            m = p["stats"]["max_tile_list"]
+            seen.add("4" if 256 < m <= 512 else ("8" if 512 < m <= 1024 else "-"))
+            per.append(p)
+        outs.append(per)
+    assert {"4", "8"} <= seen, seen
+    for a, b in zip(*outs):
+        assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"])
+        for n in util.GRAD_NAMES:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
+
+
 @pytest.mark.parametrize("crowd", [0, 3000], ids=["rows_kernel", "lists_kernel"])
 def test_far_off_centre_anisotropic_splat_gradients(hip_lib, crowd):
     """A thin splat 0.09 units in front of the near plane whose centre projects ~490 px outside an 80x25 image (radius
