@@ -129,7 +129,7 @@ typedef struct SpfGrads {
                                  once per pair by its tile (no global atomics, no memset), indexed by pair_off + k;
                                  records are packed: 9 floats each, 10 when dL_ddepth != NULL
                                  (dL/d pixel centre xy, dL/d 2-D covariance (a, b, c), dL/d opacity, dL/d rgb[, dL/d depth]) */
-    float* vpartial;          /* [R, nblk, 12] scratch for the deterministic viewmatrix reduction,
+    float* vpartial;          /* [R, nblk, 12] (16-byte aligned) scratch for the deterministic viewmatrix reduction,
                                  nblk = spf_raster_view_partial_blocks(G) */
     float* dL_dmeans3D;       /* [S,G,3] */
     float* dL_dscales;        /* [S,G,3]   (NULL when enable_cov_grad is false) */

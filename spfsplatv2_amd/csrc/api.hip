@@ -341,6 +341,8 @@ int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, in
     int rc = check_camera(cam, false);
     if (rc) return rc;
     if (!vpartial || !dL_dextrinsics || nblk < 1) return fail(SPF_E_INVALID, "camera_backward_partials: bad argument");
+    if (reinterpret_cast<uintptr_t>(vpartial) & 15)
+        return fail(SPF_E_INVALID, "camera_backward_partials: vpartial must be 16-byte aligned");
     SPF_HIP(spf::launch_camera_bwd_reduce(*cam, vpartial, nblk, dL_dextrinsics, static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }

@@ -168,27 +168,40 @@ __global__ void spf_camera_bwd_kernel(SpfCamera c, const float* __restrict__ dL_
 
 // The decoder's last launch: sum the projection backward's per-block viewmatrix partials vpartial[r][0..nblk)[12]
 // (fixed order: deterministic) and chain the result to the pose -- what spf_view_reduce_kernel + the kernel above do
-// in two launches.  grid = R, block = 64.
-__global__ void spf_camera_bwd_reduce_kernel(SpfCamera c, const float* __restrict__ vpartial, int nblk,
-                                             float* __restrict__ dL_dext) {
+// in two launches.  grid = R, block = 256: four waves take every fourth group of 64 blocks (three 16-byte loads per
+// record), their totals are added in a fixed order -- deterministic, and a quarter of the dependent loads per wave that a
+// single wave had (the kernel is pure latency: 1,954 records per render on the 500,000-Gaussian workload took 13.8 us).
+__global__ __launch_bounds__(kBlock) void spf_camera_bwd_reduce_kernel(SpfCamera c, const float* __restrict__ vpartial,
+                                                                       int nblk, float* __restrict__ dL_dext) {
+    __shared__ float s_w[kBlock / kWave][12];
     __shared__ float s_dv[16];
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int r = blockIdx.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-    for (int b = lane; b < nblk; b += kWave) {
-        const float* pp = vpartial + ((size_t)r * nblk + b) * 12;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) acc[k] += pp[k];
+    for (int b = threadIdx.x; b < nblk; b += kBlock) {
+        const float4* pp = reinterpret_cast<const float4*>(vpartial + ((size_t)r * nblk + b) * 12);
+        const float4 a = pp[0], b4 = pp[1], c4 = pp[2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b4.x; acc[5] += b4.y; acc[6] += b4.z; acc[7] += b4.w;
+        acc[8] += c4.x; acc[9] += c4.y; acc[10] += c4.z; acc[11] += c4.w;
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = wave_sum(acc[k]);
     if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s_w[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tot[k] = (s_w[0][k] + s_w[1][k]) + (s_w[2][k] + s_w[3][k]);
         // partial k < 9: dL/dVm[4i+j] with k = 3i+j (i, j < 3); k = 9+j: dL/dVm[12+j]; the last column gets none
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_dv[4 * i + j] = j < 3 ? acc[i < 3 ? 3 * i + j : 9 + j] : 0.f;
+            for (int j = 0; j < 4; ++j) s_dv[4 * i + j] = j < 3 ? tot[i < 3 ? 3 * i + j : 9 + j] : 0.f;
         camera_bwd_one(c, r, s_dv, dL_dext);
     }
 }
@@ -213,7 +226,7 @@ hipError_t launch_camera_fwd_zero(const SpfCamera& c, void* zero, uint64_t nbyte
 
 hipError_t launch_camera_bwd_reduce(const SpfCamera& c, const float* vpartial, int nblk, float* dL_dext,
                                     hipStream_t stream) {
-    spf_camera_bwd_reduce_kernel<<<c.R, kWave, 0, stream>>>(c, vpartial, nblk, dL_dext);
+    spf_camera_bwd_reduce_kernel<<<c.R, kBlock, 0, stream>>>(c, vpartial, nblk, dL_dext);
     return hipGetLastError();
 }
 
