@@ -892,7 +892,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         for (int w = 0; w < kRoundL / 32; ++w) s_pm[w][tid] = 0u;
         const bool have = tid < kRoundL && (uint32_t)tid < hi;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, cc = a;
-        uint32_t gid = 0;
+        uint32_t gid = 0, pslot = 0;
         int xl = 0, yl = 0, bw = 0, bh = 0;
         if (have) {
 #ifdef SPF_CHECK
@@ -904,6 +904,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
 #endif
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             a = rp[0]; b = rp[1]; cc = rp[2];
+            // (the pair's slot hangs off two more gathers -- rect, pair_off: issued here, next to the record's, they
+            //  cost no round trip of their own; looked up at the end of phase C they were one per round, exposed)
+            if (!DEPTH_GRAD) pslot = pair_slot(gid);
             const TileBox tb = clipped_box(a.x, a.y, b.w, X0, Y0);
             xl = tb.xl; yl = tb.yl; bw = tb.bw; bh = tb.bh;
         }
@@ -925,7 +928,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             // slot of pixel (lx, ly) = off + (ly - yl) * bw + (lx - xl) = [off - yl*bw - xl] + bw*ly + lx: the box width
             // and the (signed) bracket travel as integers in the two fields phase B has no other use for
             // (as BYTE offsets into the pool, 8 bytes per slot: the replay then needs one v_mad_i32_i24 and one add)
-            s_p1[tid] = make_float4(kLog2e * a.w, b.y, __int_as_float(8 * bw), b.z);
+            // (.w: the depth for the depth-gradient kernel; otherwise free -- it carries the pair slot to phase C: 32,560
+            //  bytes of LDS, i.e. an array of its own, measured 4 blocks per CU instead of 5 and 157 -> 177 us)
+            s_p1[tid] = make_float4(kLog2e * a.w, b.y, __int_as_float(8 * bw), DEPTH_GRAD ? b.z : __uint_as_float(pslot));
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, __int_as_float(8 * ((int)off - yl * bw - xl)));
         }
 #pragma unroll
@@ -1082,7 +1087,8 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
 #ifdef SPF_CHECK
             if (pair_slot(gid) >= capacity) { printf("CHK slot: r %d tile %d tid %d gid %u slot %u cap %llu hi %u cnt %d\n", r, tile, tid, gid, pair_slot(gid), (unsigned long long)capacity, hi, cnt); return; }
 #endif
-            store_grec<DEPTH_GRAD>(gpair, pair_slot(gid), -o * S1.x, -o * S1.y, 0.5f * o * Sxx, o * Sxy, 0.5f * o * Syy,
+            const uint32_t my_slot = DEPTH_GRAD ? pair_slot(gid) : __float_as_uint(s_p1[tid].w);
+            store_grec<DEPTH_GRAD>(gpair, my_slot, -o * S1.x, -o * S1.y, 0.5f * o * Sxx, o * Sxy, 0.5f * o * Syy,
                                    M0, c01.x, c01.y, c2s.x, cd);
         }
         hi -= (uint32_t)cnt;
