@@ -271,6 +271,124 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
             }
 }
 
+// ---- the same scatter for VB views of a scene at once ------------------------------------------------------------
+// The block above is a latency chain -- loads, barrier, LDS count, barrier, one global atomic round trip, barrier, LDS
+// slots, store -- and a launch of (G / 256) x R such blocks is many rounds of them.  A scene's V views project the SAME 256
+// Gaussians, so one block can walk the chain once for VB of them: VB histograms in LDS, VB rects and depth keys per
+// thread, all their global atomics in one round trip.  V / VB times fewer blocks, the same number of barriers per block --
+// but the LDS phases of a block grow with VB, so it only pays for renders of many blocks (see launch_bin_pairs).
+template <int VB>
+__global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float* __restrict__ zkey,
+                                                                     const uint32_t* __restrict__ rect,
+                                                                     const uint32_t* __restrict__ tile_start,
+                                                                     uint32_t* __restrict__ tile_fill,
+                                                                     uint32_t* __restrict__ counters,
+                                                                     uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                     const uint32_t* __restrict__ blk_base,
+                                                                     uint32_t* __restrict__ pair_off,
+                                                                     int G, int T, int tiles_x, int V, int nvb,
+                                                                     uint32_t max_tile_hint, uint32_t dense_hint,
+                                                                     uint32_t RT) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [VB][T] counts, [VB][T] bases
+    __shared__ uint32_t s_wtot[VB][4];
+    uint32_t* const s_cnt = s_bin;
+    uint32_t* const s_base = s_bin + VB * T;
+    const int sc = blockIdx.y / nvb, vb = blockIdx.y - sc * nvb;
+    const int v0 = vb * VB, nv = min(VB, V - v0);
+    const int r0 = sc * V + v0;                                        // first render of this block
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (blockIdx.y == 0 && g == 0) {                                   // the plan check (see the kernel above)
+        uint32_t flag = counters[0] > capacity ? 1u : 0u;
+        if (max_tile_hint != 0u && counters[1] > max_tile_hint) flag |= 2u;
+        if ((dense_hint == 0u && counters[3] != 0u) || (dense_hint == RT && counters[3] != RT)) flag |= 4u;
+        if (flag) counters[2] = flag;
+    }
+    if (counters[0] > capacity) return;
+    const bool live = g < G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kPre = 4;                                            // tiles t = tid + 256 j of every view: T <= 1024
+    uint32_t rc[VB], bbase[VB], ts_pre[VB][kPre];
+    float zk[VB];
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        const bool on = k < nv;
+        const size_t rg = (size_t)(r0 + (on ? k : 0)) * G + (live ? g : 0);
+        rc[k] = (on && live) ? rect[rg] : 0u;
+        zk[k] = (on && live) ? zkey[rg] : 0.f;
+        bbase[k] = on ? blk_base[(size_t)(r0 + k) * gridDim.x + blockIdx.x] : 0u;
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const int t = threadIdx.x + j * kBlock;
+            ts_pre[k][j] = (on && t < T) ? tile_start[(size_t)(r0 + k) * T + t] : 0u;
+        }
+    }
+    uint32_t cnt[VB], inc[VB];
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        const int x0 = rc[k] & 0xff, y0 = (rc[k] >> 8) & 0xff, x1 = (rc[k] >> 16) & 0xff, y1 = rc[k] >> 24;
+        cnt[k] = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+        inc[k] = wave_iscan_u32(cnt[k]);
+        if (lane == kWave - 1) s_wtot[k][wave] = inc[k];
+    }
+    for (int t = threadIdx.x; t < VB * T; t += kBlock) s_cnt[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        uint32_t off = bbase[k] + inc[k] - cnt[k];
+        for (int w = 0; w < wave; ++w) off += s_wtot[k][w];
+        if (live && k < nv) pair_off[(size_t)(r0 + k) * G + g] = off;
+    }
+    // ---- count: run-wise for single-tile Gaussians (see the kernel above), one view after the other ----
+    LaneRun run[VB];
+    int stile[VB];
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        const int x0 = rc[k] & 0xff, y0 = (rc[k] >> 8) & 0xff, x1 = (rc[k] >> 16) & 0xff, y1 = rc[k] >> 24;
+        stile[k] = cnt[k] == 1u ? y0 * tiles_x + x0 : -1;
+        run[k] = lane_runs(stile[k], lane);
+        uint32_t* __restrict__ c = s_cnt + k * T;
+        if (cnt[k] == 1u && run[k].head == lane) atomicAdd(&c[stile[k]], (uint32_t)run[k].len);
+        if (cnt[k] > 1u)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) atomicAdd(&c[ty * tiles_x + tx], 1u);
+    }
+    __syncthreads();
+    // ---- reserve: every touched (view, tile) of the block gets its range with ONE global atomic; all in one round trip ----
+#pragma unroll
+    for (int k = 0; k < VB; ++k)
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const int t = threadIdx.x + j * kBlock;
+            if (k < nv && t < T) {
+                const uint32_t c = s_cnt[k * T + t];
+                if (c) {
+                    s_base[k * T + t] = ts_pre[k][j] + atomicAdd(&tile_fill[(size_t)(r0 + k) * T + t], c);
+                    s_cnt[k * T + t] = 0;
+                }
+            }
+        }
+    __syncthreads();
+    // ---- slots inside the ranges, keys out ----
+#pragma unroll
+    for (int k = 0; k < VB; ++k) {
+        const int x0 = rc[k] & 0xff, y0 = (rc[k] >> 8) & 0xff, x1 = (rc[k] >> 16) & 0xff, y1 = rc[k] >> 24;
+        const uint64_t key = ((uint64_t)__float_as_uint(zk[k]) << 32) | (uint32_t)g;
+        uint32_t* __restrict__ c = s_cnt + k * T;
+        const uint32_t* __restrict__ bs = s_base + k * T;
+        const bool single = cnt[k] == 1u;
+        uint32_t first = 0u;
+        if (single && run[k].head == lane) first = atomicAdd(&c[stile[k]], (uint32_t)run[k].len);
+        first = (uint32_t)__shfl((int)first, run[k].head, kWave);          // (every lane takes part: uniform flow)
+        if (single) pairs[bs[stile[k]] + first + (uint32_t)(lane - run[k].head)] = key;
+        if (cnt[k] > 1u)
+            for (int ty = y0; ty < y1; ++ty)
+                for (int tx = x0; tx < x1; ++tx) {
+                    const int t = ty * tiles_x + tx;
+                    pairs[bs[t] + atomicAdd(&c[t], 1u)] = key;
+                }
+    }
+}
+
 // ---- per-tile sort in LDS ---------------------------------------------------------------------
 // Bitonic network in its "all comparators ascending" form (first step of every merge compares
 // i with i ^ (k-1), the rest with i ^ j): it needs no padding, because a missing partner above n
@@ -692,6 +810,21 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
                             uint32_t max_tile_hint, uint32_t dense_hint, uint32_t RT_total, hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= max_lds_tiles() ? 1 : 0;
+    // Two views of a scene per block when a render has many blocks (measured, views per block 1 / 2 / 4: 320,000 Gaussians
+    // per render 47.5 / 41.6 / 43.8 us, 500,000 at 512 x 512 54.7 / 53.5 / 54.4, 65,536 23.7 / 25.1 / 29.1 -- the longer chain
+    // of a block pays only where the launch is many rounds of blocks); SPF_BIN_VIEWS=1 / 2 pins it
+    const char* const want_env = getenv("SPF_BIN_VIEWS");
+    const int want_vb = want_env ? atoi(want_env) : 0;
+    const int nblk = (d.G + kBlock - 1) / kBlock;
+    const int vb = want_vb ? (want_vb >= 2 ? 2 : 1) : (nblk >= 1024 ? 2 : 1);
+    if (lds && vb == 2 && d.V >= 2 && T <= 4 * kBlock) {
+        const int nvb = (d.V + 1) / 2;
+        dim3 vgrid(nblk, d.S * nvb);
+        spf_bin_pairs_views_kernel<2><<<vgrid, kBlock, (size_t)4 * T * sizeof(uint32_t), stream>>>(
+            st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
+            d.G, T, tiles_x, d.V, nvb, max_tile_hint, dense_hint, RT_total);
+        return hipGetLastError();
+    }
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
         st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
         d.G, T, tiles_x, lds, max_tile_hint, dense_hint, RT_total);

@@ -359,6 +359,25 @@ def test_both_sort_families_give_the_same_lists(hip_lib, monkeypatch):
             assert torch.equal(a["grads"][n], b["grads"][n]), n
 
 
+def test_two_views_per_binning_block_give_the_same_lists(hip_lib, monkeypatch):
+    """Renders of many blocks bin two views of a scene per block (`spf_bin_pairs_views_kernel`, picked from G >= 262,144;
+    `SPF_BIN_VIEWS` pins it): bins fill in another order, the sorted lists are the same -- bit-equal images and gradients,
+    for an odd number of views (the last block of a scene holds one) and for several scenes."""
+    outs = []
+    for vb in ("1", "2"):
+        monkeypatch.setenv("SPF_BIN_VIEWS", vb)
+        per = []
+        for S, V, G in ((1, 3, 3000), (2, 2, 1500), (1, 5, 700)):
+            batch = syn.make_batch("TEST", S, V, seed=31, s_mult=2.0, G=G, K=4, image_hw=(80, 72))
+            per.append(util.run_product(batch))
+        outs.append(per)
+    for a, b in zip(*outs):
+        assert a["stats"]["num_pairs"] == b["stats"]["num_pairs"]
+        assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"])
+        for n in util.GRAD_NAMES:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
+
+
 def test_wave_pair_sort_gives_the_same_lists_as_single_waves(hip_lib, monkeypatch):
     """Many-tiles family, lists of 257 .. 1024 entries: two waves share a list (`spf_sort_tiles_pair_kernel`, the default)
     or one wave takes it whole (`SPF_SORT_SINGLE=1`): same unique order, so bit-equal images and gradients -- for both
