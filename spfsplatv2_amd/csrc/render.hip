@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
     const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;   // (the top bits carry the ablation code of profiling builds)
     __shared__ float4 s_p0[kStage];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
-    __shared__ float4 s_p1[kStage];   // B', opacity, cull r^2, -
+    __shared__ float2 s_p1[kStage];   // B', opacity   (8 bytes: with a float4 here the block is 20,752 bytes of LDS -- 7 per CU instead of 8)
     __shared__ float4 s_p2z[kStage + 1];   // r, g | b, depth; record 0 is all zeros (see `next` below), entry i is record i + 1
     __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
     float4* const s_p2 = s_p2z + 1;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
-            s_p1[tid] = make_float4(kLog2e * a.w, b.y, b.w, 0.f);
+            s_p1[tid] = make_float2(kLog2e * a.w, b.y);
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
             gx = a.x; gy = a.y; r2 = b.w;
         }
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             const uint32_t base16 = (base + 1u) << 4;
             // hm: the lanes that hold a candidate.  A finished pixel keeps walking its bits (its lane is masked by dm,
             // so it neither composites nor keeps the loop alive).
-            auto composite = [&](uint64_t hm, int j, const float4& p0, const float4& p1, const float4& p2) {
+            auto composite = [&](uint64_t hm, int j, const float4& p0, const float2& p1, const float4& p2) {
                 v2f dxy;
                 const float pw = lists_power2(p0, p1.x, fxy, dxy);
                 const float alpha = fminf(kAlphaMax, p1.y * __builtin_amdgcn_exp2f(pw));
@@ -499,14 +499,15 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 asm("v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"(hits), "=s"(carry_out) : "s"(hitm & ~stopm));
             };
             auto rec0 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p0) + j); };
-            auto rec1 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p1) + j); };
+            auto rec1 = [&](int j) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_p1) + (j >> 1)); };
             auto rec2 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p2) + j); };
             // software pipeline, unrolled by two: the LDS gathers of one candidate are in flight while the other is
             // composited, and the two register sets swap roles instead of being copied
             bool ha, hb;
             int ja = next(ha), jb;
             uint64_t ma = lane_ballot(ha) & ~dm, mb;
-            float4 a0 = rec0(ja), a1 = rec1(ja), a2 = rec2(ja), b0, b1, b2;
+            float4 a0 = rec0(ja), a2 = rec2(ja), b0, b2;
+            float2 a1 = rec1(ja), b1;
             while (true) {
                 if (!ma) break;
                 jb = next(hb);
