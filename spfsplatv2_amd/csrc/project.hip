@@ -989,11 +989,19 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
     if (gr.dL_dscales && gr.dL_drotations) {
         // N[i][k] = R[i][k] s_k.  R is rebuilt from the quaternion here rather than carried through the view loop (nine
         // registers; the compiler would otherwise keep the copy it made for N0 alive: hence the opaque quaternion)
+        // (degree 3 runs at the 256-register cap with spills and degree 1 sat two registers above the 168 of three waves per SIMD:
+        //  from degree 1 on the quaternion and the scales are READ AGAIN here --
+        //  28 bytes per Gaussian from the L2 -- instead of being held through the view loop, seven registers)
         float4 q2 = q;
+        float sv[3] = {sx, sy, sz};
+        if (DEG >= 1) {
+            q2 = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+            sv[0] = in.scales[3 * sg] * d.scale_modifier; sv[1] = in.scales[3 * sg + 1] * d.scale_modifier;
+            sv[2] = in.scales[3 * sg + 2] * d.scale_modifier;
+        }
         asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
         float R[9];
         quat_rot(q2, R);
-        const float sv[3] = {sx, sy, sz};
         float ds[3], dR[9];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
             for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN0[3 * i + k] * sv[k];
         }
         gr.dL_dscales[3 * sg] = ds[0]; gr.dL_dscales[3 * sg + 1] = ds[1]; gr.dL_dscales[3 * sg + 2] = ds[2];
-        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
         float4 dq;
         dq.x = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
         dq.y = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] -
