@@ -773,6 +773,9 @@ __device__ unsigned long long g_phase_buf[kPhaseWaves * 8];
 #define PHASE_FLUSH()
 #endif
 
+#ifndef SPF_LANESORT
+#define SPF_LANESORT 0
+#endif
 #ifndef SPF_POOL
 #define SPF_POOL 1536
 #define SPF_ROUNDL 192
@@ -815,10 +818,12 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     PHASE_INIT();
     if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
-    // ---- per-pixel state, then the lane <-> pixel assignment by the number of contributors the forward recorded ----
-    // Everything a pixel needs is loaded in the NATURAL order first (coalesced, and independent of the assignment, so
-    // these loads are in flight while the counting sort runs) and parked in LDS; after the sort every lane picks up
-    // the values of ITS pixel from there -- one dependent global round trip less per tile than loading after the sort.
+    // ---- per-pixel state: thread <-> pixel in the natural order ----
+    // (Rounds 1 - 3 put the pixels on lanes by the number of contributors the forward recorded -- an LDS counting sort,
+    // two barriers, the state parked in LDS and picked up again -- so that a wave's lanes finish their replay together.
+    // That paid while the replay was most of the kernel (0.242 -> 0.214 ms in round 1); at 28 % of the wave time it no
+    // longer does: without it the kernel is 2.4 us FASTER on C2 and 1 % on C5 (same-box A/B), and three barriers shorter.
+    // SPF_LANESORT=1 at build time brings it back.)
     int mypix;
     float T_final, gI0, gI1, gI2, gD, gA;
     uint32_t ncon;
@@ -838,6 +843,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             if (DEPTH_GRAD) qd = dL_ddepth[(size_t)r * P + qpix];
             if (dL_dalpha) qa = dL_dalpha[(size_t)r * P + qpix];
         }
+#if SPF_LANESORT
         s_pm[0][tid] = 0u;                        // (s_pm is free before the rounds: bins in word 0, order in word 1)
         __syncthreads();
         mypix = assign_pixels_by_load(h, &s_pm[0][0], &s_pm[1][0]);
@@ -851,6 +857,14 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         T_final = t2.x; ncon = __float_as_uint(t2.y);
         gI0 = g4.x; gI1 = g4.y; gI2 = g4.z; gD = DEPTH_GRAD ? g4.w : 0.f;
         gA = s_pool[kBlock + mypix].x;
+#else
+        (void)h;
+        mypix = tid;
+        s_gI[tid] = make_float4(q0, q1, q2, DEPTH_GRAD ? qd : 1.f);   // phase C's table; .w == 1 lets it fold sum(u) into a packed fma
+        T_final = tf; ncon = nc;                                      // (visible to the block after the barrier below)
+        gI0 = q0; gI1 = q1; gI2 = q2; gD = DEPTH_GRAD ? qd : 0.f;
+        gA = qa;
+#endif
     }
     const int lx = mypix & 15, ly = mypix >> 4;
     const int px = X0 + lx, py = Y0 + ly;
