@@ -111,7 +111,8 @@ typedef struct SpfState {
     uint32_t* blk_base;    /* [R*nblk]  exclusive scan of blk_total */
     float* final_T;        /* [R*P]     transmittance left after the last contributor */
     uint32_t* n_contrib;   /* [R*P,2]   per pixel: (1 + list position of the last contributor (0 = none),
-                                        number of contributors -- the backward balances its lanes with it) */
+                                        reserved: the number of contributors in builds with -DSPF_LANESORT=1, whose
+                                        backward balances its lanes with it; 0 in the default build) */
 } SpfState;
 
 typedef struct SpfOutputs {

@@ -21,6 +21,17 @@
 
 #include "spf_common.h"
 
+// -DSPF_LANESORT=1: the lists backward puts its pixels on lanes by contributor count (see its prologue); only then do
+// the forward kernels count a pixel's contributors (n_contrib's second word; 0 otherwise -- the profiling build counts too)
+#ifndef SPF_LANESORT
+#define SPF_LANESORT 0
+#endif
+#if SPF_LANESORT || defined(SPF_PHASE_CLOCKS)
+#define SPF_COUNT_HITS 1
+#else
+#define SPF_COUNT_HITS 0
+#endif
+
 namespace spf {
 
 constexpr int kStage = 256;  // list entries staged per round (one per thread)
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
                     C0 = fmaf(p2.x, w, C0); C1 = fmaf(p2.y, w, C1); C2 = fmaf(p2.z, w, C2); Dp = fmaf(p2.w, w, Dp);
                     Tr = take ? test_T : Tr;
                     last = take ? base + (uint32_t)j + 1u : last;
-                    hits += take ? 1u : 0u;
+                    if (SPF_COUNT_HITS) hits += take ? 1u : 0u;
                 }
                 // per-row / per-wave early termination from one ballot per 32 entries
                 const uint64_t alive = __ballot(!done);
@@ -495,8 +506,10 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 Tr = take ? test_T : Tr;
                 last16 = take ? (uint32_t)j + base16 : last16;
                 // hits += take: one add-with-carry whose carry-in is the wave mask (a select and an add otherwise)
-                uint64_t carry_out;
-                asm("v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"(hits), "=s"(carry_out) : "s"(hitm & ~stopm));
+                if (SPF_COUNT_HITS) {
+                    uint64_t carry_out;
+                    asm("v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"(hits), "=s"(carry_out) : "s"(hitm & ~stopm));
+                }
             };
             auto rec0 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p0) + j); };
             auto rec1 = [&](int j) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_p1) + (j >> 1)); };
@@ -773,9 +786,6 @@ __device__ unsigned long long g_phase_buf[kPhaseWaves * 8];
 #define PHASE_FLUSH()
 #endif
 
-#ifndef SPF_LANESORT
-#define SPF_LANESORT 0
-#endif
 #ifndef SPF_POOL
 #define SPF_POOL 1536
 #define SPF_ROUNDL 192
