@@ -1,4 +1,5 @@
-"""development: tile-list statistics of a bench workload (list lengths per tile, hits per pixel).
+"""development: tile-list statistics of a bench workload (list lengths per tile, hits per pixel -- the latter only with a
+library built with SPF_HIPCC_EXTRA=-DSPF_LANESORT=1 or -DSPF_PHASE_CLOCKS: the default build does not count them).
 
     python tools/list_stats.py [--config C2] [--scenes 8] [--views 4]
 """
