@@ -169,6 +169,14 @@ def parse_args(argv=None):
                          "`GaussianRasterizer(settings)(...)` calls with `.item()` host syncs (cuda_splatting.py:96-143) "
                          "-- on this library's drop-in `diff_gauss_pose` surface (eager; what a caller gets with zero "
                          "source changes).  batched (default): one `DecoderSplattingCUDA`-style call for all renders")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default single-GPU C2 run only: skip the `secondary` object (BASELINE configs 3 and 5, the "
+                         "reference's real 2-view workload with and without SH band 4, the two-stream C2 step and the "
+                         "test_step-shaped decoder-call latency, each measured by a child run of this script)")
+    ap.add_argument("--eval-latency", action="store_true",
+                    help="measure the LATENCY of one decoder call at the reference's test_step shape instead of the "
+                         "training step: b = 1 scene of the 2-view model (131,072 Gaussians, 25 SH coefficients), v = 3 "
+                         "target views, 256x256, forward only under no_grad (src/model/model_wrapper.py:415-454)")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -219,6 +227,126 @@ def valu_roofline(kernel: str, launch_ms: float, default_workload, chunks: int =
             "unit": "G wave-instructions/s", "frac": round(ach / peak, 5), "wave_instructions_per_launch": insts}
 
 
+SECONDARY = (
+    # name, extra argv, extra environment
+    ("C3", ["--config", "C3"], {}),
+    ("C5", ["--config", "C5"], {}),
+    ("REF2V", ["--config", "REF2V"], {"SPF_SH_BAND4": "0"}),
+    ("REF2V_band4", ["--config", "REF2V"], {"SPF_SH_BAND4": "1"}),
+    ("C2_streams2", ["--config", "C2", "--streams", "2"], {}),
+    ("eval_1x3", ["--eval-latency"], {"SPF_SH_BAND4": "0"}),
+)
+
+
+def run_secondary(args) -> dict:
+    """The other workloads under the same clock as the headline: one child run of this script each (its own process:
+    a failure cannot take the headline down, and every child gets the library state of a fresh start), >= 1 s of timed
+    GPU work per child, no CPU baseline.  Returns {name: trimmed child line + wall_s}."""
+    out = {}
+    env0 = {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                         "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    for name, extra, env_extra in SECONDARY:
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--no-cpu-baseline", "--no-secondary", "--min-seconds", "1.0", "--min-trials", "5",
+               *extra]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=dict(env0, **env_extra), capture_output=True, text=True, timeout=120)
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:                                  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300], "wall_s": round(time.perf_counter() - t0, 2)}
+            log(f"secondary {name}: FAILED ({out[name]['error']})")
+            continue
+        keep = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better") if k in line}
+        keep["workload"] = line.get("config", {}).get("workload")
+        keep["launch"] = line.get("config", {}).get("launch")
+        if "roofline" in line:
+            rf = line["roofline"]
+            keep["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "launch_ms", "achieved", "frac", "traffic",
+                                                               "algorithmic_bytes_per_launch")}
+        for k in ("latency_ms", "timing"):
+            if k in line:
+                keep[k] = line[k]
+        keep["wall_s"] = round(time.perf_counter() - t0, 2)
+        out[name] = keep
+        log(f"secondary {name}: {keep.get('value')} {keep.get('unit')} ({keep['wall_s']} s)")
+    return out
+
+
+def eval_latency(args, dev) -> dict:
+    """One decoder call at the shape the reference evaluates with (`test_step`: b = 1, v = 3 target views rendered from
+    the 2-view model's 131,072 Gaussians with 25 SH coefficients, forward only, src/model/model_wrapper.py:415-454):
+    wall time from the call to its result being complete, i.e. with a device synchronisation per call."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import synthetic as syn
+    b = syn.make_batch("REF2V", 1, 3, seed=4242).to(dev)
+    h, w = b.image_shape
+    G, K = b.means.shape[1], b.harmonics.shape[-1]
+    bg = torch.zeros(3, device=dev)
+    rec = spf.CallRecord()
+
+    def call(max_pairs):
+        with torch.no_grad():
+            return spf.render_views(b.extrinsics, b.intrinsics, b.near, b.far, (h, w), bg, b.means, b.harmonics,
+                                    b.opacities, b.rotations, b.scales, scale_invariant=True, max_pairs=max_pairs,
+                                    record=rec)
+
+    def latency(fn, n):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
+
+    n = max(args.steps * 10, 100)
+    for _ in range(max(args.warmup, 3)):
+        call(None)
+    exact_med, exact_min = latency(lambda: call(None), n)
+    plan = spf.plan_pair_budget(rec, slack=1.25, check="deferred")
+    for _ in range(max(args.warmup, 3)):
+        call(plan)
+    plan_med, plan_min = latency(lambda: call(plan), n)
+    graph_med = graph_min = None
+    try:
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            call(plan)
+        for _ in range(3):
+            g_.replay()
+        graph_med, graph_min = latency(g_.replay, n)
+    except Exception as e:                                      # noqa: BLE001
+        log(f"eval latency: graph capture failed ({type(e).__name__}: {e})")
+    # back-to-back planned calls (no wait between them): what an evaluation loop that only reads the images later sees
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    m = 0
+    while m < n or time.perf_counter() - t0 < 1.0:
+        call(plan)
+        m += 1
+    torch.cuda.synchronize(dev)
+    stream_ms = (time.perf_counter() - t0) / m * 1e3
+    if spf.plan_flags(rec) != 0:
+        raise RuntimeError("the planned pair budget did not hold in the evaluation-shape run")
+    best = min(x for x in (plan_med, graph_med) if x is not None)
+    return {"metric": "decoder forward latency, b=1 x v=3 at 256x256 (test_step shape)", "value": round(best, 4),
+            "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": n, "warmup": args.warmup,
+            "ms_per_step": round(best, 4), "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"eval_1x3: 1 scene of {G} Gaussians, {K} SH coefficients per channel, 3 target views, "
+                                   f"{h}x{w}, decoder forward only under no_grad",
+                       "launch": "one call, then torch.cuda.synchronize: wall time per call"},
+            "latency_ms": {"exact_mode_median": round(exact_med, 4), "exact_mode_min": round(exact_min, 4),
+                           "planned_median": round(plan_med, 4), "planned_min": round(plan_min, 4),
+                           "planned_graph_replay_median": None if graph_med is None else round(graph_med, 4),
+                           "planned_graph_replay_min": None if graph_min is None else round(graph_min, 4),
+                           "planned_back_to_back": round(stream_ms, 4), "calls_each": n,
+                           "Mpixels_per_s_back_to_back": round(3 * h * w / stream_ms / 1e3, 1)}}
+
+
 def main():
     args = parse_args()
     if args.gpus is None:
@@ -262,6 +390,14 @@ def main():
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
 
+    if args.eval_latency:
+        if world != 1:
+            sys.exit("bench.py: --eval-latency is a single-GPU measurement")
+        print(json.dumps(eval_latency(args, dev)), flush=True)
+        if launched:
+            dist.destroy_process_group()
+        return
+
     S = args.scenes if args.scenes is not None else WORKLOADS[args.config][0]
     V = args.views if args.views is not None else WORKLOADS[args.config][1]
     from spfsplatv2_amd import shard
@@ -276,7 +412,6 @@ def main():
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
     bg = torch.zeros(3, device=dev)
-    one = torch.ones((), device=dev)
     if args.streams > 1:
         if S % args.streams or args.allreduce:
             sys.exit("bench.py: --streams N needs a scene count divisible by N (and is not combined with --allreduce)")
@@ -346,7 +481,7 @@ def main():
                                          L["means"], L["harmonics"], L["opacities"], L["rotations"], L["scales"],
                                          record=self.record)
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
-                loss.backward(gradient=one)
+                loss.backward(gradient=spf.unit_grad(dev))
                 return loss
             color, depth, _alpha = spf.render_views(
                 L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
@@ -356,7 +491,9 @@ def main():
                 loss = torch.nn.functional.mse_loss(color, b.target[sl]) * self.weight
             else:
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
-            loss.backward(gradient=one)          # (a cached dL/dloss = 1 saves autograd's fill kernel)
+            # (the cached dL/dloss = 1 saves autograd's fill kernel, and the fused loss recognises it: its backward is
+            #  the forward's unit gradient, no launch)
+            loss.backward(gradient=spf.unit_grad(dev))
             if args.allreduce:
                 shard.allreduce_gaussian_grads([L[n].grad for n in names[:5]], skip_single=False)
             return loss
@@ -551,6 +688,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, batch_cpu)
+        headline_defaults = (args.config == "C2" and default_workload == "C2" and not args.eager and not args.exact
+                             and not args.torch_loss)
+        if world == 1 and headline_defaults and not args.no_secondary:
+            torch.cuda.empty_cache()
+            out["secondary"] = run_secondary(args)
         print(json.dumps(out), flush=True)
     if launched:
         dist.barrier()

@@ -62,6 +62,18 @@ ALPHA_MIN = 1.0 / 255.0  # B#10
 T_MIN = 1e-4             # B#10
 FOV_CLAMP = 1.3          # B#4
 
+# Knife-edge windows (what `composite(..., want_fragile=True)` / `rasterize` flag; see tests/util.py::compare):
+FRAG_ALPHA_REL = 5e-5    # alpha within this relative distance of 1/255 (round 4: was 2e-4) ...
+# ... plus what the float32 pixel centre moves ln(alpha) by.  x_pix = ((ndc + 1) W - 1) / 2 with ndc = hom_x / hom_w:
+# the quotient and the product are good to ~3 roundings of ndc, i.e. FRAG_POS_NDC * |x - (W-1)/2| pixels, and the sum
+# (ndc + 1) W to one rounding at its own size, FRAG_POS_SUM * (W/2 + 1) pixels.  (Round 3 used 1.2e-7 (|x| + W/2 + 1):
+# three times this at the image centre, 1.5 times at its edge -- the flagged set was 100-250 x the pixels that
+# actually differ.)
+FRAG_POS_NDC = 1.8e-7
+FRAG_POS_SUM = 6e-8
+FRAG_MAG_ULP = 4e-7      # ... plus the float32 rounding of the exponent's own three terms at THEIR size
+FRAG_T_REL = 1e-3        # transmittance within this relative distance of the 1e-4 stop
+
 
 @dataclass
 class Projected:
@@ -313,19 +325,19 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
             Ap = 1.0 - T_final                                     # B#11
             if want_fragile:
                 with torch.no_grad():
-                    rel = 2e-4
-                    # ... plus what the float32 resolution of the pixel centre itself can move alpha by: the centre
-                    # comes out of ((ndc + 1) * W - 1) / 2, i.e. it is only good to ~1.2e-7 * (|x| + W/2) pixels
-                    # (6e-5 px at x = 500), and at the rim of a footprint d(ln alpha)/dx = A dx + B dy is ~5 per pixel
-                    ex = 1.2e-7 * (gxy[None, :, 0].abs() + 0.5 * W + 1.0)
-                    ey = 1.2e-7 * (gxy[None, :, 1].abs() + 0.5 * H + 1.0)
+                    rel = FRAG_ALPHA_REL
+                    # ... plus what the float32 resolution of the pixel centre itself can move alpha by (FRAG_POS_*:
+                    # ~1e-5 px at the image centre, ~3e-5 px at the edge of a 256-px image, 1e-4 px at x = 500); at the
+                    # rim of a footprint d(ln alpha)/dx = A dx + B dy is ~5 per pixel
+                    ex = FRAG_POS_NDC * (gxy[None, :, 0] - 0.5 * (W - 1)).abs() + FRAG_POS_SUM * (0.5 * W + 1.0)
+                    ey = FRAG_POS_NDC * (gxy[None, :, 1] - 0.5 * (H - 1)).abs() + FRAG_POS_SUM * (0.5 * H + 1.0)
                     # ... and what evaluating the exponent itself in float32 costs: its three terms are each rounded
                     # at THEIR size (`mag`), which for a thin splat centred hundreds of pixels away is ~1e2..1e3 while
                     # their sum is ~ -5 (ln alpha moves by up to ~1e-4 there; negligible for ordinary footprints)
                     mag = 0.5 * (con[None, :, 0].abs() * dx * dx + con[None, :, 2].abs() * dy * dy) \
                         + (con[None, :, 1] * dx * dy).abs()
                     win = rel + (con[None, :, 0] * dx + con[None, :, 1] * dy).abs() * ex \
-                        + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey + 4e-7 * mag
+                        + (con[None, :, 2] * dy + con[None, :, 1] * dx).abs() * ey + FRAG_MAG_ULP * mag
                     near_alpha = ((alpha - ALPHA_MIN).abs() < win * ALPHA_MIN) & (power <= 0)
                     # power > 0 (skipped) vs <= 0 can only flip where the three terms cancel to rounding level
                     near_pow = power.abs() <= 1e-5 * mag
@@ -333,7 +345,7 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                     # entry that decides is the last one kept OR the first one refused
                     refused = valid & ~keep
                     first_refused = refused & (torch.cumsum(refused.to(torch.int32), dim=1) == 1)
-                    near_T = ((incl - T_MIN).abs() < 1e-3 * T_MIN) & (keep | first_refused)
+                    near_T = ((incl - T_MIN).abs() < FRAG_T_REL * T_MIN) & (keep | first_refused)
                     frag = (near_alpha | near_pow | near_T).any(dim=1)
                     # not a branch but a resolution limit: the same exponent rounding moves every alpha SMOOTHLY by
                     # alpha * 4e-7 * mag; where that adds up to a visible amount no float32 evaluation of the classic
@@ -359,6 +371,14 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                             at_stop = first_refused[:, k:] | first_refused[:, :-k]
                             swap = torch.where(at_stop, T_excl[:, :-k] * torch.maximum(a_c[:, :-k], a_c[:, k:]), swap)
                             frag = frag | ((swap > 2e-5) & tie[None, :]).any(dim=1)
+                    if capture is not None and "fragile_stats" in capture:      # (diagnostics: which window flags how many pixels)
+                        fs = capture["fragile_stats"]
+                        base = (near_alpha | near_pow | near_T).any(dim=1)
+                        for name, m in (("near_alpha", near_alpha.any(dim=1)), ("near_pow", near_pow.any(dim=1)),
+                                        ("near_T", near_T.any(dim=1)),
+                                        ("smooth_mag", (w.detach() * mag).sum(dim=1) * 4e-7 > 3e-5),
+                                        ("order_or_smooth_only", frag & ~base), ("any", frag)):
+                            fs[name] = fs.get(name, 0) + int(m.sum())
             else:
                 frag = torch.zeros(n_pix, dtype=torch.bool)
         rows_c[ty][tx] = C.reshape(TILE, TILE, 3)
@@ -432,14 +452,19 @@ def rasterize(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Ten
                 box[b0:b1, a0:a1] = True
                 if c1 > c0 and d1 > d0:
                     box[d0:d1, c0:c1] = False
-                # ... and inside those tiles only the pixels the Gaussian can reach (its 3-sigma box, padded)
-                reach = torch.zeros(H, W, dtype=torch.bool)
-                rr = float(r_hi[g]) + 2.0
-                y0p, y1p = max(0, int(py[g] - rr)), min(H, int(py[g] + rr) + 2)
-                x0p, x1p = max(0, int(px[g] - rr)), min(W, int(px[g] + rr) + 2)
-                if y1p > y0p and x1p > x0p:
-                    reach[y0p:y1p, x0p:x1p] = True
-                fr |= box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W] & reach
+                # ... and inside those tiles only the pixels the Gaussian would CONTRIBUTE to if the tile were on its
+                # list: power <= 0 and alpha >= 1/255 (with the alpha window's margin).  (Round 3 tainted its whole
+                # padded 3-sigma box there; beyond 3 sigma alpha = 0.011 x opacity, below 1/255 unless opacity > 0.35.)
+                tiles_px = box.repeat_interleave(TILE, 0).repeat_interleave(TILE, 1)[:H, :W]
+                if not bool(tiles_px.any()):
+                    continue
+                yy, xx = torch.nonzero(tiles_px, as_tuple=True)
+                cg = pr.conic[g].detach().double()
+                ddx, ddy = px[g] - xx.double(), py[g] - yy.double()
+                pw_g = -0.5 * (cg[0] * ddx * ddx + cg[2] * ddy * ddy) - cg[1] * ddx * ddy
+                al_g = torch.clamp(pr.opacity[g].detach().double() * torch.exp(pw_g.clamp(max=0.0)), max=ALPHA_MAX)
+                hit = (pw_g <= 1e-9) & (al_g >= ALPHA_MIN * (1.0 - 1e-3))
+                fr[yy[hit], xx[hit]] = True
         res = (out[0], out[1], out[2], pr.radii, fr)
     else:
         res = (out[0], out[1], out[2], pr.radii)

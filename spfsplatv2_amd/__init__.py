@@ -8,7 +8,7 @@ from .decoder import (DECODERS, camera_tensors, Decoder, DecoderOutput, DecoderS
 from .rasterizer import (CallRecord, GaussianRasterizationSettings, GaussianRasterizer, PairBudget, camera_forward,
                          last_forward_stats, last_plan_flags, plan_flags, plan_pair_budget, rasterize_batch,
                          render_batch, sh_band4_default)
-from .loss import Loss, LossMse, LossMseCfg, LossMseCfgWrapper, mse_loss
+from .loss import Loss, LossMse, LossMseCfg, LossMseCfgWrapper, mse_loss, unit_grad
 from .rope import (PositionGetter, RoPE2D, RotaryPositionEmbedding2D, append_token_position, cuRoPE2D, cuRoPE2D_func,
                    rope_2d, rope_2d_head_major, rope_2d_pair)
 
@@ -16,5 +16,5 @@ __all__ = [
     "DECODERS", "Decoder", "DecoderOutput", "DecoderSplattingCUDA", "DecoderSplattingCUDACfg",
     "DecoderSplattingHIP", "Gaussians", "get_decoder", "get_fov", "get_projection_matrix", "render_cuda",
     "render_cuda_orthographic", "render_views", "GaussianRasterizationSettings", "GaussianRasterizer",
-    "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags", "plan_flags", "CallRecord", "sh_band4_default", "orthographic_camera", "rasterize_batch", "render_batch", "camera_forward", "camera_tensors", "Loss", "LossMse", "LossMseCfg", "LossMseCfgWrapper", "mse_loss", "PositionGetter", "append_token_position", "RoPE2D", "RotaryPositionEmbedding2D", "cuRoPE2D", "cuRoPE2D_func", "rope_2d", "rope_2d_head_major", "rope_2d_pair",
+    "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags", "plan_flags", "CallRecord", "sh_band4_default", "orthographic_camera", "rasterize_batch", "render_batch", "camera_forward", "camera_tensors", "Loss", "LossMse", "LossMseCfg", "LossMseCfgWrapper", "mse_loss", "unit_grad", "PositionGetter", "append_token_position", "RoPE2D", "RotaryPositionEmbedding2D", "cuRoPE2D", "cuRoPE2D_func", "rope_2d", "rope_2d_head_major", "rope_2d_pair",
 ]

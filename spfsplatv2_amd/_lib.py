@@ -139,6 +139,11 @@ def fast():
                 spec.loader.exec_module(mod)
                 if mod.abi_version() == ABI_VERSION:
                     _fast = mod
+                else:                                # a stale build left next to a newer library: say so, once
+                    import warnings
+                    warnings.warn(f"spfsplatv2_amd: {path} was built for ABI {mod.abi_version()}, the library is ABI "
+                                  f"{ABI_VERSION}; using the (slower) ctypes binding -- rebuild with "
+                                  "`python -m spfsplatv2_amd.build`")
             except (ImportError, OSError) as e:      # e.g. built against another torch: fall back, but say so once
                 import warnings
                 warnings.warn(f"spfsplatv2_amd: {path} could not be loaded ({e}); using the ctypes binding")

@@ -105,7 +105,9 @@ struct LaneSet {
     hipEvent_t stagger = nullptr, join = nullptr;
 };
 LaneSet* lane_set() {
-    static thread_local LaneSet lanes[32];     // per (device, calling thread): see render.hip::aux_stream
+    // per (device, calling thread): see render.hip::aux_stream.  One stream and two events per pair, created on first
+    // use and kept for the life of the process (SPF_CHUNKS experiments only; nothing is created by default)
+    static thread_local LaneSet lanes[32];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
     LaneSet& a = lanes[dev];
@@ -121,7 +123,8 @@ LaneSet* lane_set() {
     return &a;
 }
 // Chunk boundaries in RENDERS: bounds[0..C].  Whole scenes per chunk when there are several scenes (`by_scene`),
-// else groups of views of the one scene.  A chunk keeps >= 1024 tiles.
+// else groups of views of the one scene.  One chunk unless SPF_CHUNKS asks for more (experiments only: no lower bound
+// on a chunk's size is applied -- small chunks are what the bit-identity tests run).
 int plan_chunks(int S, int V, int T, int* bounds, bool* by_scene) {
     const char* e = getenv("SPF_CHUNKS");
     int want = e ? atoi(e) : 1;
@@ -129,10 +132,7 @@ int plan_chunks(int S, int V, int T, int* bounds, bool* by_scene) {
     const int units = S > 1 ? S : V, per_unit = S > 1 ? V : 1;
     *by_scene = S > 1;
     int C = want < 1 ? 1 : want;
-    if (!e) {
-        const long tiles = (long)S * V * T;
-        while (C > 1 && tiles / C < 1024) --C;
-    }
+    (void)T;
     if (C > units) C = units;
     for (int c = 0; c <= C; ++c) bounds[c] = (int)(((long)units * c) / C) * per_unit;
     return C;
@@ -367,7 +367,9 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
     LaneSet* lanes = C > 1 ? lane_set() : nullptr;
     if (!lanes) { C = 1; bounds[0] = 0; bounds[1] = d->S * d->V; }
-    for (int c = 0; c < C; ++c) {
+    // (a failure inside the loop must not leave the auxiliary lane forked: an un-joined stream invalidates an ongoing
+    //  HIP-graph capture -- the chunk body reports, the join below runs either way)
+    auto chunk = [&](int c) -> int {
         const hipStream_t cs = (c & 1) ? lanes->s : stream;
         const Chunk ch = make_chunk(*d, *in, *st, out, nullptr, bounds[c], bounds[c + 1], -1, 0);
         const int rt = (bounds[c + 1] - bounds[c]) * T;
@@ -387,12 +389,15 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
             StageScope t(SPF_STAGE_RENDER_FWD, cs);
             SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, dh, cs));
         }
-    }
+        return SPF_OK;
+    };
+    for (int c = 0; c < C && rc == SPF_OK; ++c) rc = chunk(c);
     if (C > 1) {
-        SPF_HIP(hipEventRecord(lanes->join, lanes->s));
-        SPF_HIP(hipStreamWaitEvent(stream, lanes->join, 0));
+        const hipError_t e1 = hipEventRecord(lanes->join, lanes->s), e2 = hipStreamWaitEvent(stream, lanes->join, 0);
+        if (rc == SPF_OK && (e1 != hipSuccess || e2 != hipSuccess))
+            return fail(SPF_E_LAUNCH, "joining the auxiliary lane: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
-    return SPF_OK;
+    return rc;
 }
 
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g,
@@ -418,7 +423,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
     LaneSet* lanes = (C > 1 && by_scene) ? lane_set() : nullptr;     // the projection backward owns whole scenes
     if (!lanes) { C = 1; bounds[0] = 0; bounds[1] = d->S * d->V; }
-    for (int c = 0; c < C; ++c) {
+    auto chunk = [&](int c) -> int {                                        // (see spf_raster_forward_render)
         const hipStream_t cs = (c & 1) ? lanes->s : stream;
         const int s0 = bounds[c] / d->V, ns = (bounds[c + 1] - bounds[c]) / d->V;
         const Chunk ch = C > 1 ? make_chunk(*d, *in, *st, nullptr, g, bounds[c], bounds[c + 1], s0, ns)
@@ -436,12 +441,15 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
             SPF_HIP(spf::launch_project_bwd(ch.d, ch.in, ch.st, ch.g, spf_raster_view_partial_blocks(d->G), capacity,
                                             cs));
         }
-    }
+        return SPF_OK;
+    };
+    for (int c = 0; c < C && rc == SPF_OK; ++c) rc = chunk(c);
     if (C > 1) {
-        SPF_HIP(hipEventRecord(lanes->join, lanes->s));
-        SPF_HIP(hipStreamWaitEvent(stream, lanes->join, 0));
+        const hipError_t e1 = hipEventRecord(lanes->join, lanes->s), e2 = hipStreamWaitEvent(stream, lanes->join, 0);
+        if (rc == SPF_OK && (e1 != hipSuccess || e2 != hipSuccess))
+            return fail(SPF_E_LAUNCH, "joining the auxiliary lane: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     }
-    return SPF_OK;
+    return rc;
 }
 
 int spf_adapter_forward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps, float* scales,

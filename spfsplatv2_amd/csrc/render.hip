@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
                 if (hit) {
                     const float4 p2 = s_p2[j];
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    Tr = Tr * inv1ma;
+                    Tr = fmaf(Tr, alpha * inv1ma, Tr);       // (not Tr * inv1ma: see the lists kernel)
                     const float w = alpha * Tr;
                     // colour accumulated behind this entry (recurrence, back to front)
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
@@ -1013,7 +1013,11 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                     // (image = C + T_final*bg and alpha_out = 1 - T_final see alpha_i only through T_final); the
                     // bracket is ONE running scalar, sB.
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                    Tr = Tr * inv1ma;                                           // T_i: transmittance in front of i
+                    // T_i = T_{i+1} / (1 - alpha_i), formed as T + T * (alpha / (1 - alpha)): the hardware reciprocal's
+                    // error (1 ulp, not centred) then enters scaled by alpha instead of in full.  As T * inv1ma it walked
+                    // T off by ~0.4 ulp per entry -- 1e-3 of dL/dcolour at the front of a 40,000-entry list (round 4:
+                    // seen once the knife-edge masks stopped covering half of that test's pixels).
+                    Tr = fmaf(Tr, alpha * inv1ma, Tr);                           // T_i: transmittance in front of i
                     float cg = fmaf(p2.x, gI0, fmaf(p2.y, gI1, p2.z * gI2));
                     if (DEPTH_GRAD) cg = fmaf(p1.w, gD, cg);
                     const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));

@@ -48,9 +48,26 @@ def _kernel_operand(t: Tensor) -> Tensor:
     return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
 
 
+_ONES: dict = {}
+
+
+def unit_grad(device) -> Tensor:
+    """THE dL/dloss = 1 of this process on `device`: a cached 0-dim float32 one.  `loss.backward(gradient=unit_grad(dev))`
+    saves autograd's fill kernel, and the loss's backward recognises this very tensor (by its storage) and hands the
+    forward's unit gradient on without even the one-scalar look of `spf_mse_scale_grad`: no launch at all.  Never write
+    to it."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device(dev.type, torch.cuda.current_device())
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
 class _Mse(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, prediction: Tensor, image: Tensor, weight: float):
+    def forward(ctx, prediction: Tensor, image: Tensor, weight: float, grad_mode: bool = True):
         p, t = _kernel_operand(prediction), _kernel_operand(image)
         lib = _lib.load()
         dev = p.device
@@ -60,7 +77,9 @@ class _Mse(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         # when a backward will come, the forward pass also writes the gradient for dL/dloss = 1 (what
         # `loss.backward()` passes): the backward is then one scalar look at the upstream gradient
-        unit = torch.empty_like(p) if ctx.needs_input_grad[0] else None
+        # (`grad_mode` = torch.is_grad_enabled() at the CALL SITE: needs_input_grad stays True under no_grad, and an
+        #  evaluation loss on a tensor that requires grad must not pay a batch-sized allocation and write)
+        unit = torch.empty_like(p) if (grad_mode and ctx.needs_input_grad[0]) else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             if unit is not None:
@@ -92,8 +111,10 @@ class _Mse(torch.autograd.Function):
                 # first backward through this node: the forward's unit gradient, scaled in place by dL/dloss (a no-op
                 # launch when that is 1).  The buffer is handed to autograd; a second backward (retain_graph) recomputes.
                 gp = unit
-                _lib.check(lib.spf_mse_scale_grad(C.c_void_p(gp.data_ptr()), gp.numel(), C.c_void_p(g.data_ptr()), stream),
-                           "spf_mse_scale_grad")
+                one = _ONES.get(g.device)
+                if not (one is not None and g.data_ptr() == one.data_ptr()):     # (unit_grad(): exactly 1, nothing to do)
+                    _lib.check(lib.spf_mse_scale_grad(C.c_void_p(gp.data_ptr()), gp.numel(), C.c_void_p(g.data_ptr()),
+                                                      stream), "spf_mse_scale_grad")
             else:
                 gp = torch.empty_like(p)
                 _lib.check(lib.spf_mse_backward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
@@ -101,7 +122,7 @@ class _Mse(torch.autograd.Function):
                            "spf_mse_backward")
         gp = gp.view(ctx.shape)
         gi = -gp if ctx.needs_input_grad[1] else None
-        return gp, gi, None
+        return gp, gi, None, None
 
 
 def mse_loss(prediction: Tensor, image: Tensor, weight: float = 1.0) -> Tensor:
@@ -116,7 +137,7 @@ def mse_loss(prediction: Tensor, image: Tensor, weight: float = 1.0) -> Tensor:
         prediction = prediction.float()
     if image.dtype != torch.float32:
         image = image.float()
-    return _Mse.apply(prediction, image, weight)
+    return _Mse.apply(prediction, image, weight, torch.is_grad_enabled())
 
 
 class Loss(nn.Module, ABC, Generic[T_cfg, T_wrapper]):

@@ -161,13 +161,22 @@ _tanfov_cache: dict = {}
 def _tanfov_tensor(tx: float, ty: float, device) -> Tensor:
     """[1,1,2] device tensor of a settings object's two Python floats.  The reference builds its settings from
     `.item()` values once per view (cuda_splatting.py:108-109) and a training run sees the same few cameras' values
-    again and again: the host->device copy (a synchronising call from pageable memory) is paid once per value pair."""
+    again and again: the host->device copy is paid once per value pair.  A cached tensor is shared by every later call
+    on ANY stream, so (a) a miss waits for its copy (one stream synchronisation per new value pair -- the reference's
+    glue has just synchronised twice for the `.item()`s that produced the pair) and (b) cached tensors are never
+    released: the caching allocator cannot hand their memory to someone else while a side stream still reads it.  Beyond
+    4096 pairs new values are simply not cached."""
     key = (tx, ty, device)
     t = _tanfov_cache.get(key)
     if t is None:
-        if len(_tanfov_cache) >= 4096:
-            _tanfov_cache.clear()
-        t = _tanfov_cache[key] = torch.tensor([[[tx, ty]]], dtype=torch.float32, device=device)
+        src = torch.tensor([[[tx, ty]]], dtype=torch.float32)
+        if torch.cuda.is_current_stream_capturing():
+            # (a miss inside a HIP-graph capture: a pageable copy is illegal there; stage through pinned memory, uncached)
+            return src.pin_memory().to(device, non_blocking=True)
+        t = src.to(device)
+        if len(_tanfov_cache) < 4096:
+            torch.cuda.current_stream(t.device).synchronize()
+            _tanfov_cache[key] = t
     return t
 
 

@@ -1,6 +1,9 @@
 """Freeze the rasterizer oracle's OWN values (SURVEY.md 8c fixture (3); BASELINE.md "C1 ... known-answer fixture").
 
-    python tests/golden/make_oracle_known_answers.py        -> tests/golden/oracle_known_answers.pt
+    python tests/golden/make_oracle_known_answers.py                -> tests/golden/oracle_known_answers.pt
+    python tests/golden/make_oracle_known_answers.py --masks-only   -> the same file with ONLY the knife-edge masks
+                                                                       replaced (every frozen VALUE is first checked
+                                                                       against today's oracle to 1e-12 and kept as is)
 
 The rasterizer's arithmetic is parity-unpinned (oracle/splat_ref.py header): no reference binary, no reference-held
 vector.  The one integrity property the parity story can have is that the checker does not drift towards the kernels
@@ -68,8 +71,32 @@ def render(batch, bg, si, band4):
                 grads={k: v for k, v in ref["grads"].items()})
 
 
+def masks_only(dst: Path):
+    """An oracle edit that moves a knife-edge WINDOW (not a value): keep every frozen value, replace the masks.  Refuses
+    if any value differs from the fixture (that would be a change of the arithmetic, to be regenerated in full)."""
+    out = torch.load(dst)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-300))
+    for name, (batch, bg, si, band4) in cases().items():
+        want = out[name]["expect"]
+        got = render(batch, bg, si, band4)
+        for k in ("color", "depth", "alpha"):
+            assert rel(got[k], want[k]) < 1e-12, (name, k, "a VALUE changed: regenerate in full, and say why")
+        assert torch.equal(got["radii"], want["radii"]), name
+        # (loss and gradients are taken over the unflagged pixels: they move WITH the masks and are re-frozen with them)
+        old_f, old_r = float(want["fragile"].float().mean()), float(want["radii_fragile"].float().mean())
+        for k in ("fragile", "radii_fragile", "loss", "grads"):
+            want[k] = got[k]
+        print(name, "fragile", old_f, "->", float(got["fragile"].float().mean()), "radii_fragile", old_r, "->",
+              float(got["radii_fragile"].float().mean()))
+    torch.save(out, dst)
+    print("rewrote the masks (and the masked loss / gradients) of", dst)
+
+
 def main():
     torch.set_num_threads(1)                 # one summation order
+    dst = Path(__file__).resolve().parent / "oracle_known_answers.pt"
+    if "--masks-only" in sys.argv:
+        return masks_only(dst)
     out = {}
     for name, (batch, bg, si, band4) in cases().items():
         res = render(batch, bg, si, band4)
@@ -77,7 +104,6 @@ def main():
                          background=bg, scale_invariant=si, band4=band4, expect=res)
         print(name, "loss", res["loss"], "fragile", float(res["fragile"].float().mean()),
               "visible", int((res["radii"] > 0).sum()), "of", res["radii"].numel())
-    dst = Path(__file__).resolve().parent / "oracle_known_answers.pt"
     torch.save(out, dst)
     print("wrote", dst, dst.stat().st_size, "bytes")
 

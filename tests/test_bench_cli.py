@@ -52,3 +52,17 @@ def test_workload_table_covers_baseline_configs():
     stages = ("project_fwd", "bin_pairs", "tile_sort", "render_fwd", "render_bwd", "project_bwd")
     assert sum(b.stage_bytes(s, S, V, G, K, P, D) for s in stages) > 0
     assert b.total_bytes(S, V, G, K, P, D) == S * V * (G * (308 + 36 * K) + 60.0 * P) + 124.0 * D
+
+
+def test_secondary_children_parse_and_cover_the_verdict_list():
+    """The default single-GPU run reports every BASELINE config, the reference's real workload (with and without SH
+    band 4), the two-stream step and the test_step-shaped latency under `secondary`; every child's command line must be
+    accepted by the script's own parser and must not recurse."""
+    b = _bench()
+    names = [n for n, _, _ in b.SECONDARY]
+    assert names == ["C3", "C5", "REF2V", "REF2V_band4", "C2_streams2", "eval_1x3"]
+    for _name, extra, env in b.SECONDARY:
+        a = b.parse_args(["--gpus", "1", "--no-cpu-baseline", "--no-secondary", *extra])
+        assert a.no_secondary and a.no_cpu_baseline
+        assert all(isinstance(k, str) and isinstance(v, str) for k, v in env.items())
+    assert dict((n, e) for n, _, e in b.SECONDARY)["REF2V_band4"] == {"SPF_SH_BAND4": "1"}

@@ -23,16 +23,17 @@ SH_C0 = 0.28209479177387814
 
 
 # ---- oracle parity at full size --------------------------------------------------------------------------------
-# knife-edge budget: the measured fraction of flagged pixels (profiles/r03_parity_reports.jsonl) + one point
-FRAGILE_CAP = {"C3": 0.05, "C5": 0.035}       # measured 0.037 / 0.021
+# knife-edge budget: about twice the measured fraction of flagged pixels (profiles/r04_parity_reports.jsonl: 0.22 % / 0.19 %
+# with round 4's windows; round 3 flagged 3.7 % / 2.1 % to hide 0.014 % / 0.008 % of pixels that actually differ)
+FRAGILE_CAP = {"C3": 0.005, "C5": 0.004}
 @pytest.mark.parametrize("config,min_pairs,min_list", [("C3", 250000, 1025), ("C5", 400000, 513)])
 def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
     """BASELINE configs 3 and 5 at FULL size, forward and every gradient, one (scene, view) each: 320,000 Gaussians at
     256x256; 500,000 Gaussians with 16 SH coefficients at 512x512 (1,024 tiles).  (The float64 oracle needs seconds for
     these with 16 threads -- tests/conftest.py caps them: on a 256-core host the default is 20x slower.)"""
     batch = syn.make_batch(config, 1, 1, seed=5)
-    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
-    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True, unmasked_too=True)
+    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"], unmasked_too=True)
     # lists of >1000 entries per pixel: proportionally more pixels sit next to an alpha / transmittance threshold
     rep = util.compare(prod, ref, max_fragile_frac=FRAGILE_CAP[config])
     rep.update(num_pairs=prod["stats"]["num_pairs"], max_tile_list=prod["stats"]["max_tile_list"])

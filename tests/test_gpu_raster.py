@@ -31,6 +31,11 @@ CASES = {
 }
 
 
+# knife-edge budget at BASELINE config 2's full size: round 3 flagged 0.8 % of the pixels to hide 0.003 %; with round 4's
+# windows (oracle/splat_ref.py FRAG_*) the flagged fraction is measured at 0.05 % (K = 1) -- the cap is twice that
+FRAGILE_CAP_C2 = 0.002
+
+
 @pytest.mark.parametrize("K,s_mult", [(1, 1.0), (16, 2.0)], ids=["c2", "c2_sh3_wider"])
 def test_parity_vs_oracle_at_full_size(hip_lib, K, s_mult):
     """BASELINE.json configs[1] at FULL size (the bench workload): 65,536 pixel-aligned Gaussians, 256x256 -- and the
@@ -41,9 +46,9 @@ def test_parity_vs_oracle_at_full_size(hip_lib, K, s_mult):
     gate as everywhere else AND switched off in the loss of both sides, so that the gradient gate (1e-3 of the
     tensor's scale, over every Gaussian) compares like with like."""
     batch = syn.make_batch(config="C2", n_scenes=1, n_views=1, seed=8, K=K, s_mult=s_mult)
-    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
-    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
-    rep = util.compare(prod, ref)
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True, unmasked_too=True)
+    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"], unmasked_too=True)
+    rep = util.compare(prod, ref, max_fragile_frac=FRAGILE_CAP_C2)
     rep["num_pairs"] = prod["stats"].get("num_pairs")
     _report(f"c2_full_size_K{K}", rep)
     assert not rep["fails"], rep
@@ -63,8 +68,8 @@ def test_parity_vs_oracle(hip_lib, name):
     batch = syn.make_batch(**kw)
     # knife-edge pixels (flagged by the float64 oracle) are excluded from the RGB gate and switched off in the loss of
     # both sides, so that the gradient gate compares like with like (see test_parity_vs_oracle_at_full_size)
-    ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True)
-    prod = util.run_product(batch, background=bg, scale_invariant=si, pixel_mask=ref["pixel_mask"])
+    ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True, unmasked_too=True)
+    prod = util.run_product(batch, background=bg, scale_invariant=si, pixel_mask=ref["pixel_mask"], unmasked_too=True)
     rep = util.compare(prod, ref)
     rep["num_pairs"] = prod["stats"].get("num_pairs")
     _report(name, rep)

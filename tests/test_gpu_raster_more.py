@@ -9,6 +9,16 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
+# flagged-pixel budgets of the long-list cases and the tolerance of their UNMASKED gradients (measured: see
+# profiles/r04_parity_reports.jsonl, cases long_lists_G*)
+# Round 3 allowed 25 % / 50 % of these images to be masked; with round 4's windows the measured fractions are 0.1 % (3,200 -
+# 12,000 Gaussians), 1.5 % / 2.9 % (50,000 / 110,000) and 5.5 % (131,072 in ONE tile) -- and the unmasked gradients of the
+# two register-sort classes agree to 5e-6 (no pixel flips at all there), so they are gated at the ordinary 1e-3.
+LONG_LIST_FRAGILE_CAP = 0.04
+LONG_LIST_FRAGILE_CAP_ONE_TILE = 0.08
+UNMASKED_GRAD_TOL = 1e-3
+
+
 @pytest.mark.parametrize("G,expect_min_list,hw", [(3200, 513, None), (6500, 1025, None), (12000, 2049, None),
                                                    (50000, 8193, None), (110000, 16385, None),
                                                    (131072, 32769, (16, 16))])
@@ -19,17 +29,22 @@ def test_long_tile_lists_every_sort_class(hip_lib, G, expect_min_list, hw):
     131k Gaussians)."""
     batch = syn.make_batch("TESTBIG", 1, 1, seed=21, s_mult=1.0, G=G, image_hw=hw)     # (16x16: everything in ONE tile)
     batch.opacities = batch.opacities * 0.03        # keep transmittance alive deep into the lists
-    # (knife-edge pixels are switched off in the loss of both sides, as in every other parity test: with a third of
-    #  the pixels next to some threshold a single flipped contribution is a 1e-3 gradient difference by itself)
-    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
-    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    # Knife-edge pixels are excluded from the RGB gate AND switched off in the loss of both sides, as in every other
+    # parity test: every pixel is reached by thousands of entries here, so a good part of the image sits next to some
+    # alpha / stop threshold and a single flipped contribution is a 1e-3 gradient difference by itself.  The gradients
+    # of the loss over ALL pixels are compared too (`gall_*` in the report) and, for the two register-sort classes,
+    # GATED at UNMASKED_GRAD_TOL -- a regression of the long-list backward cannot hide behind the mask.
+    small = G <= 6500
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True, unmasked_too=small)
+    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"], unmasked_too=small)
     assert prod["stats"]["max_tile_list"] >= expect_min_list, prod["stats"]
-    # tens of thousands of Gaussians over a 32x32 image: every pixel is reached by thousands of entries, so
-    # proportionally more pixels sit next to a tile-membership / stop-threshold knife-edge and are excluded from the
-    # RGB gate (gradients are still gated on everything)
-    # (one 16x16 tile under 40,000 entries: more than a third of its 256 pixels are next to some threshold)
-    rep = util.compare(prod, ref, max_fragile_frac=0.25 if hw is None else 0.5)
+    rep = util.compare(prod, ref, max_fragile_frac=LONG_LIST_FRAGILE_CAP if hw is None else LONG_LIST_FRAGILE_CAP_ONE_TILE)
+    from tests.test_gpu_raster import _report
+    _report(f"long_lists_G{G}", rep)
     assert not rep["fails"], rep
+    if small:
+        worst = max(v for k, v in rep.items() if k.startswith("gall_"))
+        assert worst < UNMASKED_GRAD_TOL, rep
 
 
 def test_render_cuda_colors_precomp_matches_oracle(hip_lib):

@@ -138,4 +138,15 @@ def test_hip_loss_unit_gradient_from_the_forward_and_second_backward(hip_lib):
     assert float((a2.grad - want2).abs().max()) <= 1e-6 * float(want2.abs().max())
     # no backward coming: nothing extra is written, the value is the same
     with torch.no_grad():
-        assert torch.equal(L.mse_loss(a, b, 0.5), l.detach())
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        l_eval = L.mse_loss(a, b, 0.5)
+        # (only the loss scalar and the block partials are live: no batch-sized unit-gradient buffer, although `a`
+        #  requires grad -- needs_input_grad stays True under no_grad, the call site's grad mode decides)
+        assert torch.cuda.memory_allocated() - before < a.numel() * 4
+        assert torch.equal(l_eval, l.detach())
+    # the process-wide dL/dloss = 1 (`unit_grad`): recognised by its storage, the backward launches nothing and hands
+    # the forward's unit gradient on as it is
+    a3 = a.detach().clone().requires_grad_(True)
+    L.mse_loss(a3, b, 0.5).backward(gradient=L.unit_grad(a3.device))
+    assert torch.equal(a3.grad, g1)

@@ -38,6 +38,16 @@ def rel_linf(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
 
 
+def rel_elementwise(a: torch.Tensor, b: torch.Tensor, floor: float = 1e-2) -> float:
+    """max over the entries with |b| >= floor * max|b| of |a-b| / |b|: the per-ELEMENT relative error of every entry
+    that is not two orders below the tensor's largest (rel_linf alone lets such an entry be 10 % off unseen)."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    big = b.abs() >= floor * max(float(b.abs().max()), 1e-300)
+    if not bool(big.any()):
+        return 0.0
+    return float(((a - b).abs()[big] / b.abs()[big]).max())
+
+
 # ---------------------------------------------------------------------------------------------
 # Rasterizer parity plumbing
 # ---------------------------------------------------------------------------------------------
@@ -65,11 +75,13 @@ def scalar_loss(color, depth_bvhw, alpha_bv1hw, target, wd, wa, mask=None):
 
 
 def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_invariant=True, want_fragile=True,
-               with_grads=True, mask_fragile=False, band4=False, grad_names=GRAD_NAMES, pixel_mask=None):
+               with_grads=True, mask_fragile=False, band4=False, grad_names=GRAD_NAMES, pixel_mask=None,
+               unmasked_too=False):
     """`mask_fragile`: the loss ignores the pixels the oracle flags as knife-edge; the mask comes back as
     res["pixel_mask"] for `run_product(..., pixel_mask=...)`.  `grad_names`: the inputs that require grad (the others
     are constants, e.g. only "extrinsics" for the reference's test-time pose alignment).  `pixel_mask`: use THIS mask
-    in the loss (a float32 evaluation of the oracle held against the float64 one's mask: `float32_resolvable`)."""
+    in the loss (a float32 evaluation of the oracle held against the float64 one's mask: `float32_resolvable`).
+    `unmasked_too`: also res["grads_all"] / res["loss_all"], the gradients of the loss over ALL pixels (same forward)."""
     from oracle import glue_ref
     leaves = {n: getattr(batch, n).detach().clone().to(dtype).requires_grad_(with_grads and n in grad_names)
               for n in GRAD_NAMES}
@@ -87,11 +99,20 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
         mask = (~out[4]).to(torch.float32) if (mask_fragile and want_fragile) else pixel_mask
         res["pixel_mask"] = mask
         loss = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype), mask)
+        take = lambda: {n: (leaves[n].grad.detach().clone() if leaves[n].grad is not None
+                            else torch.zeros_like(leaves[n])) for n in grad_names}
         if loss.requires_grad:               # (nothing visible in any view: the loss is a constant)
-            loss.backward()
+            loss.backward(retain_graph=unmasked_too)
         res["loss"] = float(loss.detach())
-        res["grads"] = {n: (leaves[n].grad.detach() if leaves[n].grad is not None else torch.zeros_like(leaves[n]))
-                        for n in grad_names}
+        res["grads"] = take()
+        if unmasked_too:
+            for n in grad_names:
+                leaves[n].grad = None
+            loss_all = scalar_loss(color, depth, alpha, batch.target.to(dtype), wd.to(dtype), wa.to(dtype), None)
+            if loss_all.requires_grad:
+                loss_all.backward()
+            res["loss_all"] = float(loss_all.detach())
+            res["grads_all"] = take()
     return res
 
 
@@ -108,7 +129,7 @@ def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cu
 
 
 def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invariant=True, with_grads=True,
-                max_pairs=None, pixel_mask=None, band4=None, grad_names=GRAD_NAMES):
+                max_pairs=None, pixel_mask=None, band4=None, grad_names=GRAD_NAMES, unmasked_too=False):
     """The product, end to end THROUGH ITS DECODER MODULE (`DecoderSplattingCUDA.render` = `forward` + the alpha and
     radii the reference's decoder drops): colour and depth are the module's own outputs, including its depth x near
     post-processing (decoder_splatting_cuda.py:72-76) -- nothing of it is re-implemented here."""
@@ -126,20 +147,33 @@ def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invarian
         wd, wa = loss_weights(batch)
         loss = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device),
                            None if pixel_mask is None else pixel_mask.to(device))
-        loss.backward()
+        loss.backward(retain_graph=unmasked_too)
         res["loss"] = float(loss.detach())
         res["grads"] = {n: leaves[n].grad.detach().cpu() for n in grad_names}
+        if unmasked_too:          # the loss over ALL pixels, second backward through the same forward
+            for n in grad_names:
+                leaves[n].grad = None
+            loss_all = scalar_loss(color, depth, alpha, bd.target, wd.to(device), wa.to(device), None)
+            loss_all.backward()
+            res["loss_all"] = float(loss_all.detach())
+            res["grads_all"] = {n: leaves[n].grad.detach().cpu() for n in grad_names}
     return res
 
 
-def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac=0.02) -> dict:
+def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac=0.005, grad_el_tol=1e-2) -> dict:
     """Returns a report; raises AssertionError with the report if a gate fails.
 
-    Gates (BASELINE.json north_star): RGB within 1e-4 absolute, gradients within 1e-3 of the tensor's scale.
-    Pixels the float64 oracle flags as knife-edge (an alpha within 2e-4 relative of 1/255, a transmittance
-    within 0.1% of the 1e-4 stop, a footprint radius within 1e-4 of an integer, two contributors closer in depth
-    than float32 resolves -- their order is decided by float32 depth bits) are excluded from the RGB gate
-    -- there a one-ulp difference legitimately flips a branch -- but must stay a small fraction.
+    Gates (BASELINE.json north_star): RGB within 1e-4 absolute, gradients within 1e-3 of the tensor's scale -- and
+    (round 4) every gradient ENTRY that is at least 1 % of its tensor's largest within 1e-2 of itself (`gel_*`).
+    Reported, not gated: `rgb_max_all` (the unmasked image) and, when both sides carry them, `gall_*`: the gradients of
+    the loss over ALL pixels, knife-edge pixels included (a branch that legitimately flips there moves them).
+    Pixels the float64 oracle flags as knife-edge (an alpha within 5e-5 relative of 1/255 plus what the float32 pixel
+    centre can move it by, a transmittance within 0.1% of the 1e-4 stop, a contribution that depends on a tile
+    membership decided by a footprint radius within 1e-4 of an integer, two contributors closer in depth than float32
+    resolves -- their order is decided by float32 depth bits; oracle/splat_ref.py FRAG_*) are excluded from the RGB gate
+    -- there a one-ulp difference legitimately flips a branch -- but must stay a small fraction: <= 0.5 % by default
+    (measured <= 0.05 % on the fixed cases), and the number of pixels of the UNMASKED image that are off by more than
+    the tolerance may not exceed the number flagged.
     """
     frag = ref["fragile"] if ref.get("fragile") is not None else torch.zeros_like(ref["depth"], dtype=torch.bool)
     ok = ~frag
@@ -161,6 +195,10 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
     if "grads" in prod and "grads" in ref:
         for n in ref["grads"]:
             rep["g_" + n] = rel_linf(prod["grads"][n], ref["grads"][n])
+            rep["gel_" + n] = rel_elementwise(prod["grads"][n], ref["grads"][n])
+    if "grads_all" in prod and "grads_all" in ref:
+        for n in ref["grads_all"]:
+            rep["gall_" + n] = rel_linf(prod["grads_all"][n], ref["grads_all"][n])
     fails = []
     if rep["fragile_frac"] > max_fragile_frac:
         fails.append("fragile_frac")
@@ -179,6 +217,8 @@ def compare(prod: dict, ref: dict, rgb_tol=1e-4, grad_tol=1e-3, max_fragile_frac
     for n in GRAD_NAMES:
         if rep.get("g_" + n, 0.0) > grad_tol:
             fails.append("g_" + n)
+        if rep.get("gel_" + n, 0.0) > grad_el_tol:
+            fails.append("gel_" + n)
     rep["fails"] = fails
     return rep
 
