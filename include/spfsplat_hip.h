@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SPF_ABI_VERSION 3
+#define SPF_ABI_VERSION 4
 
 #define SPF_OK 0
 #define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
@@ -63,6 +63,16 @@ typedef struct SpfDims {
                             cuda_splatting.py:77-78,114) is accepted as a stride and evaluated to degree 3 like the
                             published 3DGS kernels; 1: band 4 (coefficients 16..24) is evaluated too, forward and
                             backward (the `pose` fork's behaviour is not knowable offline: SURVEY.md 0.6) */
+    int32_t bin_cap;     /* 0: tile lists are packed (tile_start = exclusive scan of the tile counts; the classic chain
+                            project -> scan -> bin -> sort).  > 0 ("direct bins", planned calls only): every tile owns a
+                            fixed bin of bin_cap entries at pairs[tile * bin_cap ..] and the PROJECTION kernel itself
+                            writes the keys there -- no scan, no binning pass, two launches and one pass over the
+                            (Gaussian, view) pairs fewer.  The caller sizes st->pairs for S*V*tiles*bin_cap entries
+                            (<= 2^31) and passes the same value to every call of the forward/backward pair; a tile that
+                            needs more than bin_cap entries raises plan flag 2 (see spf_raster_forward_render). */
+    int64_t pair_capacity; /* direct bins only: number of gradient records g->gpair will hold (the `capacity` the
+                            backward is given); the projection kernel numbers the (Gaussian, tile) pairs and raises plan
+                            flag 1 if they do not fit */
 } SpfDims;
 
 /* Inputs (all float32, contiguous, row-major). */
@@ -98,21 +108,26 @@ typedef struct SpfState {
     float* zkey;           /* [R*G]     view-space depth again, compact (the binning pass reads 8 B per Gaussian
                                         instead of pulling the 48-byte record through the cache) */
     uint32_t* tile_count;  /* [R*T]     Gaussians per tile */
-    uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D */
+    uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D (unused with direct bins) */
     uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */
     uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
                                         area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
                                         "rows" render kernels, the others the sparse "lists" kernels */
-    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: plan verdict (0 = held) 3: number of dense tiles */
-    uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id) */
-    uint32_t* pair_off;    /* [R*G]     index of the Gaussian's first (Gaussian, tile) pair in Gaussian-major order:
-                                        its pair with the k-th tile of its rect (row-major) has index pair_off + k */
+    uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: plan verdict (0 = held) 3: number of dense tiles
+                                        (direct bins: 0 and 3 are not maintained) */
+    uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id)
+                                        (direct bins: [R*T*bin_cap], tile t's list at t * bin_cap) */
+    uint32_t* pair_off;    /* [R*G,2]   (packed tile rect as in `rect`, index of the Gaussian's first (Gaussian, tile) pair):
+                                        its pair with the k-th tile of its rect (row-major) has index pair_off + k.  One
+                                        8-byte record so that the composite backward finds a list entry's gradient slot
+                                        with ONE gather (round 3: rect and pair_off were two arrays, two gathers) */
     uint32_t* blk_total;   /* [R*nblk]  pairs per block of 256 Gaussians, nblk = spf_raster_view_partial_blocks(G) */
     uint32_t* blk_base;    /* [R*nblk]  exclusive scan of blk_total */
     float* final_T;        /* [R*P]     transmittance left after the last contributor */
-    uint32_t* n_contrib;   /* [R*P,2]   per pixel: (1 + list position of the last contributor (0 = none),
-                                        reserved: the number of contributors in builds with -DSPF_LANESORT=1, whose
-                                        backward balances its lanes with it; 0 in the default build) */
+    uint32_t* n_contrib;   /* [R*P]     per pixel: 1 + list position of the last contributor (0 = none) */
+    uint32_t* pair_cursor; /* [8]       direct bins only (may be NULL otherwise): cursors of the pair numbering, ZERO on
+                                        entry of spf_raster_forward_project* (spf_decoder_prepare clears them when they
+                                        lie inside the buffer it is given) */
 } SpfState;
 
 typedef struct SpfOutputs {

@@ -12,7 +12,7 @@ from pathlib import Path
 
 # SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
 LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
                "project_bwd", "rope2d")
@@ -22,7 +22,8 @@ STAGE_COUNT = len(STAGE_NAMES)
 class SpfDims(C.Structure):
     _fields_ = [("S", C.c_int32), ("V", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("sh_degree", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("scale_modifier", C.c_float), ("sh_layout", C.c_int32), ("sh_band4", C.c_int32)]
+                ("scale_modifier", C.c_float), ("sh_layout", C.c_int32), ("sh_band4", C.c_int32),
+                ("bin_cap", C.c_int32), ("pair_capacity", C.c_int64)]
 
 
 def _ptr_struct(name, fields):
@@ -33,7 +34,7 @@ SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opaciti
                                       "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
-                                    "n_contrib"])
+                                    "n_contrib", "pair_cursor"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
 SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",

@@ -12,7 +12,7 @@ hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&,
 hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, uint32_t, hipStream_t);
-hipError_t launch_tile_sort(const SpfState&, int, int, uint64_t, uint32_t, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
                              uint32_t, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
@@ -170,9 +170,9 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
     c.st.rec = off(st.rec, r * G * spf::kRec); c.st.radii = off(st.radii, r * G); c.st.rect = off(st.rect, r * G);
     c.st.zkey = off(st.zkey, r * G); c.st.tile_count = off(st.tile_count, r * T);
     c.st.tile_start = off(st.tile_start, r * T); c.st.tile_fill = off(st.tile_fill, r * T);
-    c.st.tile_flags = off(st.tile_flags, r * T); c.st.pair_off = off(st.pair_off, r * G);
+    c.st.tile_flags = off(st.tile_flags, r * T); c.st.pair_off = off(st.pair_off, 2 * r * G);
     c.st.blk_total = off(st.blk_total, r * nblk); c.st.blk_base = off(st.blk_base, r * nblk);
-    c.st.final_T = off(st.final_T, r * P); c.st.n_contrib = off(st.n_contrib, 2 * r * P);
+    c.st.final_T = off(st.final_T, r * P); c.st.n_contrib = off(st.n_contrib, r * P);
     if (out) {
         c.out.image = off(out->image, 3 * r * P); c.out.depth = off(out->depth, r * P);
         c.out.alpha = off(out->alpha, r * P);
@@ -215,6 +215,15 @@ int check_dims(const SpfDims* d) {
     if (d->K < 0) return fail(SPF_E_INVALID, "K must be >= 0");
     if (d->sh_band4 != 0 && d->sh_band4 != 1) return fail(SPF_E_INVALID, "sh_band4 must be 0 or 1");
     if (d->sh_layout != 0 && d->sh_layout != 1) return fail(SPF_E_INVALID, "sh_layout must be 0 or 1");
+    if (d->bin_cap < 0) return fail(SPF_E_INVALID, "bin_cap must be >= 0");
+    if (d->bin_cap > 0) {
+        const int64_t rt = (int64_t)d->S * d->V * spf_raster_num_tiles(d->H, d->W);
+        if (rt * d->bin_cap > ((int64_t)1 << 31))
+            return fail(SPF_E_INVALID, "direct bins: S*V*tiles*bin_cap = %lld exceeds 2^31", (long long)(rt * d->bin_cap));
+        if (spf_raster_num_tiles(d->H, d->W) > spf::max_lds_tiles())
+            return fail(SPF_E_INVALID, "direct bins need the per-render tile histogram in LDS (<= %d tiles)", spf::max_lds_tiles());
+        if (d->pair_capacity <= 0) return fail(SPF_E_INVALID, "direct bins: pair_capacity must be positive");
+    }
     return SPF_OK;
 }
 
@@ -278,7 +287,8 @@ int spf_camera_backward(const SpfCamera* cam, const float* dL_dviewmatrix, float
 }
 
 // tiles_cleared: 0 = nothing (this call clears the counts), 1 = tile_count | tile_flags, 2 = all the tile bookkeeping
-static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, int tiles_cleared, void* stream_) {
+static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, int tiles_cleared, void* stream_,
+                           uint64_t cleared_words = 0) {
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -289,6 +299,17 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
+    const bool direct = d->bin_cap > 0;
+    if (direct) {
+        if (!st->pairs || !st->pair_cursor || !st->pair_off)
+            return fail(SPF_E_INVALID, "direct bins: pairs, pair_cursor and pair_off are needed by forward_project");
+        // counters[0..3] and the cursors start at zero: inside what spf_decoder_prepare cleared, or cleared here
+        const uint32_t* const end = st->tile_count + cleared_words;
+        if (!(tiles_cleared == 2 && st->counters >= st->tile_count && st->counters + 4 <= end))
+            SPF_HIP(hipMemsetAsync(st->counters, 0, 4 * sizeof(uint32_t), stream));
+        if (!(tiles_cleared == 2 && st->pair_cursor >= st->tile_count && st->pair_cursor + 8 <= end))
+            SPF_HIP(hipMemsetAsync(st->pair_cursor, 0, 8 * sizeof(uint32_t), stream));
+    }
     if (tiles_cleared) {
         // spf_decoder_prepare cleared tile_count | tile_flags | tile_start | tile_fill | counters with the camera set-up
     } else if (st->tile_flags == st->tile_count + RT) {   // adjacent (the Python binding lays them out so): one fill
@@ -301,6 +322,7 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
         StageScope t(SPF_STAGE_PROJECT, stream);
         SPF_HIP(spf::launch_project_fwd(*d, *in, *st, tiles_x, tiles_y, stream));
     }
+    if (direct) return SPF_OK;              // the projection kernel binned; tile_count is the bins' fill: no scan
     {
         StageScope t(SPF_STAGE_SCAN, stream);
         SPF_HIP(spf::launch_tile_scan(*st, d->S * d->V, tiles_x * tiles_y, spf_raster_view_partial_blocks(d->G),
@@ -322,8 +344,8 @@ int spf_raster_forward_project_prepared(const SpfDims* d, const SpfInputs* in, S
     const uint64_t RT = (uint64_t)d->S * d->V * spf_raster_num_tiles(d->H, d->W);
     const bool laid_out = st->tile_count && st->tile_flags == st->tile_count + RT && st->tile_start == st->tile_flags + RT &&
                           st->tile_fill == st->tile_start + RT + 1 && st->counters == st->tile_fill + RT;
-    if (laid_out && cleared_bytes >= 4 * (4 * RT + 5)) return forward_project(d, in, st, 2, stream_);
-    if (laid_out && cleared_bytes >= 8 * RT) return forward_project(d, in, st, 1, stream_);
+    if (laid_out && cleared_bytes >= 4 * (4 * RT + 5)) return forward_project(d, in, st, 2, stream_, cleared_bytes / 4);
+    if (laid_out && cleared_bytes >= 8 * RT) return forward_project(d, in, st, 1, stream_, cleared_bytes / 4);
     return forward_project(d, in, st, 0, stream_);
 }
 
@@ -354,7 +376,7 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     rc = check_inputs(d, in);
     if (rc) return rc;
     if (!st || !st->rec || !st->rect || !st->zkey || !st->tile_start || !st->tile_fill || !st->tile_flags ||
-        !st->counters ||
+        !st->counters || !st->tile_count ||
         !st->final_T || !st->n_contrib || !st->pair_off || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_render is null");
     if (capacity > 0 && !st->pairs) return fail(SPF_E_INVALID, "pairs is null but capacity > 0");
@@ -362,6 +384,22 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
+    if (d->bin_cap > 0) {
+        // direct bins: the lists are already in their bins (spf_raster_forward_project*): sort and composite.  `capacity`
+        // is the number of gradient records here; the bins are memory-safe by construction.
+        if (max_tile_hint != 0u && (uint32_t)d->bin_cap > max_tile_hint) max_tile_hint = (uint32_t)d->bin_cap;
+        const spf::TileLists tl = spf::tile_lists(*st, *d);
+        {
+            StageScope t(SPF_STAGE_SORT, stream);
+            SPF_HIP(spf::launch_tile_sort(*st, tl, RT, RT, ~0ull, max_tile_hint ? max_tile_hint : (uint32_t)d->bin_cap,
+                                          dense_tiles_hint, stream));
+        }
+        {
+            StageScope t(SPF_STAGE_RENDER_FWD, stream);
+            SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, ~0ull, T, tiles_x, dense_tiles_hint, stream));
+        }
+        return SPF_OK;
+    }
     int bounds[kMaxChunks + 1];
     bool by_scene = false;
     int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
@@ -383,7 +421,8 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
         if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));
         {
             StageScope t(SPF_STAGE_SORT, cs);
-            SPF_HIP(spf::launch_tile_sort(ch.st, rt, RT, capacity, max_tile_hint, cs));
+            SPF_HIP(spf::launch_tile_sort(ch.st, spf::tile_lists(ch.st, ch.d), rt, RT, capacity, max_tile_hint,
+                                          dense_tiles_hint, cs));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, cs);
@@ -407,7 +446,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     rc = check_inputs(d, in);
     if (rc) return rc;
     if (!st || !st->rec || !st->radii || !st->rect || !st->tile_start || !st->tile_flags || !st->pairs ||
-        !st->final_T || !st->n_contrib || !st->pair_off)
+        !st->final_T || !st->n_contrib || !st->pair_off || !st->tile_count)
         return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
     if (!g || !g->gpair || !g->dL_dmeans3D || !g->dL_dopacities)
         return fail(SPF_E_INVALID, "gpair, dL_dmeans3D and dL_dopacities are required");
@@ -420,7 +459,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     // (every pair record is written exactly once by its tile: no memset of gpair)
     int bounds[kMaxChunks + 1];
     bool by_scene = false;
-    int C = plan_chunks(d->S, d->V, T, bounds, &by_scene);
+    int C = d->bin_cap > 0 ? 1 : plan_chunks(d->S, d->V, T, bounds, &by_scene);
     LaneSet* lanes = (C > 1 && by_scene) ? lane_set() : nullptr;     // the projection backward owns whole scenes
     if (!lanes) { C = 1; bounds[0] = 0; bounds[1] = d->S * d->V; }
     auto chunk = [&](int c) -> int {                                        // (see spf_raster_forward_render)

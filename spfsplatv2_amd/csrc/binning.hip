@@ -16,6 +16,8 @@
 
 namespace spf {
 
+uint32_t dense_threshold();     // render.hip
+
 // ---- scan of tile counts: single block, n = R*T is small (<= a few 10^5) --------------------
 constexpr int kScanThreads = 1024;
 
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     {
         uint32_t off = bbase + inc - cnt;
         for (int w = 0; w < wave; ++w) off += s_wtot[w];
-        if (live) pair_off[rg] = off;
+        if (live) reinterpret_cast<uint2*>(pair_off)[rg] = make_uint2(rc, off);      // (rect, first pair): SpfState.pair_off
     }
     const uint64_t key = any ? (((uint64_t)__float_as_uint(zk) << 32) | (uint32_t)g) : 0ull;
     if (!lds) {
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
     for (int k = 0; k < VB; ++k) {
         uint32_t off = bbase[k] + inc[k] - cnt[k];
         for (int w = 0; w < wave; ++w) off += s_wtot[k][w];
-        if (live && k < nv) pair_off[(size_t)(r0 + k) * G + g] = off;
+        if (live && k < nv) reinterpret_cast<uint2*>(pair_off)[(size_t)(r0 + k) * G + g] = make_uint2(rc[k], off);
     }
     // ---- count: run-wise for single-tile Gaussians (see the kernel above), one view after the other ----
     LaneRun run[VB];
@@ -389,20 +391,32 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
     }
 }
 
+// Direct bins: nobody scans the tiles, so the sparse / dense census of a PLANNED call (dense_hint = 0: no dense tile,
+// = RT: every tile dense) is verified here, by the one sort kernel that visits every tile -- before the render kernels
+// look at the verdict.  One lane per tile; flag bit 4 as in the binning kernels' plan check.
+__device__ __forceinline__ void census_check(const TileLists& tl, const uint32_t* __restrict__ flags,
+                                             uint32_t* __restrict__ counters, int tile, uint32_t n, int RT,
+                                             uint32_t dense_hint, uint32_t dense_thr) {
+    if (!tl.cap || (threadIdx.x & (kWave - 1)) != 0) return;
+    if (dense_hint != 0u && dense_hint != (uint32_t)RT) return;            // both render kernels run: nothing assumed
+    const bool dense = tile_is_dense(flags[tile], n, dense_thr);
+    if (dense != (dense_hint != 0u)) atomicOr(&counters[2], 4u);
+}
+
 // ---- per-tile sort in LDS ---------------------------------------------------------------------
 // Bitonic network in its "all comparators ascending" form (first step of every merge compares
 // i with i ^ (k-1), the rest with i ^ j): it needs no padding, because a missing partner above n
 // behaves as +infinity and an ascending comparator never moves +infinity.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void spf_sort_tiles_lds_kernel(const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(THREADS) void spf_sort_tiles_lds_kernel(TileLists tl,
                                                                      const uint32_t* __restrict__ counters,
                                                                      uint64_t* __restrict__ pairs,
                                                                      uint64_t capacity, uint32_t lo, uint32_t hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
     if (counters[0] > capacity) return;
-    const uint32_t b = tile_start[blockIdx.x];
-    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, blockIdx.x, b, n);
     if (n <= lo || n > hi) return;
     uint64_t* __restrict__ p = pairs + b;
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) s[i] = p[i];
@@ -531,15 +545,17 @@ __device__ __forceinline__ void sort_tile_in_wave(uint64_t* __restrict__ p, uint
 // Four tiles per 256-thread block (one per wave).  SMALL: lists of 2..64*E entries, keys-per-lane (2/4/8/16 <= E)
 // chosen per tile; otherwise one size class (lo, 64*E].
 template <int E, bool SMALL>
-__global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(const uint32_t* __restrict__ tile_start,
-                                                                     const uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(TileLists tl, const uint32_t* __restrict__ flags,
+                                                                     uint32_t* __restrict__ counters,
                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                     uint32_t lo, int RT) {
+                                                                     uint32_t lo, int RT, uint32_t dense_hint,
+                                                                     uint32_t dense_thr) {
     if (counters[0] > capacity) return;
     const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
-    const uint32_t b = tile_start[tile];
-    const uint32_t n = tile_start[tile + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, tile, b, n);
+    if (SMALL) census_check(tl, flags, counters, tile, n, RT, dense_hint, dense_thr);
     if (n <= lo || n > (uint32_t)(kWave * E)) return;
     if (SMALL) {
         if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
@@ -598,14 +614,14 @@ __device__ __forceinline__ void sort_tile_in_block(uint64_t* __restrict__ p, uin
 }
 
 template <int E>
-__global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_block_kernel(TileLists tl,
                                                                       const uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                       uint32_t lo) {
     __shared__ uint64_t s_x[E * kBlock];
     if (counters[0] > capacity) return;
-    const uint32_t b = tile_start[blockIdx.x];
-    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, blockIdx.x, b, n);
     if (n <= lo || n > (uint32_t)(kBlock * E)) return;
     sort_tile_in_block<E>(pairs + b, n, s_x);
 }
@@ -650,13 +666,15 @@ __device__ __forceinline__ void sort_tile_in_pair(uint64_t* __restrict__ p, uint
         if (e < n) p[e] = r[k];
     }
 }
-__global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(const uint32_t* __restrict__ tile_start,
-                                                                        const uint32_t* __restrict__ counters,
-                                                                        uint64_t* __restrict__ pairs, uint64_t capacity) {
+__global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileLists tl, const uint32_t* __restrict__ flags,
+                                                                        uint32_t* __restrict__ counters,
+                                                                        uint64_t* __restrict__ pairs, uint64_t capacity,
+                                                                        uint32_t dense_hint, uint32_t dense_thr) {
     __shared__ uint64_t s_x[8 * 2 * kWave];
     if (counters[0] > capacity) return;
-    const uint32_t b = tile_start[blockIdx.x];
-    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, blockIdx.x, b, n);
+    census_check(tl, flags, counters, (int)blockIdx.x, n, (int)gridDim.x, dense_hint, dense_thr);
     if (n <= 1u || n > 1024u) return;
     if (n <= 4u * kWave) {                            // one wave is enough (and as fast): the second leaves
         if (threadIdx.x >= kWave) return;
@@ -674,15 +692,16 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(const ui
 // classes touch disjoint tiles, and each alone is a one-round kernel that leaves most of the chip idle (REF2V: 4,096
 // tiles -- 30 % short lists, 70 % of 513 .. 1024, a handful longer: 15 + 23 + 12 us back to back); the long lists are
 // dispatched first.  Same networks, same lists bit for bit.
-__global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(const uint32_t* __restrict__ tile_start,
-                                                                      const uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists tl, const uint32_t* __restrict__ flags,
+                                                                      uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                      int RT) {
+                                                                      int RT, uint32_t dense_hint, uint32_t dense_thr) {
     __shared__ uint64_t s_x[8 * kBlock];
     if (counters[0] > capacity) return;
     if ((int)blockIdx.x < RT) {
-        const uint32_t b = tile_start[blockIdx.x];
-        const uint32_t n = tile_start[blockIdx.x + 1] - b;
+        uint32_t b, n;
+        tile_range(tl, blockIdx.x, b, n);
+        census_check(tl, flags, counters, (int)blockIdx.x, n, RT, dense_hint, dense_thr);
         if (n <= 512u || n > 2048u) return;
         if (n <= 1024u) sort_tile_in_block<4>(pairs + b, n, s_x);
         else sort_tile_in_block<8>(pairs + b, n, s_x);
@@ -690,8 +709,8 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(const uint
     }
     const int tile = ((int)blockIdx.x - RT) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
-    const uint32_t b = tile_start[tile];
-    const uint32_t n = tile_start[tile + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, tile, b, n);
     if (n <= 1u || n > 512u) return;
     if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
     else if (n <= 4u * kWave) sort_tile_in_wave<4>(pairs + b, n);
@@ -740,14 +759,14 @@ __device__ __forceinline__ void lds_tail(uint64_t* s, uint32_t cn) {
     }
 }
 
-__global__ __launch_bounds__(1024) void spf_sort_tiles_big_kernel(const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(1024) void spf_sort_tiles_big_kernel(TileLists tl,
                                                                   const uint32_t* __restrict__ counters,
                                                                   uint64_t* pairs, uint64_t capacity, uint32_t lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
     if (counters[0] > capacity) return;
-    const uint32_t b = tile_start[blockIdx.x];
-    const uint32_t n = tile_start[blockIdx.x + 1] - b;
+    uint32_t b, n;
+    tile_range(tl, blockIdx.x, b, n);
     if (n <= lo) return;
     uint64_t* p = pairs + b;
     uint32_t m = 1;
@@ -834,10 +853,13 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 // Size classes: (1, 512]: one wave per tile, list in registers; (512, 1024], (1024, 2048]: one 256-thread block per tile, list in
 // registers, three LDS exchanges; (2048, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
-// `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family)
-hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t capacity, uint32_t max_tile_hint,
-                            hipStream_t stream) {
+// `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family).
+// `tl`: where the lists are (packed, or direct bins: then the family's first kernel also verifies the planned dense-tile
+// census `dense_hint`, see census_check)
+hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int RT_call, uint64_t capacity,
+                            uint32_t max_tile_hint, uint32_t dense_hint, hipStream_t stream) {
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
+    const uint32_t thr = dense_threshold();
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
     // Lists of 513 .. 2048 entries: one wave per tile (16 / 32 keys per lane) when there are enough tiles to fill the
     // chip with single waves, one 256-thread block per tile when there are not (measured: 2,048 tiles of ~1,000 entries
@@ -847,26 +869,28 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (mixed)
-        spf_sort_tiles_mixed_kernel<<<RT + wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, RT);
+        spf_sort_tiles_mixed_kernel<<<RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
+                                                                       dense_hint, thr);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE");
     if (pairsk)
-        spf_sort_tiles_pair_kernel<<<RT, 2 * kWave, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity);
+        spf_sort_tiles_pair_kernel<<<RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
+                                                                 dense_hint, thr);
     if (mx > 1 && (mx <= 512 || blocks) && !mixed && !pairsk)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
-        spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
-                                                                          capacity, 1, RT);
+        spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                          capacity, 1, RT, dense_hint, thr);
     if (mx > 512 && !blocks && !pairsk)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
-        spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
-                                                                           capacity, 1, RT);
+        spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                           capacity, 1, RT, dense_hint, thr);
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
-        spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs,
-                                                                            capacity, 1024, RT);
+        spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                            capacity, 1024, RT, dense_hint, thr);
     if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
-        spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 512);
+        spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
     if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread
-        spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 1024);
+        spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 1024);
     if (mx > 2048)
-        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 2048, 8192);
+        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 2048, 8192);
     if (mx > 8192) {
         // the opt-in to 128 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device
         static std::atomic<bool> attr_set[64];          // (zero-initialised; the attribute is idempotent, so two host
@@ -880,10 +904,10 @@ hipError_t launch_tile_sort(const SpfState& st, int RT, int RT_call, uint64_t ca
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
-        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 8192, 16384);
+        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 16384 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 8192, 16384);
     }
     if (mx > 16384)
-        spf_sort_tiles_big_kernel<<<RT, 1024, 16384 * 8, stream>>>(st.tile_start, st.counters, st.pairs, capacity, 16384);
+        spf_sort_tiles_big_kernel<<<RT, 1024, 16384 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 16384);
     return hipGetLastError();
 }
 

@@ -415,11 +415,17 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 // (a block holds 256 Gaussians), footprint load (sum of cull-box areas capped at 256 each: <= 65,536) in the low 20.
 constexpr uint32_t kHistCountShift = 20u, kHistAreaMask = (1u << 20) - 1u;
 // views whose histograms fit the LDS budget at once (the loop flushes between groups)
-__host__ __device__ inline int hist_view_group(int V, int T) {
-    const int fit = (32 * 1024) / (4 * T);
+// (direct bins: a group also holds the bins' base offsets [VG][T] and every thread's (rect, depth) per view)
+__host__ __device__ inline int hist_view_group(int V, int T, bool direct = false) {
+    const int fit = direct ? (36 * 1024) / (8 * T + 2048) : (32 * 1024) / (4 * T);
     return fit < 1 ? 1 : (fit < V ? fit : V);
 }
 
+// Direct bins (d.bin_cap > 0; lds_hist only): the kernel ALSO bins.  After the views of a group the block reserves,
+// with one returning global atomic per touched (view, tile), a range of that tile's fixed bin (st.pairs[tile * bin_cap ..]),
+// numbers its (Gaussian, tile) pairs from a sharded global cursor, and every thread writes its keys
+// (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
+// rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
@@ -429,11 +435,17 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
     // 16-byte stores (a lane's own three float4 stores at a 48-byte stride touch three times the cache lines).
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     const int T = tiles_x * tiles_y;
-    const int VG = lds_hist ? hist_view_group(d.V, T) : d.V;
+    const bool direct = d.bin_cap > 0;                                    // (host: only together with lds_hist)
+    const int VG = lds_hist ? hist_view_group(d.V, T, direct) : d.V;
     uint32_t* const s_hist = s_dyn;                                       // [VG][T]   (lds_hist only)
     uint32_t* const s_wtot = s_dyn + (lds_hist ? VG * T : 0);             // [VG][4]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float4* const s_rec = reinterpret_cast<float4*>(s_wtot + ((VG * 4 + 3) & ~3)) + wave * (kWave * 3);
+    float4* const s_rec0 = reinterpret_cast<float4*>(s_wtot + ((VG * 4 + 3) & ~3));
+    float4* const s_rec = s_rec0 + wave * (kWave * 3);
+    // direct bins: [VG][T] base of the block's range in every bin | [VG][256] (rect, depth bits) of every thread | [VG] pair base
+    uint32_t* const s_base = reinterpret_cast<uint32_t*>(s_rec0 + 4 * kWave * 3);
+    uint2* const s_park = reinterpret_cast<uint2*>(s_base + VG * T);
+    uint32_t* const s_vbase = reinterpret_cast<uint32_t*>(s_park + VG * kBlock);
     const int g = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
     const bool live = g < d.G;
@@ -561,8 +573,10 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             // (per-lane 64-bit index as is: a scalar per-render base plus a 32-bit lane offset saves a few address
             //  instructions but measured 10 % SLOWER on the SH-heavy forwards -- K = 16: 139 -> 152 us, K = 25: 167 -> 187)
             const size_t rg_ = (size_t)r * d.G + g;
-            st.radii[rg_] = ok ? (int)radius : 0; st.rect[rg_] = rect_w; st.zkey[rg_] = zk;
+            st.radii[rg_] = ok ? (int)radius : 0;
+            if (!direct) { st.rect[rg_] = rect_w; st.zkey[rg_] = zk; }      // (direct bins: parked below, binned by this block)
         }
+        if (direct) s_park[(v - v0) * kBlock + threadIdx.x] = make_uint2(rect_w, __float_as_uint(zk));
         // ---- the wave's 64 records: own 48 bytes into LDS (conflict-free at this stride), contiguous 16-byte pieces out ----
         s_rec[3 * lane] = rec0; s_rec[3 * lane + 1] = rec1; s_rec[3 * lane + 2] = rec2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -611,6 +625,84 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         // pairs produced by this wave for this render (feeds the Gaussian-major pair numbering)
         const uint32_t wtot = wave_iscan_u32((uint32_t)npair);
         if (lane == kWave - 1) s_wtot[(v - v0) * 4 + wave] = wtot;
+      }
+      if (direct) {
+          // ---- direct bins: reserve, number, write keys (see the kernel's header comment) ----
+          __syncthreads();
+          const int nv = vend - v0;
+          if (threadIdx.x == 0) {
+              // the block's pairs of this group of views, numbered from one cursor (Gaussian-major inside the block)
+              uint32_t tot = 0;
+              for (int i = 0; i < nv; ++i) {
+                  s_vbase[i] = tot;
+                  tot += s_wtot[4 * i] + s_wtot[4 * i + 1] + s_wtot[4 * i + 2] + s_wtot[4 * i + 3];
+              }
+              const int nsh = pair_shards((int)(gridDim.x * gridDim.y));
+              const int sh = (int)((blockIdx.x + blockIdx.y * gridDim.x) % (unsigned)nsh);
+              const uint64_t shard_cap = (uint64_t)d.pair_capacity / (uint64_t)nsh;
+              const uint32_t at = tot ? atomicAdd(&st.pair_cursor[sh], tot) : 0u;
+              if ((uint64_t)at + tot > shard_cap) atomicOr(&st.counters[2], 1u);        // gradient records would not fit
+              s_vbase[VG] = (uint32_t)(shard_cap * (uint64_t)sh) + at;
+          }
+          uint32_t longest = 0;
+          for (int i = threadIdx.x; i < nv * T; i += kBlock) {
+              const uint32_t c = s_hist[i];
+              if (c) {
+                  const int vi = i / T, t = i - vi * T;
+                  const size_t rt = (size_t)(s * d.V + v0 + vi) * T + t;
+                  const uint32_t cnt = c >> kHistCountShift;
+                  const uint32_t old = atomicAdd(&st.tile_count[rt], cnt);
+                  atomicAdd(&st.tile_flags[rt], c & kHistAreaMask);
+                  s_base[i] = old;
+                  s_hist[i] = 0;                                                         // (now: slots handed out)
+                  longest = max(longest, old + cnt);
+              }
+          }
+          longest = wave_max_u32(longest);
+          if (lane == 0 && longest) {
+              atomicMax(&st.counters[1], longest);
+              if (longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);         // a bin overflows: plan flag 2
+          }
+          __syncthreads();
+          const uint32_t pbase = s_vbase[VG];
+          for (int vi = 0; vi < nv; ++vi) {
+              const int r = s * d.V + v0 + vi;
+              const uint2 pk = s_park[vi * kBlock + threadIdx.x];
+              const uint32_t rc = pk.x;
+              const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff, y1 = rc >> 24;
+              const uint32_t cnt = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
+              const uint32_t inc = wave_iscan_u32(cnt);
+              uint32_t off = pbase + s_vbase[vi] + inc - cnt;
+              for (int w = 0; w < wave; ++w) off += s_wtot[4 * vi + w];
+              if (live) reinterpret_cast<uint2*>(st.pair_off)[(size_t)r * d.G + g] = make_uint2(rc, off);
+              const uint64_t key = ((uint64_t)pk.y << 32) | (uint32_t)g;
+              uint32_t* __restrict__ slots = s_hist + vi * T;
+              const uint32_t* __restrict__ bs = s_base + vi * T;
+              uint64_t* __restrict__ bins = st.pairs + (size_t)r * T * (size_t)d.bin_cap;
+              const bool single = cnt == 1u;
+              const int stile = single ? y0 * tiles_x + x0 : -1;
+              const LaneRun run = lane_runs(stile, lane);
+              uint32_t first = 0u;
+              if (single && run.head == lane) first = atomicAdd(&slots[stile], (uint32_t)run.len);
+              first = (uint32_t)__shfl((int)first, run.head, kWave);                    // (uniform flow: every lane)
+              if (single) {
+                  const uint32_t pos = bs[stile] + first + (uint32_t)(lane - run.head);
+                  if (pos < (uint32_t)d.bin_cap) bins[(size_t)stile * d.bin_cap + pos] = key;
+              }
+              if (cnt > 1u)
+                  for (int ty = y0; ty < y1; ++ty)
+                      for (int tx = x0; tx < x1; ++tx) {
+                          const int t = ty * tiles_x + tx;
+                          const uint32_t pos = bs[t] + atomicAdd(&slots[t], 1u);
+                          if (pos < (uint32_t)d.bin_cap) bins[(size_t)t * d.bin_cap + pos] = key;
+                      }
+          }
+          if (vend < d.V) {
+              __syncthreads();
+              for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
+              __syncthreads();
+          }
+          continue;
       }
       // ---- flush the group: block pair totals and the tiles this block touched (one global atomic pair per tile) ----
       __syncthreads();
@@ -731,9 +823,10 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
     auto pairs_of = [](uint32_t rc) -> int {
         return (int)(((rc >> 16) & 0xff) - (rc & 0xff)) * (int)((rc >> 24) - ((rc >> 8) & 0xff));
     };
-    uint32_t rc_cur = live ? st.rect[rg0] : 0u, po_cur = live ? st.pair_off[rg0] : 0u;
-    uint32_t rc_nxt = 0u, po_nxt = 0u;
-    if (live && d.V > 1) { rc_nxt = st.rect[rg0 + d.G]; po_nxt = st.pair_off[rg0 + d.G]; }
+    const uint2* __restrict__ pinfo = reinterpret_cast<const uint2*>(st.pair_off);     // (rect, first pair): one 8-byte load
+    uint32_t rc_cur = 0u, po_cur = 0u, rc_nxt = 0u, po_nxt = 0u;
+    if (live) { const uint2 pi = pinfo[rg0]; rc_cur = pi.x; po_cur = pi.y; }
+    if (live && d.V > 1) { const uint2 pi = pinfo[rg0 + d.G]; rc_nxt = pi.x; po_nxt = pi.y; }
     f4a q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
     float q8 = 0.f, q9 = 0.f;
     if (pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
@@ -764,7 +857,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)
         float4 g2 = make_float4(q8, q9, 0.f, 0.f);
         // ... and the loads of the views behind it
         rc_cur = rc_nxt; po_cur = po_nxt;
-        if (live && v + 2 < d.V) { rc_nxt = st.rect[rg + 2 * (size_t)d.G]; po_nxt = st.pair_off[rg + 2 * (size_t)d.G]; }
+        if (live && v + 2 < d.V) { const uint2 pi = pinfo[rg + 2 * (size_t)d.G]; rc_nxt = pi.x; po_nxt = pi.y; }
         q0 = f4a{0.f, 0.f, 0.f, 0.f}; q1 = q0; q8 = 0.f; q9 = 0.f;
         if (v + 1 < d.V && pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
             const float* __restrict__ gp = gr.gpair + (size_t)po_cur * gs;
@@ -1102,10 +1195,14 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
     const int lds = T <= max_lds_tiles() ? 1 : 0;
-    const int VG = lds ? hist_view_group(d.V, T) : d.V;
+    const bool direct = d.bin_cap > 0;
+    if (direct && (!lds || !st.pairs || !st.pair_cursor)) return hipErrorInvalidValue;   // (api.hip checks first)
+    const int VG = lds ? hist_view_group(d.V, T, direct) : d.V;
     // packed tile histograms of a group of views | per-wave pair totals | record staging (4 waves x 64 x 48 bytes)
-    const size_t sm = sizeof(uint32_t) * ((lds ? (size_t)VG * T : 0) + (((size_t)VG * 4 + 3) & ~(size_t)3)) +
-                      (size_t)kBlock * kRec * sizeof(float);
+    // [| direct bins: range bases [VG][T] | parked (rect, depth) [VG][256] | pair bases [VG + 1]]
+    size_t sm = sizeof(uint32_t) * ((lds ? (size_t)VG * T : 0) + (((size_t)VG * 4 + 3) & ~(size_t)3)) +
+                (size_t)kBlock * kRec * sizeof(float);
+    if (direct) sm += sizeof(uint32_t) * ((size_t)VG * T + 2 * (size_t)VG * kBlock + (((size_t)VG + 1 + 3) & ~(size_t)3));
     if (sm > 64 * 1024) return hipErrorInvalidValue;     // (V > ~3,000 views per scene without LDS histograms)
     SPF_DISPATCH_DEG(project_fwd_t, grid, sm, stream, d, in, st, tiles_x, tiles_y, lds)
     return hipGetLastError();

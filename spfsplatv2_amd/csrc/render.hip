@@ -21,12 +21,8 @@
 
 #include "spf_common.h"
 
-// -DSPF_LANESORT=1: the lists backward puts its pixels on lanes by contributor count (see its prologue); only then do
-// the forward kernels count a pixel's contributors (n_contrib's second word; 0 otherwise -- the profiling build counts too)
-#ifndef SPF_LANESORT
-#define SPF_LANESORT 0
-#endif
-#if SPF_LANESORT || defined(SPF_PHASE_CLOCKS)
+// (profiling builds -- SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS -- count a pixel's contributors in the forward lists kernel)
+#ifdef SPF_PHASE_CLOCKS
 #define SPF_COUNT_HITS 1
 #else
 #define SPF_COUNT_HITS 0
@@ -151,7 +147,7 @@ __device__ __forceinline__ void poison_tile(int RT, int T, int tiles_x, int H, i
 // Forward: front-to-back compositing, one 4x4 pixel block per DPP row (see the header comment).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
     const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
@@ -165,15 +161,15 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
     BlockCtx c;
     if (!block_ctx(c, RT, T, tiles_x, H, W)) return;
-    const uint32_t beg = tile_start[(size_t)c.r * T + c.tile];
-    const uint32_t n = tile_start[(size_t)c.r * T + c.tile + 1] - beg;
+    uint32_t beg, n;
+    tile_range(tl, (size_t)c.r * T + c.tile, beg, n);
     if (!tile_is_dense(tile_flags[(size_t)c.r * T + c.tile], n, dense_thr)) return;   // sparse tiles: lists kernel
     const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
     float fx = (float)c.px, fy = (float)c.py;
     asm volatile("" : "+v"(fx), "+v"(fy));   // keep the converted coordinates live (no per-iteration v_cvt)
 
     float Tr = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0, hits = 0;
+    uint32_t last = 0;
     bool done = !c.inside;
     bool row_done = false;
     bool wave_done = __ballot(!done) == 0;
@@ -226,7 +222,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
                     C0 = fmaf(p2.x, w, C0); C1 = fmaf(p2.y, w, C1); C2 = fmaf(p2.z, w, C2); Dp = fmaf(p2.w, w, Dp);
                     Tr = take ? test_T : Tr;
                     last = take ? base + (uint32_t)j + 1u : last;
-                    if (SPF_COUNT_HITS) hits += take ? 1u : 0u;
                 }
                 // per-row / per-wave early termination from one ballot per 32 entries
                 const uint64_t alive = __ballot(!done);
@@ -246,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
         depth_out[(size_t)c.r * P + pix] = Dp;
         alpha_out[(size_t)c.r * P + pix] = 1.0f - Tr;
         final_T[(size_t)c.r * P + pix] = Tr;
-        reinterpret_cast<uint2*>(n_contrib)[(size_t)c.r * P + pix] = make_uint2(last, hits);
+        n_contrib[(size_t)c.r * P + pix] = last;
     }
 }
 
@@ -357,32 +352,8 @@ __device__ __forceinline__ TileBox clipped_box(float gx, float gy, float r2, int
     return t;
 }
 
-// Lane <-> pixel assignment of the lists backward (the forward keeps the natural order: sorting its pixels by
-// candidate count was measured -- 20 % fewer replay instructions, no time gained).  A wave of the pixel-private loops runs as long as its busiest pixel,
-// so the tile's 256 pixels are put on lanes in descending order of `load` (<= 255): pixels of similar load share a
-// wave.  Counting sort in LDS with two barriers: histogram by LDS atomics (the rank inside a bin is the atomic's
-// return value), then EVERY wave scans all 256 bins for itself (4 bins per lane, DPP prefix sum) -- no cross-wave
-// exchange.  s_cnt must hold 256 zeros (with a barrier since they were written); s_perm: 256 words.  Returns the pixel
-// (0..255, row-major in the tile) of the calling thread.  All 256 threads must call it.
-__device__ __forceinline__ int assign_pixels_by_load(uint32_t load, uint32_t* s_cnt, uint32_t* s_perm) {
-    const int tid = threadIdx.x, lane = tid & (kWave - 1);
-    const uint32_t bin = 255u - min(load, 255u);                        // descending load
-    const uint32_t rank_in_bin = atomicAdd(&s_cnt[bin], 1u);
-    __syncthreads();
-    const uint4 c = reinterpret_cast<const uint4*>(s_cnt)[lane];        // bins 4*lane .. 4*lane+3
-    const uint32_t tot = c.x + c.y + c.z + c.w;
-    const uint32_t excl = wave_iscan_u32(tot) - tot;                    // pixels in bins before 4*lane
-    const uint32_t before = (uint32_t)__shfl((int)excl, (int)(bin >> 2), kWave);
-    const uint4 g = reinterpret_cast<const uint4*>(s_cnt)[bin >> 2];    // the four bins of my group
-    const uint32_t k = bin & 3u;
-    const uint32_t start = before + (k > 0u ? g.x : 0u) + (k > 1u ? g.y : 0u) + (k > 2u ? g.z : 0u);
-    s_perm[start + rank_in_bin] = (uint32_t)tid;
-    __syncthreads();
-    return (int)s_perm[tid];
-}
-
 __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
     const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
@@ -409,8 +380,8 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const int pid = ly * kTile + lx;            // this thread's pixel inside the tile (row-major): its candidate column
     const int px = X0 + lx, py = Y0 + ly;
     const bool inside = px < W && py < H;
-    const uint32_t beg = tile_start[(size_t)r * T + tile];
-    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
+    uint32_t beg, n;
+    tile_range(tl, (size_t)r * T + tile, beg, n);
     if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
@@ -554,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         depth_out[(size_t)r * P + pix] = c2d.y;
         alpha_out[(size_t)r * P + pix] = 1.0f - Tr;
         final_T[(size_t)r * P + pix] = Tr;
-        reinterpret_cast<uint2*>(n_contrib)[(size_t)r * P + pix] = make_uint2(last, hits);
+        n_contrib[(size_t)r * P + pix] = last;
     }
 }
 
@@ -573,10 +544,10 @@ __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t s
 
 template <bool DEPTH_GRAD>
 __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off, float* __restrict__ gpair, int G, int H,
+    const uint2* __restrict__ pinfo, float* __restrict__ gpair, int G, int H,
     int W, int T, int tiles_x, int RT, uint32_t dense_thr, const uint32_t* __restrict__ counters, uint64_t capacity) {
     (void)capacity;
     if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
@@ -591,9 +562,9 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     if (vid >= RT) return;
     const int r = vid / T, tile = vid - r * T;
-    if (!tile_is_dense(tile_flags[(size_t)r * T + tile],
-                       tile_start[(size_t)r * T + tile + 1] - tile_start[(size_t)r * T + tile], dense_thr))
-        return;                                                             // sparse tiles: lists kernel
+    uint32_t beg, n;
+    tile_range(tl, (size_t)r * T + tile, beg, n);
+    if (!tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;   // sparse tiles: lists kernel
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1);
@@ -601,25 +572,22 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     const int px = tx * kTile + bx * 4 + (l16 & 3), py = ty * kTile + by * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
 
-    const uint32_t beg = tile_start[(size_t)r * T + tile];
-    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
     if (n == 0) return;
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     const float fx = (float)px, fy = (float)py;
     const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
-    // Gaussian-major index of list entry idx's (Gaussian, tile) pair
+    // Gaussian-major index of list entry idx's (Gaussian, tile) pair: ONE 8-byte gather (rect, first pair)
     auto pair_slot = [&](uint32_t gid) -> uint32_t {
-        const size_t rg = (size_t)r * G + gid;
-        const uint32_t rc = rect[rg];
-        const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
-        return pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+        const uint2 pi = pinfo[(size_t)r * G + gid];
+        const int x0 = pi.x & 0xff, y0 = (pi.x >> 8) & 0xff, x1 = (pi.x >> 16) & 0xff;
+        return pi.y + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     };
 
     float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
     uint32_t ncon = 0;
     if (inside) {
         T_final = final_T[(size_t)r * P + pix];
-        ncon = n_contrib[2 * ((size_t)r * P + pix)];
+        ncon = n_contrib[(size_t)r * P + pix];
         if (dL_dimage) {
             const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
             gI0 = gi[pix]; gI1 = gi[P + pix]; gI2 = gi[2 * P + pix];
@@ -796,10 +764,10 @@ constexpr int kRoundL = SPF_ROUNDL;  // candidate entries per round (6 mask word
 
 template <bool DEPTH_GRAD>
 __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ tile_start,
+    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha, const uint32_t* __restrict__ rect, const uint32_t* __restrict__ pair_off,
+    const float* __restrict__ dL_dalpha, const uint2* __restrict__ pinfo,
     float* __restrict__ gpair, int G, int H, int W, int T, int tiles_x, int RT, uint32_t dense_thr_arg,
     const uint32_t* __restrict__ counters, uint64_t capacity) {
     (void)capacity;
@@ -821,8 +789,8 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = tx * kTile, Y0 = ty * kTile;
-    const uint32_t beg = tile_start[(size_t)r * T + tile];
-    const uint32_t n = tile_start[(size_t)r * T + tile + 1] - beg;
+    uint32_t beg, n;
+    tile_range(tl, (size_t)r * T + tile, beg, n);
     if (n == 0) return;
     if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
     PHASE_INIT();
@@ -830,62 +798,36 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const size_t P = (size_t)H * W;
     // ---- per-pixel state: thread <-> pixel in the natural order ----
     // (Rounds 1 - 3 put the pixels on lanes by the number of contributors the forward recorded -- an LDS counting sort,
-    // two barriers, the state parked in LDS and picked up again -- so that a wave's lanes finish their replay together.
-    // That paid while the replay was most of the kernel (0.242 -> 0.214 ms in round 1); at 28 % of the wave time it no
-    // longer does: without it the kernel is 2.4 us FASTER on C2 and 1 % on C5 (same-box A/B), and three barriers shorter.
-    // SPF_LANESORT=1 at build time brings it back.)
-    int mypix;
-    float T_final, gI0, gI1, gI2, gD, gA;
-    uint32_t ncon;
+    // three barriers, the state parked in LDS and picked up again.  It paid while the replay was most of the kernel; at
+    // 28 % of the wave time it cost 2.4 us more than it gave on C2, and it went together with the forward's per-pixel
+    // contributor count in round 4.)
+    const int mypix = tid;
+    float T_final = 1.f, gI0 = 0.f, gI1 = 0.f, gI2 = 0.f, gD = 0.f, gA = 0.f;
+    uint32_t ncon = 0;
     {
         const int qx = X0 + (tid & 15), qy = Y0 + (tid >> 4);
-        uint32_t h = 0, nc = 0;
-        float tf = 1.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, qd = 0.f, qa = 0.f;
         if (qx < W && qy < H) {
             const size_t qpix = (size_t)qy * W + qx;
-            const uint2 c2 = reinterpret_cast<const uint2*>(n_contrib)[(size_t)r * P + qpix];   // (last, hits)
-            nc = c2.x; h = c2.y;
-            tf = final_T[(size_t)r * P + qpix];
+            ncon = n_contrib[(size_t)r * P + qpix];
+            T_final = final_T[(size_t)r * P + qpix];
             if (dL_dimage) {
                 const float* __restrict__ gi = dL_dimage + (size_t)r * 3 * P;
-                q0 = gi[qpix]; q1 = gi[P + qpix]; q2 = gi[2 * P + qpix];
+                gI0 = gi[qpix]; gI1 = gi[P + qpix]; gI2 = gi[2 * P + qpix];
             }
-            if (DEPTH_GRAD) qd = dL_ddepth[(size_t)r * P + qpix];
-            if (dL_dalpha) qa = dL_dalpha[(size_t)r * P + qpix];
+            if (DEPTH_GRAD) gD = dL_ddepth[(size_t)r * P + qpix];
+            if (dL_dalpha) gA = dL_dalpha[(size_t)r * P + qpix];
         }
-#if SPF_LANESORT
-        s_pm[0][tid] = 0u;                        // (s_pm is free before the rounds: bins in word 0, order in word 1)
-        __syncthreads();
-        mypix = assign_pixels_by_load(h, &s_pm[0][0], &s_pm[1][0]);
-        // (the loads are only needed from here on)
-        s_gI[tid] = make_float4(q0, q1, q2, DEPTH_GRAD ? qd : 1.f);   // .w == 1 lets phase C fold sum(u) into a packed fma
-        s_pool[tid] = make_float2(tf, __uint_as_float(nc));           // (the pool is free before the rounds too)
-        s_pool[kBlock + tid] = make_float2(qa, 0.f);
-        __syncthreads();
-        const float4 g4 = s_gI[mypix];
-        const float2 t2 = s_pool[mypix];
-        T_final = t2.x; ncon = __float_as_uint(t2.y);
-        gI0 = g4.x; gI1 = g4.y; gI2 = g4.z; gD = DEPTH_GRAD ? g4.w : 0.f;
-        gA = s_pool[kBlock + mypix].x;
-#else
-        (void)h;
-        mypix = tid;
-        s_gI[tid] = make_float4(q0, q1, q2, DEPTH_GRAD ? qd : 1.f);   // phase C's table; .w == 1 lets it fold sum(u) into a packed fma
-        T_final = tf; ncon = nc;                                      // (visible to the block after the barrier below)
-        gI0 = q0; gI1 = q1; gI2 = q2; gD = DEPTH_GRAD ? qd : 0.f;
-        gA = qa;
-#endif
+        s_gI[tid] = make_float4(gI0, gI1, gI2, DEPTH_GRAD ? gD : 1.f);   // phase C's table; .w == 1 lets it fold sum(u) into a packed fma
     }
     const int lx = mypix & 15, ly = mypix >> 4;
     const int px = X0 + lx, py = Y0 + ly;
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
-    auto pair_slot = [&](uint32_t gid) -> uint32_t {
-        const size_t rg = (size_t)r * G + gid;
-        const uint32_t rc = rect[rg];
-        const int x0 = rc & 0xff, y0 = (rc >> 8) & 0xff, x1 = (rc >> 16) & 0xff;
-        return pair_off[rg] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    auto pair_slot = [&](uint32_t gid) -> uint32_t {                  // ONE 8-byte gather: (rect, first pair)
+        const uint2 pi = pinfo[(size_t)r * G + gid];
+        const int x0 = pi.x & 0xff, y0 = (pi.x >> 8) & 0xff, x1 = (pi.x >> 16) & 0xff;
+        return pi.y + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
     };
     const float* __restrict__ bg = bg_all + 3 * r;
     const float tail = gA - (bg[0] * gI0 + bg[1] * gI1 + bg[2] * gI2);
@@ -1208,13 +1150,14 @@ static void join_dense(hipStream_t stream, AuxStream* a) {
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
                              uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, hipStream_t stream) {
     const int RT = d.S * d.V * T;
+    const TileLists tl = tile_lists(st, d);
     const int grid = (RT + 7) / 8 * 8;
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
     if (sparse)
         spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT,
 #ifdef SPF_ABLATE
             dense_threshold() | ((uint32_t)g_ablate_host << 28));
@@ -1223,7 +1166,7 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
 #endif
     if (dense)
         spf_render_fwd_rows_kernel<<<grid, kBlock, 0, ds>>>(
-            st.rec, st.pairs, st.tile_start, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
     join_dense(stream, a);
     return hipGetLastError();
@@ -1234,12 +1177,14 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
                                 int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity,
                                 hipStream_t stream) {
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
+    const TileLists tl = tile_lists(st, d);
+    const uint2* const pinfo = reinterpret_cast<const uint2*>(st.pair_off);
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
     if (sparse)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
+            st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
 #ifdef SPF_ABLATE
             dense_threshold() | ((uint32_t)g_ablate_host << 28),
 #else
@@ -1248,8 +1193,8 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
             st.counters, capacity);
     if (dense)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, ds>>>(
-            st.rec, st.pairs, st.tile_start, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, st.rect, st.pair_off, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters,
+            st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters,
             capacity);
     join_dense(stream, a);
 }

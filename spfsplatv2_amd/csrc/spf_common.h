@@ -219,6 +219,29 @@ __device__ __forceinline__ uint32_t disc_area_capped_fast(float gx, float gy, fl
 }
 __device__ __forceinline__ bool tile_is_dense(uint32_t area_sum, uint32_t n, uint32_t thr = SPF_DENSE_AREA) { return area_sum > thr * n; }
 
+// Where tile `vid` (= render * T + tile) keeps its list: packed lists (start = exclusive scan of the counts) or, with
+// direct bins (SpfDims.bin_cap), a fixed bin of `cap` entries per tile filled by the projection kernel.
+struct TileLists {
+    const uint32_t* __restrict__ start;   // [R*T+1] (packed lists)
+    const uint32_t* __restrict__ count;   // [R*T]   (direct bins)
+    uint32_t cap;                         // 0: packed lists
+};
+__device__ __forceinline__ void tile_range(const TileLists& tl, size_t vid, uint32_t& beg, uint32_t& n) {
+    if (tl.cap) {
+        beg = (uint32_t)vid * tl.cap;
+        n = min(tl.count[vid], tl.cap);
+    } else {
+        beg = tl.start[vid];
+        n = tl.start[vid + 1] - beg;
+    }
+}
+inline TileLists tile_lists(const SpfState& st, const SpfDims& d) {
+    return TileLists{st.tile_start, st.tile_count, (uint32_t)(d.bin_cap > 0 ? d.bin_cap : 0)};
+}
+// shards of the direct-bins pair numbering (one cursor each): blocks spread over up to 8 cursors so that the returning
+// atomics of a whole round of blocks do not queue on one address (~88 per us); few blocks -> one shard (no imbalance)
+__host__ __device__ inline int pair_shards(int nblocks) { return nblocks >= 512 ? 8 : 1; }
+
 // XCD-aware block remap: the dispatcher places block b on XCD b % 8, so give each XCD one
 // contiguous range of work ids (contiguous renders -> their records stay in that XCD's L2).
 // Speed only; correctness never depends on it.  grid must be a multiple of 8.

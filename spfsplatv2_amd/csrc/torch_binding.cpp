@@ -65,18 +65,20 @@ SpfState make_state(const Tensor& rec, const Tensor& radii, const Tensor& rect, 
     st.rect = ptr<uint32_t>(rect); st.zkey = reinterpret_cast<float*>(ptr<uint32_t>(rect) + RG);
     st.tile_count = t; st.tile_flags = t + RT; st.tile_start = t + 2 * RT; st.tile_fill = t + 3 * RT + 1;
     st.counters = t + 4 * RT + 1;
+    st.pair_cursor = tiles.numel() >= 4 * RT + 13 ? t + 4 * RT + 5 : nullptr;
     st.pairs = pairs.defined() ? reinterpret_cast<uint64_t*>(pairs.data_ptr()) : nullptr;
-    st.pair_off = pi; st.blk_total = pi + RG; st.blk_base = pi + RG + RB;
+    st.pair_off = pi; st.blk_total = pi + 2 * RG; st.blk_base = pi + 2 * RG + RB;      // pair_off: (rect, first pair) per (render, Gaussian)
     st.final_T = ptr<float>(final_T); st.n_contrib = ptr<uint32_t>(n_contrib);
     return st;
 }
 
 SpfDims make_dims(int64_t S, int64_t V, int64_t G, int64_t K, int64_t sh_degree, int64_t H, int64_t W,
-                  double scale_modifier, int64_t sh_layout, bool sh_band4) {
+                  double scale_modifier, int64_t sh_layout, bool sh_band4, int64_t bin_cap = 0, int64_t pair_capacity = 0) {
     SpfDims d;
     d.S = (int32_t)S; d.V = (int32_t)V; d.G = (int32_t)G; d.K = (int32_t)K; d.sh_degree = (int32_t)sh_degree;
     d.H = (int32_t)H; d.W = (int32_t)W; d.scale_modifier = (float)scale_modifier; d.sh_layout = (int32_t)sh_layout;
     d.sh_band4 = sh_band4 ? 1 : 0;
+    d.bin_cap = (int32_t)bin_cap; d.pair_capacity = bin_cap ? pair_capacity : 0;
     return d;
 }
 
@@ -110,8 +112,8 @@ std::tuple<std::vector<Tensor>, std::vector<int64_t>> raster_forward(
     const auto i32 = means3D.options().dtype(at::kInt), f32 = means3D.options().dtype(at::kFloat);
 
     Tensor rec = at::empty({RG, 12}, f32), radii = at::empty({RG}, i32), rect = at::empty({2 * RG}, i32);
-    Tensor pair_idx = at::empty({RG + 2 * RB}, i32), tiles = at::empty({4 * RT + 8}, i32);
-    Tensor final_T = at::empty({R * P}, f32), n_contrib = at::empty({2 * R * P}, i32);
+    Tensor pair_idx = at::empty({2 * RG + 2 * RB}, i32), tiles = at::empty({4 * RT + 16}, i32);
+    Tensor final_T = at::empty({R * P}, f32), n_contrib = at::empty({R * P}, i32);
     Tensor image = at::empty({S, V, 3, H, W}, f32), depth = at::empty({S, V, 1, H, W}, f32),
            alpha = at::empty({S, V, 1, H, W}, f32);
 
@@ -145,14 +147,15 @@ std::vector<Tensor> raster_backward(
     const OptTensor& view_scale, const OptTensor& view64, const Tensor& rec, const Tensor& radii, const Tensor& rect,
     const Tensor& tiles, const Tensor& pairs, const Tensor& pair_idx, const Tensor& final_T, const Tensor& n_contrib,
     int64_t H, int64_t W, int64_t sh_degree, double scale_modifier, int64_t sh_layout, bool sh_band4, int64_t dense,
-    const OptTensor& g_image, const OptTensor& g_depth, const OptTensor& g_alpha, bool want_scales_rot, bool want_shs,
+    int64_t bin_cap, int64_t capacity, const OptTensor& g_image, const OptTensor& g_depth, const OptTensor& g_alpha, bool want_scales_rot, bool want_shs,
     bool want_colors, int64_t want_view, bool want_means2D) {
     require_device(means3D, "means3D"); require_device(rec, "rec"); require_device(pairs, "pairs");
     const c10::DeviceGuard guard(means3D.device());   // (ROCm torch reports its devices as "cuda": the generic guard)
     const int64_t S = means3D.size(0), G = means3D.size(1), V = viewmatrix.size(1), R = S * V;
     const bool have_sh = shs.has_value() && shs->defined(), have_col = colors.has_value() && colors->defined();
     const int64_t K = have_sh ? shs->size(sh_layout ? 3 : 2) : 0;
-    const SpfDims dims = make_dims(S, V, G, K, sh_degree, H, W, scale_modifier, sh_layout, sh_band4);
+    // `capacity`: gradient records (= the forward's pair capacity; with direct bins `pairs` holds the bins instead)
+    const SpfDims dims = make_dims(S, V, G, K, sh_degree, H, W, scale_modifier, sh_layout, sh_band4, bin_cap, capacity);
     const int64_t T = spf_raster_num_tiles((int32_t)H, (int32_t)W), RT = R * T, RG = R * G;
     const int64_t nblk = spf_raster_view_partial_blocks((int32_t)G), RB = R * nblk;
     const auto f32 = means3D.options().dtype(at::kFloat);
@@ -161,7 +164,6 @@ std::vector<Tensor> raster_backward(
         return g->contiguous().to(at::kFloat);
     };
     const Tensor gi = grad_in(g_image), gd = grad_in(g_depth), ga = grad_in(g_alpha);
-    const int64_t capacity = pairs.numel();
     Tensor gpair = at::empty({capacity, 10}, f32);
     Tensor d_means = at::empty_like(means3D), d_opac = at::empty_like(opacities);
     Tensor d_scales, d_rot, d_shs, d_col, d_view, vpartial, d_m2d;

@@ -233,11 +233,15 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
             if _plan_mode(max_pairs) == 1 and nothing_needs_grad and not torch.cuda.is_current_stream_capturing():
                 _raise_if_plan_failed(counters, pairs.numel())
         return ((image, depth, alpha, radii_v),
-                (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
+                (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, 0, pairs.numel()))
     K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)))
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
+    # DIRECT BINS (planned calls): every tile owns a fixed bin of `bin_cap` keys that the projection kernel fills itself
+    # -- no tile scan, no binning pass (SpfDims.bin_cap).  The bin size is the plan's list-length class.
+    bin_cap = _direct_bin_cap(max_pairs, R * T, T)
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
+                        bin_cap, _plan_numbers(max_pairs, R * T)[0] if bin_cap else 0)
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -245,12 +249,12 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     radii = torch.empty((R * G,), **i32)
     rect = torch.empty((2 * R * G,), **i32)        # packed tile rect | depth key (float bits)
     nblk = lib.spf_raster_view_partial_blocks(G)
-    pair_idx = torch.empty((R * G + 2 * R * nblk,), **i32)   # pair_off | blk_total | blk_base
-    # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | padding to a multiple of 16 bytes
-    tiles = torch.empty((4 * R * T + 8,), **i32)
+    pair_idx = torch.empty((2 * R * G + 2 * R * nblk,), **i32)   # pair_off (rect, first pair) | blk_total | blk_base
+    # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | pair cursors (8) | padding to 16 bytes
+    tiles = torch.empty((4 * R * T + 16,), **i32)
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
     final_T = torch.empty((R * P,), **f32)
-    n_contrib = torch.empty((2 * R * P,), **i32)
+    n_contrib = torch.empty((R * P,), **i32)
     image = torch.empty((S, V, 3, H, W), **f32)
     depth = torch.empty((S, V, 1, H, W), **f32)
     alpha = torch.empty((S, V, 1, H, W), **f32)
@@ -258,7 +262,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
                          _ptr(view_scale), _ptr(view64))
-    st = _state_struct(rec, radii, rect, tiles, None, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
+    pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev) if bin_cap else None
+    st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
     if camera is not None and tiles.data_ptr() % 16 == 0:
         # camera set-up and the clearing of ALL the tile bookkeeping in one kernel (the scan then needs no single-block
@@ -286,8 +291,9 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         capacity, max_tile, dense = _plan_numbers(max_pairs, R * T)
         rec_out["counters"] = counters
         _last["counters"] = counters
-    pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
-    st.pairs = _ptr(pairs)
+    if not bin_cap:
+        pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
+        st.pairs = _ptr(pairs)
     out = _lib.SpfOutputs(_ptr(image), _ptr(depth), _ptr(alpha))
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
                                              capacity, max_tile, dense, stream),
@@ -296,9 +302,21 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
             and not torch.cuda.is_current_stream_capturing():
         # check="backward" promises that a failed plan raises -- but no backward will come (evaluation under
         # no_grad, or nothing requires grad): verify now (one host sync; eval loops should use exact mode anyway)
-        _raise_if_plan_failed(counters, pairs.numel())
+        _raise_if_plan_failed(counters, capacity)
     return ((image, depth, alpha, radii.view(S, V, G)),
-            (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), dense)
+            (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, bin_cap, max(int(capacity), 1)))
+
+
+def _direct_bin_cap(max_pairs, RT: int, T: int) -> int:
+    """Bin size of a planned call that runs with DIRECT BINS (0: packed lists, the classic chain).  Needs a plan with a
+    list-length class (PairBudget.max_tile_list), the per-render tile histogram in LDS (T <= 4096) and R*T*cap keys of
+    memory within reason (<= 2^27 = 1 GiB); `SPF_DIRECT_BINS=0` pins the classic chain (A/B runs)."""
+    if max_pairs is None or os.environ.get("SPF_DIRECT_BINS", "1") == "0":
+        return 0
+    cap = max_pairs.max_tile_list if isinstance(max_pairs, PairBudget) else 0
+    if cap <= 0 or T > 4096 or RT * cap > (1 << 27):
+        return 0
+    return int(cap)
 
 
 def _plan_numbers(max_pairs, RT: int):
@@ -324,12 +342,13 @@ class _spf_errors:
 
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
+    cursor = tiles[4 * RT + 5:4 * RT + 13] if tiles.numel() >= 4 * RT + 13 else None   # (the compiled binding's buffer has none)
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
                          _ptr(tiles[2 * RT:3 * RT + 1]),
                          _ptr(tiles[3 * RT + 1:4 * RT + 1]), _ptr(tiles[RT:2 * RT]),
                          _ptr(tiles[4 * RT + 1:4 * RT + 5]), _ptr(pairs),
-                         _ptr(pair_idx[:RG]), _ptr(pair_idx[RG:RG + RB]), _ptr(pair_idx[RG + RB:]),
-                         _ptr(final_T), _ptr(n_contrib))
+                         _ptr(pair_idx[:2 * RG]), _ptr(pair_idx[2 * RG:2 * RG + RB]), _ptr(pair_idx[2 * RG + RB:]),
+                         _ptr(final_T), _ptr(n_contrib), _ptr(cursor))
 
 
 def _raise_if_plan_failed(counters: Tensor, capacity: int) -> None:
@@ -356,14 +375,14 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, view64 = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
-    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, dense, sh_layout, sh_band4 = geom
+    S, V, G, K, sh_degree, H, W, scale_modifier, capacity_mode, (dense, bin_cap, capacity), sh_layout, sh_band4 = geom
     R = S * V
     dev = means3D.device
     T = lib.spf_raster_num_tiles(H, W)
     # (a device->host read is illegal while a HIP graph is being captured: graph users check the flag themselves
     # with `pair_buffer_overflowed` after a replay)
     if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
-        _raise_if_plan_failed(tiles[4 * R * T + 1:], pairs.numel())
+        _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity)
     fast = _lib.fast()
     if fast is not None:
         wv = want["view"]
@@ -371,15 +390,16 @@ def _backward_impl(inputs, state, geom, grads_out, want):
             out = fast.raster_backward(
                 means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale,
                 view64, rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, H, W, sh_degree,
-                float(scale_modifier), int(sh_layout), bool(sh_band4), int(dense), grads_out[0], grads_out[1],
+                float(scale_modifier), int(sh_layout), bool(sh_band4), int(dense), int(bin_cap), int(capacity),
+                grads_out[0], grads_out[1],
                 grads_out[2], bool(want["scales_rot"]), bool(want["shs"]), bool(want["colors"]),
                 2 if wv == "partials" else (1 if wv else 0), bool(want["means2D"]))
         return tuple(out)
-    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout), int(sh_band4))
+    dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout), int(sh_band4), int(bin_cap),
+                        int(capacity) if bin_cap else 0)
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
-    capacity = pairs.numel()
     gpair = torch.empty((capacity, 10), **f32)     # packed gradient records: 9 (+1 with a depth gradient) floats
     d_means = torch.empty_like(means3D)
     d_opac = torch.empty_like(opacities)

@@ -23,9 +23,10 @@ def test_header_symbols_all_exported(hip_lib):
 
 def test_struct_sizes_match_header():
     from spfsplatv2_amd import _lib
-    assert C.sizeof(_lib.SpfDims) == 40
+    assert C.sizeof(_lib.SpfDims) == 56          # ten 4-byte fields + bin_cap + the 8-byte aligned pair_capacity (ABI 4)
+    assert _lib.SpfDims.pair_capacity.offset == 48 and _lib.SpfDims.bin_cap.offset == 40
     assert C.sizeof(_lib.SpfInputs) == 12 * 8
-    assert C.sizeof(_lib.SpfState) == 15 * 8
+    assert C.sizeof(_lib.SpfState) == 16 * 8
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
     assert C.sizeof(_lib.SpfGrads) == 13 * 8
 
@@ -50,6 +51,13 @@ def test_argument_validation_without_compute(hip_lib):
     d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 5000, 1.0, 0, 0)
     rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
     assert rc == -1 and b"4080" in hip_lib.spf_last_error()
+    # direct bins (ABI 4): the bins of all tiles must stay below 2^31 keys and the pair capacity must be given
+    d = _lib.SpfDims(64, 64, 8, 1, 0, 1024, 1024, 1.0, 0, 0, 16384, 1000)
+    rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
+    assert rc == -1 and b"2^31" in hip_lib.spf_last_error()
+    d = _lib.SpfDims(1, 1, 8, 1, 0, 64, 64, 1.0, 0, 0, 128, 0)
+    rc = hip_lib.spf_raster_forward_project(C.byref(d), C.byref(_lib.SpfInputs()), C.byref(_lib.SpfState()), None)
+    assert rc == -1 and b"pair_capacity" in hip_lib.spf_last_error()
     rc = hip_lib.spf_rope2d(None, None, 1, 1, 1, 64, 64, 64, 64, 1, 0, 100.0, 1.0, None)
     assert rc == -1
     rc = hip_lib.spf_rope2d(C.c_void_p(16), C.c_void_p(16), 1, 1, 1, 6, 6, 6, 6, 1, 0, 100.0, 1.0, None)

@@ -59,7 +59,7 @@ def _render(b, harm=None, bg=(0.0, 0.0, 0.0), max_pairs=None, scenes=None, leave
 @pytest.mark.parametrize("config,S,V,min_pairs_per_render,min_list",
                          [("C2", 8, 4, 60000, 257), ("C3", 2, 4, 200000, 1025), ("C5", 1, 8, 400000, 513)],
                          ids=["C4_share_8x4", "C3_2x4", "C5_1x8"])
-def test_full_batch_properties(hip_lib, config, S, V, min_pairs_per_render, min_list):
+def test_full_batch_properties(hip_lib, config, S, V, min_pairs_per_render, min_list, monkeypatch):
     import spfsplatv2_amd as spf
     b = syn.make_batch(config, S, V, seed=1000).to("cuda")
     K = b.harmonics.shape[-1]
@@ -81,9 +81,15 @@ def test_full_batch_properties(hip_lib, config, S, V, min_pairs_per_render, min_
         solo, solo_d, _ = _render(b, scenes=[s])
         assert torch.equal(solo[0], img[s]) and torch.equal(solo_d[0], dep[s]), s
     # planned mode (no host read-back) gives the same pixels as exact mode
+    # -- a planned call runs with DIRECT BINS (the projection kernel bins: no tile scan, no binning pass); the same plan
+    # on the classic chain (SPF_DIRECT_BINS=0: packed lists) must give the same pixels too
     plan = spf.plan_pair_budget(st, check="deferred")
     img_p, dep_p, _ = _render(b, max_pairs=plan)
     assert spf.last_plan_flags() == 0 and torch.equal(img_p, img) and torch.equal(dep_p, dep)
+    monkeypatch.setenv("SPF_DIRECT_BINS", "0")
+    img_c, dep_c, _ = _render(b, max_pairs=plan)
+    monkeypatch.delenv("SPF_DIRECT_BINS")
+    assert spf.last_plan_flags() == 0 and torch.equal(img_c, img) and torch.equal(dep_c, dep)
     # gradient checksum: loss = sum(image), bg = 0  =>  d loss / d DC coefficient of (g, c) = SH_C0 * sum_pixels w_g,
     # so sum_g of it / SH_C0 = sum_pixels (1 - T_final) = sum(alpha), per scene and channel -- a checksum over every
     # (Gaussian, tile) pair of binning, sort order, compositing, pair records and the per-Gaussian reduction
@@ -220,6 +226,33 @@ def test_band4_switches(hip_lib, monkeypatch):
     assert torch.equal(spf.render_views(*args, sh_band4=False)[0], base)
     monkeypatch.setenv("SPF_SH_BAND4", "1")
     assert torch.equal(spf.render_views(*args)[0], on)
+
+
+def test_direct_bins_give_the_gradients_of_the_classic_chain(hip_lib, monkeypatch):
+    """Planned calls bin inside the projection kernel (direct bins, SpfDims.bin_cap).  Same lists, same sort, same
+    compositing: every output and every gradient must equal the exact-mode call's and the classic planned chain's
+    (SPF_DIRECT_BINS=0) -- bit for bit where no dense tile's LDS float atomics are involved (s_mult = 1), to 1e-5 of
+    scale otherwise; also with several view groups per block (V = 9 views at 512x512: three groups of three)."""
+    import spfsplatv2_amd as spf
+    for cfg, S, V, kw, exact_bits in (("C2", 3, 4, {}, True), ("C5", 1, 9, dict(G=60000), True),
+                                      ("TEST", 2, 3, dict(s_mult=12.0, G=3000, K=4, image_hw=(96, 80)), False)):
+        batch = syn.make_batch(cfg, S, V, seed=77, **kw)
+        exact = util.run_product(batch)
+        plan = spf.plan_pair_budget(exact["stats"], check="deferred")
+        direct = util.run_product(batch, max_pairs=plan)
+        assert spf.plan_flags(direct["decoder"].last_call) == 0
+        monkeypatch.setenv("SPF_DIRECT_BINS", "0")
+        classic = util.run_product(batch, max_pairs=plan)
+        monkeypatch.delenv("SPF_DIRECT_BINS")
+        assert spf.plan_flags(classic["decoder"].last_call) == 0
+        for other in (exact, classic):
+            for k in ("color", "depth", "alpha", "radii"):
+                assert torch.equal(direct[k], other[k]), (cfg, k)
+            for n in util.GRAD_NAMES:
+                if exact_bits:
+                    assert torch.equal(direct["grads"][n], other["grads"][n]), (cfg, n)
+                else:
+                    assert util.rel_linf(direct["grads"][n], other["grads"][n]) < 1e-5, (cfg, n)
 
 
 # ---- failed plans ----------------------------------------------------------------------------------------------
