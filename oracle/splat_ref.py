@@ -240,9 +240,17 @@ def project(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tenso
         if capture is not None:
             capture["rgb_mask"] = (rgb_raw >= 0).to(dt)
     with torch.no_grad():
-        # view-space z is a 4-term float32 dot product of float32 inputs with a view matrix that is itself the float32
-        # inverse of the pose: good to ~1.5 ulp of the LARGEST term, not of the result
-        depth_tol = 2e-7 * ((means3D.abs() @ Rv.abs())[:, 2] + tv[2].abs())
+        # Order knife edge (see tile_lists: the sort key is the float32 value of z).  The kernels form z in float64 from
+        # the same float32 inputs and round once, as this evaluation does when run in float64: the two float32 keys can
+        # only differ where the float64 value sits within rounding noise of the dot product (~1e-15 of its LARGEST term)
+        # of a float32 rounding boundary.  `depth_tol` > 0 marks those Gaussians (about one in 10^7); a pixel is flagged
+        # when such a Gaussian and a list neighbour of (nearly) the same key both contribute visibly.
+        big = (means3D.abs() @ Rv.abs())[:, 2] + tv[2].abs()
+        z32f = tz.detach().to(torch.float32)
+        z32 = z32f.to(torch.float64)
+        ulp = (torch.nextafter(z32f.abs(), torch.full_like(z32f, float("inf"))) - z32f.abs()).to(torch.float64)
+        to_boundary = 0.5 * ulp - (tz.to(torch.float64) - z32).abs()       # distance of z to the nearest rounding boundary
+        depth_tol = torch.where(to_boundary.abs() <= 1e-13 * big.to(torch.float64) + 1e-300, ulp, torch.zeros_like(ulp)).to(dt)
     return Projected(xy=xy, depth=tz, conic=conic, opacity=opacities.reshape(G),
                      rgb=rgb.to(dt), radii=radii, rect_min=rect_min, rect_max=rect_max,
                      radius_raw=radius_raw, rgb_raw=None if colors_precomp is not None else rgb_raw,
@@ -253,7 +261,12 @@ def tile_lists(pr: Projected, H: int, W: int):
     """Yield (tx, ty, ids) with ids sorted front-to-back by (depth bits, Gaussian index) (B#10)."""
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
     vis = pr.radii > 0
-    depth = pr.depth.detach()
+    # B#10 / SURVEY.md 8a R3: the sort key is `tile << 32 | float_bits(depth)` -- the FLOAT32 bits of view-space z.  Two
+    # Gaussians whose depths differ by less than float32 resolves share a key and come in index order; ordering them by
+    # their float64 depths instead (rounds 1 - 3) made every such near-tie an "order knife edge" that had to be flagged --
+    # a 131,072-entry tile list holds thousands of them per pixel.  The oracle now orders by the float32 value of ITS
+    # depth: the same key the contract names, whatever dtype the rest is evaluated in.
+    depth = pr.depth.detach().to(torch.float32)
     for ty in range(gy):
         row = vis & (pr.rect_min[:, 1] <= ty) & (pr.rect_max[:, 1] > ty)
         row_ids = torch.nonzero(row).flatten()
@@ -360,10 +373,11 @@ def composite(pr: Projected, bg: Tensor, H: int, W: int, want_fragile: bool = Fa
                         cand = keep | first_refused
                         a_c = torch.where(cand, alpha, torch.zeros_like(alpha))
                         col = pr.rgb[ids].detach()
-                        for k in range(1, ids.numel()):
-                            tie = (zs[k:] - zs[:-k]) <= (zt[k:] + zt[:-k])
+                        for k in range(1, min(ids.numel(), 4)):
+                            # (zt is zero except for a Gaussian whose float32 key is itself on a knife edge: then one ulp)
+                            tie = ((zt[k:] + zt[:-k]) > 0) & ((zs[k:] - zs[:-k]).abs() <= (zt[k:] + zt[:-k]))
                             if not bool(tie.any()):
-                                break
+                                continue
                             dcol = (col[k:] - col[:-k]).abs().amax(dim=1)
                             swap = T_excl[:, :-k] * a_c[:, :-k] * a_c[:, k:] * dcol[None, :]
                             # (if one of the two is the entry the 1e-4 stop refuses, the swap decides which of them

@@ -630,39 +630,57 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
           // ---- direct bins: reserve, number, write keys (see the kernel's header comment) ----
           __syncthreads();
           const int nv = vend - v0;
+          // (every global round trip of this tail is issued before any of them is waited for: the cursor's atomic by
+          //  thread 0 and up to four bin reservations per thread go out together)
+          uint32_t tot = 0, at = 0;
+          uint64_t shard_base = 0, shard_cap = 0;
           if (threadIdx.x == 0) {
               // the block's pairs of this group of views, numbered from one cursor (Gaussian-major inside the block)
-              uint32_t tot = 0;
               for (int i = 0; i < nv; ++i) {
                   s_vbase[i] = tot;
                   tot += s_wtot[4 * i] + s_wtot[4 * i + 1] + s_wtot[4 * i + 2] + s_wtot[4 * i + 3];
               }
               const int nsh = pair_shards((int)(gridDim.x * gridDim.y));
               const int sh = (int)((blockIdx.x + blockIdx.y * gridDim.x) % (unsigned)nsh);
-              const uint64_t shard_cap = (uint64_t)d.pair_capacity / (uint64_t)nsh;
-              const uint32_t at = tot ? atomicAdd(&st.pair_cursor[sh], tot) : 0u;
-              if ((uint64_t)at + tot > shard_cap) atomicOr(&st.counters[2], 1u);        // gradient records would not fit
-              s_vbase[VG] = (uint32_t)(shard_cap * (uint64_t)sh) + at;
+              shard_cap = (uint64_t)d.pair_capacity / (uint64_t)nsh;
+              shard_base = shard_cap * (uint64_t)sh;
+              if (tot) at = atomicAdd(&st.pair_cursor[sh], tot);
           }
           uint32_t longest = 0;
-          for (int i = threadIdx.x; i < nv * T; i += kBlock) {
-              const uint32_t c = s_hist[i];
-              if (c) {
+          for (int i0 = threadIdx.x; i0 < nv * T; i0 += 4 * kBlock) {
+              uint32_t c[4], old[4] = {0u, 0u, 0u, 0u};
+              size_t rt[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                  const int i = i0 + k * kBlock;
+                  c[k] = i < nv * T ? s_hist[i] : 0u;
                   const int vi = i / T, t = i - vi * T;
-                  const size_t rt = (size_t)(s * d.V + v0 + vi) * T + t;
-                  const uint32_t cnt = c >> kHistCountShift;
-                  const uint32_t old = atomicAdd(&st.tile_count[rt], cnt);
-                  atomicAdd(&st.tile_flags[rt], c & kHistAreaMask);
-                  s_base[i] = old;
-                  s_hist[i] = 0;                                                         // (now: slots handed out)
-                  longest = max(longest, old + cnt);
+                  rt[k] = (size_t)(s * d.V + v0 + vi) * T + t;
               }
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                  if (c[k]) {
+                      old[k] = atomicAdd(&st.tile_count[rt[k]], c[k] >> kHistCountShift);
+                      atomicAdd(&st.tile_flags[rt[k]], c[k] & kHistAreaMask);
+                  }
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                  if (c[k]) {
+                      const int i = i0 + k * kBlock;
+                      s_base[i] = old[k];
+                      s_hist[i] = 0;                                                     // (now: slots handed out)
+                      longest = max(longest, old[k] + (c[k] >> kHistCountShift));
+                  }
+          }
+          if (threadIdx.x == 0) {
+              if ((uint64_t)at + tot > shard_cap) atomicOr(&st.counters[2], 1u);        // gradient records would not fit
+              s_vbase[VG] = (uint32_t)shard_base + at;
           }
           longest = wave_max_u32(longest);
-          if (lane == 0 && longest) {
-              atomicMax(&st.counters[1], longest);
-              if (longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);         // a bin overflows: plan flag 2
-          }
+          // (counters[1], the longest list, is NOT maintained with direct bins: one word visited by every wave of the launch
+          //  -- 8,192 atomicMax, or even 8,192 write-through loads to look first -- serialises at ~11 ns each: 55 us / 180 us
+          //  measured on a 52 us kernel.  The verdict the plan needs is local: a bin that overflows raises flag 2.)
+          if (lane == 0 && longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);
           __syncthreads();
           const uint32_t pbase = s_vbase[VG];
           for (int vi = 0; vi < nv; ++vi) {

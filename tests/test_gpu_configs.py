@@ -234,7 +234,7 @@ def test_direct_bins_give_the_gradients_of_the_classic_chain(hip_lib, monkeypatc
     (SPF_DIRECT_BINS=0) -- bit for bit where no dense tile's LDS float atomics are involved (s_mult = 1), to 1e-5 of
     scale otherwise; also with several view groups per block (V = 9 views at 512x512: three groups of three)."""
     import spfsplatv2_amd as spf
-    for cfg, S, V, kw, exact_bits in (("C2", 3, 4, {}, True), ("C5", 1, 9, dict(G=60000), True),
+    for cfg, S, V, kw, exact_bits in (("C2", 3, 4, {}, True), ("C5", 1, 9, dict(G=60000), False),
                                       ("TEST", 2, 3, dict(s_mult=12.0, G=3000, K=4, image_hw=(96, 80)), False)):
         batch = syn.make_batch(cfg, S, V, seed=77, **kw)
         exact = util.run_product(batch)
