@@ -432,6 +432,11 @@ def main():
             self.weight = (s1 - s0) / S
             self.record = spf.CallRecord()
             self.max_pairs = None
+            # --allreduce: the five Gaussian gradients are written straight into ONE flat bucket (no cat, no copy back)
+            # and summed across the ranks by one collective per micro-batch, issued asynchronously: RCCL runs it on
+            # its own stream under the next micro-batch's kernels
+            self.bucket = shard.GradBucket(*(self.leaves[n] for n in names[:5])) if args.allreduce else None
+            self.work = None
 
         def render_per_view(self):
             """The reference's decoder + render_cuda, statement for statement, on the drop-in rasterizer surface."""
@@ -493,17 +498,28 @@ def main():
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
             # (the cached dL/dloss = 1 saves autograd's fill kernel, and the fused loss recognises it: its backward is
             #  the forward's unit gradient, no launch)
-            loss.backward(gradient=spf.unit_grad(dev))
             if args.allreduce:
-                shard.allreduce_gaussian_grads([L[n].grad for n in names[:5]], skip_single=False)
+                with self.bucket:
+                    loss.backward(gradient=spf.unit_grad(dev))
+                self.work = self.bucket.all_reduce(async_op=True, skip_single=False)
+            else:
+                loss.backward(gradient=spf.unit_grad(dev))
             return loss
 
     per = S // args.streams
-    micro = [MicroBatch(i * per, (i + 1) * per) for i in range(args.streams)]
+    if args.allreduce and S > 1:
+        # one micro-batch per scene on the one stream: scene i's all-reduce overlaps scene i+1's forward and backward
+        micro = [MicroBatch(i, i + 1) for i in range(S)]
+    else:
+        micro = [MicroBatch(i * per, (i + 1) * per) for i in range(args.streams)]
 
     def step():
         for m in micro:
             m.step()
+        for m in micro:
+            if m.work is not None:
+                m.work.wait()           # (stream-level wait: the current stream waits for the collective, the host does not)
+                m.work = None
 
     def barrier():
         if launched:
@@ -670,7 +686,9 @@ def main():
                        "api": ("per-view: the reference's own glue (repeat + torch camera preamble + b*v sequential "
                                "GaussianRasterizer calls with .item() syncs) on the drop-in surface"
                                if args.api == "per-view" else "batched: one decoder call for all renders"),
-                       "sharding": ("views of the same scenes per rank + RCCL all-reduce of Gaussian grads"
+                       "sharding": ("views of the same scenes per rank + RCCL all-reduce of the Gaussian gradients: one flat "
+                                    "bucket per scene micro-batch, written in place by the backward kernels, reduced "
+                                    "asynchronously under the next micro-batch"
                                     if args.allreduce else "scene-first, no data-path collective")},
             "timing": {"trials": n_trials, "statistic": "median trial; each trial = exactly `steps` steps between "
                                                         "barrier+synchronize, max over ranks",

@@ -408,6 +408,9 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #ifndef SPF_PFWD_BPC
 #define SPF_PFWD_BPC 1
 #endif
+#ifndef SPF_PBWD_DEG4_BPC
+#define SPF_PBWD_DEG4_BPC 1   // (experiment: 2 caps the degree-4 backward at 256 VGPRs -- 96 of them spilled)
+#endif
 #ifndef SPF_PABL
 #define SPF_PABL 0      // profiling builds of the BACKWARD kernel only (-DSPF_PABL=5..9: gather / partials / stores / SH cut out)
 #endif
@@ -760,7 +763,7 @@ __host__ __device__ inline bool sh_stage_out(int V, int K) {
 // (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
 // the SH section -- 300+ VGPRs, one wave per SIMD; asking for two blocks per CU caps it at 256 VGPRs)
 template <int DEG, bool NATIVE>
-__global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : SPF_PBWD_BPC)) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+__global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? SPF_PBWD_DEG4_BPC : SPF_PBWD_BPC))) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
     (void)capacity;
     const int g = blockIdx.x * kBlock + threadIdx.x;

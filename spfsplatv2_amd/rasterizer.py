@@ -383,7 +383,9 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     # with `pair_buffer_overflowed` after a replay)
     if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
         _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity)
-    fast = _lib.fast()
+    from .shard import active_bucket
+    bucket = active_bucket()
+    fast = _lib.fast() if bucket is None else None      # (a gradient bucket supplies the output buffers: ctypes path)
     if fast is not None:
         wv = want["view"]
         with _spf_errors():
@@ -401,11 +403,14 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
     gpair = torch.empty((capacity, 10), **f32)     # packed gradient records: 9 (+1 with a depth gradient) floats
-    d_means = torch.empty_like(means3D)
-    d_opac = torch.empty_like(opacities)
-    d_scales = torch.empty_like(scales) if want["scales_rot"] else None
-    d_rot = torch.empty_like(rotations) if want["scales_rot"] else None
-    d_shs = torch.empty_like(shs) if (shs is not None and want["shs"]) else None
+    def out(name, like):          # a view of the caller's flat gradient bucket (shard.GradBucket) or a fresh buffer
+        v = bucket.take(name, like) if bucket is not None else None
+        return torch.empty_like(like) if v is None else v
+    d_means = out("means", means3D)
+    d_opac = out("opacities", opacities)
+    d_scales = out("scales", scales) if want["scales_rot"] else None
+    d_rot = out("rotations", rotations) if want["scales_rot"] else None
+    d_shs = out("harmonics", shs) if (shs is not None and want["shs"]) else None
     d_col = torch.empty_like(colors) if (colors is not None and want["colors"]) else None
     # want["view"] == "partials": leave the viewmatrix gradient as per-block partial sums (the decoder chains them to
     # the poses in one kernel, spf_camera_backward_partials); returned in place of d_view

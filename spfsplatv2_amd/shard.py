@@ -12,10 +12,81 @@ flat list of independent calls (decoder_splatting_cuda.py:53-64, cuda_splatting.
 """
 from __future__ import annotations
 
-from typing import Iterable, Sequence
+import threading
+from typing import Iterable, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+_sink = threading.local()
+
+
+class GradBucket:
+    """ONE flat float32 buffer that holds the gradients of a decoder call's Gaussian tensors -- means [S,G,3], scales
+    [S,G,3], rotations [S,G,4], opacities [S,G], harmonics (any shape) -- as contiguous views, in this order.
+
+    With ``with bucket:`` around the backward pass the rasterizer's backward writes its results straight into those
+    views (rasterizer._backward_impl takes its output buffers from the active bucket instead of allocating them), the
+    leaves' ``.grad`` alias the bucket, and ``bucket.all_reduce()`` sums the whole parameter set across the ranks with
+    ONE collective on the flat buffer: no ``torch.cat`` into a fresh bucket, no copy back (what
+    ``allreduce_gaussian_grads`` costs: two extra passes over G*(11+3K)*4 bytes).  ``async_op=True`` returns the
+    work handle: issue it after one micro-batch's backward and wait after the next one's -- the collective then runs on
+    RCCL's own stream under the next micro-batch's kernels (the reference gets the same overlap from DDP's bucketed
+    hooks, src/main.py:141-145).
+    """
+
+    NAMES = ("means", "scales", "rotations", "opacities", "harmonics")
+
+    def __init__(self, means: torch.Tensor, scales: torch.Tensor, rotations: torch.Tensor, opacities: torch.Tensor,
+                 harmonics: torch.Tensor):
+        shapes = [tuple(t.shape) for t in (means, scales, rotations, opacities, harmonics)]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+        # every view starts at a multiple of 4 floats: the kernels' 16-byte stores stay aligned
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) // 4 * 4
+        self.flat = torch.empty((total,), dtype=torch.float32, device=means.device)
+        self.views = {name: self.flat[o:o + n].view(sh) for name, o, n, sh in zip(self.NAMES, offs, sizes, shapes)}
+        self._prev = None
+
+    def take(self, name: str, like: torch.Tensor) -> Optional[torch.Tensor]:
+        """The view for `name` if it fits `like` (shape, device), else None (the caller allocates as usual)."""
+        v = self.views.get(name)
+        if v is None or tuple(v.shape) != tuple(like.shape) or v.device != like.device or like.dtype != torch.float32:
+            return None
+        # (a fresh alias of the view: autograd keeps a gradient it is handed without copying only when nobody else holds
+        #  that tensor object -- the storage is the bucket's either way)
+        return v.view(v.shape)
+
+    def __enter__(self):
+        self._prev = getattr(_sink, "bucket", None)
+        _sink.bucket = self
+        return self
+
+    def __exit__(self, *exc):
+        _sink.bucket = self._prev
+        return False
+
+    def all_reduce(self, group=None, async_op: bool = False, skip_single: bool = True):
+        """In-place SUM over the ranks of everything in the bucket; returns the work handle with ``async_op=True``
+        (None when there is nothing to do)."""
+        if not dist.is_available() or not dist.is_initialized():
+            return None
+        if skip_single and dist.get_world_size(group) == 1:
+            return None
+        if self.flat.is_cuda and dist.get_backend(group) == "gloo":
+            # testing configuration only (a CPU backend under device tensors): stage through the host, synchronously
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            self.flat.copy_(host)
+            return None
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def active_bucket() -> Optional[GradBucket]:
+    """The GradBucket of the enclosing ``with`` block on this thread (what the rasterizer's backward asks for)."""
+    return getattr(_sink, "bucket", None)
 
 
 def scene_shard(n_scenes: int, rank: int, world: int) -> list[int]:

@@ -32,8 +32,9 @@ def _free_port():
     return p
 
 
-def _step(spf, b, scenes, views, weight, dev):
-    """decoder forward + LossMse + backward for the given scenes / views of batch b; everything through the product."""
+def _step(spf, b, scenes, views, weight, dev, bucketed=False):
+    """decoder forward + LossMse + backward for the given scenes / views of batch b; everything through the product.
+    `bucketed`: the backward writes the Gaussian gradients into a shard.GradBucket (returned as the sixth item)."""
     sel = lambda t: t[scenes].to(dev)
     selv = lambda t: t[scenes][:, views].to(dev)
     leaves = {n: sel(getattr(b, n)).clone().requires_grad_(True) for n in GNAMES}
@@ -44,6 +45,12 @@ def _step(spf, b, scenes, views, weight, dev):
                                            leaves["scales"], scale_invariant=True, enable_cov_grad=True,
                                            enable_sh_grad=True)
     loss = spf.mse_loss(color, selv(b.target), weight)
+    if bucketed:
+        from spfsplatv2_amd import shard
+        bucket = shard.GradBucket(*(leaves[n] for n in GNAMES))
+        with bucket:
+            loss.backward()
+        return color.detach(), depth.detach(), float(loss), {n: leaves[n].grad for n in GNAMES}, ext.grad, bucket
     loss.backward()
     return color.detach(), depth.detach(), float(loss), {n: leaves[n].grad for n in GNAMES}, ext.grad
 
@@ -84,6 +91,16 @@ def _worker(rank, world, port, q):
         _, _, _, gref, _ = _step(spf, b, scenes, everything[1], 1.0, dev)
         worst = max(float((g2[n] - gref[n]).abs().max() / gref[n].abs().max()) for n in GNAMES)
         q.put(("allreduce", rank, worst))
+        # ---- 3) the same exchange through a GradBucket: written in place by the backward kernels, ONE collective ----
+        _, _, _, g3, _, bucket = _step(spf, b, scenes, myv, len(myv) / V, dev, bucketed=True)
+        lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+        aliased = all(lo <= g3[n].data_ptr() < hi for n in GNAMES)
+        work = bucket.all_reduce(async_op=True)
+        if work is not None:
+            work.wait()
+        torch.cuda.synchronize()
+        same = all(torch.equal(g3[n], g2[n]) for n in GNAMES)
+        q.put(("bucket", rank, aliased, same))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -100,12 +117,16 @@ def test_world2_product_path_scene_shard_and_allreduce(hip_lib):
     for p in procs:
         p.join(600)
         assert p.exitcode == 0, p.exitcode
-    got = [q.get(timeout=10) for _ in range(3)]
+    got = [q.get(timeout=10) for _ in range(5)]
     sc = [g for g in got if g[0] == "scene_shard"][0]
     assert sc[1], "scene-sharded images differ from the single-process batch"
     assert sc[2] < 1e-5 and sc[3] < 1e-6, sc          # gradients (dense tiles use LDS float atomics), summed loss
     ar = sorted(g for g in got if g[0] == "allreduce")
     assert [g[1] for g in ar] == [0, 1] and all(g[2] < 1e-5 for g in ar), ar
+    # GradBucket: the leaves' gradients live INSIDE the flat buffer (no cat, no copy back) and its one all-reduce gives
+    # bit for bit what the list form gave
+    bk = sorted(g for g in got if g[0] == "bucket")
+    assert [g[1:] for g in bk] == [(0, True, True), (1, True, True)], bk
 
 
 def test_bench_gpus2_starts_two_ranks_itself(hip_lib):

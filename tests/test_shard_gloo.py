@@ -53,6 +53,37 @@ def _worker(rank, world, port, q):
         sum(_toy_render(m2, c2, cams[0, v]).pow(2).sum() for v in range(V)).backward()
         ok = torch.allclose(m.grad, m2.grad, atol=1e-5) and torch.allclose(c.grad, c2.grad, atol=1e-5)
         q.put(("allreduce", rank, bool(ok)))
+        # 3) the same exchange through a GradBucket: gradients written into views of ONE flat buffer by the backward,
+        # summed by one collective (asynchronously), no cat / copy-back -- bit-equal to the list form above
+        m3 = means[0].clone().requires_grad_(True)
+        c3 = colors[0].clone().requires_grad_(True)
+        z = torch.zeros(G, 4)
+        bucket = shard.GradBucket(m3, c3, z, z[:, 0], z[:, :0])
+
+        class _Into(torch.autograd.Function):          # stands in for the rasterizer's backward (which asks the bucket)
+            @staticmethod
+            def forward(ctx, a, b):
+                ctx.save_for_backward(a, b)
+                return a.clone(), b.clone()
+
+            @staticmethod
+            def backward(ctx, ga, gb):
+                bk = shard.active_bucket()
+                oa, ob = bk.take("means", ga), bk.take("scales", gb)
+                oa.copy_(ga); ob.copy_(gb)
+                return oa, ob
+
+        a3, b3 = _Into.apply(m3, c3)
+        loss3 = sum(_toy_render(a3, b3, cams[0, v]).pow(2).sum() for v in shard.view_shard(V, rank, world))
+        with bucket:
+            loss3.backward()
+        aliased = (m3.grad.data_ptr() == bucket.views["means"].data_ptr()
+                   and c3.grad.data_ptr() == bucket.views["scales"].data_ptr())
+        work = bucket.all_reduce(async_op=True)
+        if work is not None:
+            work.wait()
+        same = torch.equal(m3.grad, m.grad) and torch.equal(c3.grad, c.grad)
+        q.put(("bucket", rank, bool(aliased), bool(same)))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -68,9 +99,11 @@ def test_world2_gloo():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = [q.get(timeout=5) for _ in range(3)]
+    got = [q.get(timeout=5) for _ in range(5)]
     assert ("gather", True) in got
     assert ("allreduce", 0, True) in got and ("allreduce", 1, True) in got
+    # the leaves' .grad ALIAS the bucket (no copy) and the one-collective result equals the list form bit for bit
+    assert ("bucket", 0, True, True) in got and ("bucket", 1, True, True) in got
 
 
 def test_partitions_cover_everything_once():
@@ -86,3 +119,24 @@ def test_single_process_is_a_no_op():
     g = torch.ones(3)
     shard.allreduce_gaussian_grads([g])
     assert torch.equal(g, torch.ones(3))
+
+
+def test_grad_bucket_layout():
+    """Five contiguous, 16-byte aligned views of one flat buffer, in the documented order; `take` hands out aliases of
+    them only for a matching shape; nothing is active outside a `with` block."""
+    S, G, K = 2, 5, 4
+    t = [torch.zeros(S, G, 3), torch.zeros(S, G, 3), torch.zeros(S, G, 4), torch.zeros(S, G), torch.zeros(S, G, 3, K)]
+    b = shard.GradBucket(*t)
+    assert list(b.views) == ["means", "scales", "rotations", "opacities", "harmonics"]
+    assert b.flat.numel() >= S * G * (11 + 3 * K)
+    base = b.flat.data_ptr()
+    for name, like in zip(b.NAMES, t):
+        v = b.views[name]
+        assert v.shape == like.shape and v.is_contiguous() and (v.data_ptr() - base) % 16 == 0
+        a = b.take(name, like)
+        assert a is not v and a.data_ptr() == v.data_ptr()
+    assert b.take("means", torch.zeros(S, G + 1, 3)) is None
+    assert shard.active_bucket() is None
+    with b:
+        assert shard.active_bucket() is b
+    assert shard.active_bucket() is None
