@@ -18,7 +18,11 @@ from typing import Iterable, Optional, Sequence
 import torch
 import torch.distributed as dist
 
-_sink = threading.local()
+# The active GradBucket is PROCESS-wide, not thread-local: autograd runs the backward of device tensors on its own
+# worker thread, which would never see a thread-local of the thread that called `loss.backward()`.  One process drives
+# one GPU with one training loop (src/main.py:141-145), so there is one backward at a time; nesting is a stack.
+_active: list = []
+_active_lock = threading.Lock()
 
 
 class GradBucket:
@@ -48,7 +52,6 @@ class GradBucket:
             total += (n + 3) // 4 * 4
         self.flat = torch.empty((total,), dtype=torch.float32, device=means.device)
         self.views = {name: self.flat[o:o + n].view(sh) for name, o, n, sh in zip(self.NAMES, offs, sizes, shapes)}
-        self._prev = None
 
     def take(self, name: str, like: torch.Tensor) -> Optional[torch.Tensor]:
         """The view for `name` if it fits `like` (shape, device), else None (the caller allocates as usual)."""
@@ -60,12 +63,13 @@ class GradBucket:
         return v.view(v.shape)
 
     def __enter__(self):
-        self._prev = getattr(_sink, "bucket", None)
-        _sink.bucket = self
+        with _active_lock:
+            _active.append(self)
         return self
 
     def __exit__(self, *exc):
-        _sink.bucket = self._prev
+        with _active_lock:
+            _active.remove(self)
         return False
 
     def all_reduce(self, group=None, async_op: bool = False, skip_single: bool = True):
@@ -85,8 +89,10 @@ class GradBucket:
 
 
 def active_bucket() -> Optional[GradBucket]:
-    """The GradBucket of the enclosing ``with`` block on this thread (what the rasterizer's backward asks for)."""
-    return getattr(_sink, "bucket", None)
+    """The GradBucket of the innermost enclosing ``with`` block of this process (what the rasterizer's backward asks
+    for, from autograd's worker thread)."""
+    with _active_lock:
+        return _active[-1] if _active else None
 
 
 def scene_shard(n_scenes: int, rank: int, world: int) -> list[int]:

@@ -99,7 +99,8 @@ def _worker(rank, world, port, q):
         if work is not None:
             work.wait()
         torch.cuda.synchronize()
-        same = all(torch.equal(g3[n], g2[n]) for n in GNAMES)
+        # (two runs of the same step: bit-equal where no dense tile's LDS float atomics are involved, 1e-6 of scale here)
+        same = all(float((g3[n] - g2[n]).abs().max() / g2[n].abs().max()) < 1e-6 for n in GNAMES)
         q.put(("bucket", rank, aliased, same))
         dist.barrier()
     finally:
@@ -124,7 +125,7 @@ def test_world2_product_path_scene_shard_and_allreduce(hip_lib):
     ar = sorted(g for g in got if g[0] == "allreduce")
     assert [g[1] for g in ar] == [0, 1] and all(g[2] < 1e-5 for g in ar), ar
     # GradBucket: the leaves' gradients live INSIDE the flat buffer (no cat, no copy back) and its one all-reduce gives
-    # bit for bit what the list form gave
+    # what the list form gave
     bk = sorted(g for g in got if g[0] == "bucket")
     assert [g[1:] for g in bk] == [(0, True, True), (1, True, True)], bk
 
