@@ -9,10 +9,12 @@ ERR="$OUT/bench.err"
 for cfg in ${CONFIGS:-C2 REF2V C3 C5}; do
   extra=""; [ "$cfg" != "C2" ] && extra="--no-cpu-baseline"
   # the bench line itself (graph replay, default batch of the config)
-  python bench.py --config $cfg $extra > "$OUT/bench_$cfg.json" 2>> "$ERR"
+  # (C2 with default arguments is the driver's command: it carries the `secondary` object too)
+  sec="--no-secondary"; [ "$cfg" = "C2" ] && sec=""
+  python bench.py --config $cfg $extra $sec > "$OUT/bench_$cfg.json" 2>> "$ERR"
   # per-kernel durations of THE SAME command
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$cfg" -o stats -- \
-      python bench.py --config $cfg --no-cpu-baseline > "$OUT/stats_$cfg.log" 2>&1
+      python bench.py --config $cfg --no-cpu-baseline --no-secondary > "$OUT/stats_$cfg.log" 2>&1
   find "$OUT/stats_$cfg" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_$cfg.csv" \;
   # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (eager launches: counters serialise the kernels anyway)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$cfg" -o fetch -- \
@@ -30,10 +32,11 @@ done
 if [ -z "${CONFIGS:-}" ]; then
   SPF_SH_BAND4=1 python bench.py --config REF2V --no-cpu-baseline > "$OUT/bench_REF2V_band4.json" 2>> "$ERR"
   python bench.py --streams 2 --no-cpu-baseline > "$OUT/bench_C2_streams2.json" 2>> "$ERR"
-  python bench.py --eager --no-cpu-baseline > "$OUT/bench_C2_eager.json" 2>> "$ERR"
+  python bench.py --eager --no-cpu-baseline --no-secondary > "$OUT/bench_C2_eager.json" 2>> "$ERR"
   python bench.py --scenes 64 --views 4 --no-cpu-baseline > "$OUT/bench_C2_64x4.json" 2>> "$ERR"
+  SPF_DIRECT_BINS=0 python bench.py --no-cpu-baseline --no-secondary > "$OUT/bench_C2_classic_bins.json" 2>> "$ERR"
+  python bench.py --eval-latency > "$OUT/bench_eval_1x3.json" 2>> "$ERR"
   python bench.py --api per-view --no-cpu-baseline --steps 5 --warmup 2 --min-trials 5 --min-seconds 0 > "$OUT/bench_perview.json" 2>> "$ERR"
-  for c in 2 4; do SPF_CHUNKS=$c python bench.py --no-cpu-baseline > "$OUT/bench_C2_chunks$c.json" 2>> "$ERR"; done
   python tools/bench_rope.py > "$OUT/rope_bench.txt" 2>> "$ERR"; cp gpurun_out/rope_bench.json "$OUT/rope_bench.json"
 fi
 find "$OUT" -name '*.log' -size +200k -delete
