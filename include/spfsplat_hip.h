@@ -250,11 +250,8 @@ int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh
  * partial: scratch of spf_mse_partial_blocks() floats.  The sum is taken in a fixed order: results are run-to-run
  * identical.  Tensors 16-byte aligned. */
 int spf_mse_partial_blocks(void);
-/* `ticket`: NULL, or 9 uint32 that are ZERO on entry (the kernel leaves them zero; one set per stream that may run a loss
- * concurrently).  With a ticket the last block to finish adds the partials and writes the loss -- one launch; without,
- * a second one-block launch does.  Same fixed summation order, same bits. */
 int spf_mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial,
-                    float* loss, uint32_t* ticket, void* stream);
+                    float* loss, void* stream);
 int spf_mse_backward(const float* prediction, const float* image, int64_t n, float weight, const float* dL_dloss,
                      float* dL_dprediction, void* stream);
 /* The same forward that ALSO writes dL_dprediction_unit[i] = (2 * weight / n) * (prediction[i] - image[i]) -- the gradient
@@ -262,7 +259,7 @@ int spf_mse_backward(const float* prediction, const float* image, int64_t n, flo
  * after one scalar read when dL_dloss[0] is exactly 1 (what `loss.backward()` passes): the backward of the loss costs a
  * launch instead of a pass over prediction, image and gradient. */
 int spf_mse_forward_grad(const float* prediction, const float* image, int64_t n, float weight, float* partial,
-                         float* loss, float* dL_dprediction_unit, uint32_t* ticket, void* stream);
+                         float* loss, float* dL_dprediction_unit, void* stream);
 int spf_mse_scale_grad(float* dL_dprediction, int64_t n, const float* dL_dloss, void* stream);
 
 /* In-place 2-D rotary embedding.  tokens[B,N,H,D] with element strides (stride_b, stride_n, stride_h) and

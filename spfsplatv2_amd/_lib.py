@@ -68,11 +68,10 @@ SYMBOLS = {
                                                       C.c_uint64, C.c_void_p]),
     "spf_camera_backward_partials": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "spf_mse_partial_blocks": (C.c_int, []),
-    "spf_mse_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]),
+    "spf_mse_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spf_mse_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spf_mse_forward_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p]),
+                                       C.c_void_p]),
     "spf_mse_scale_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "spf_adapter_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),

@@ -21,7 +21,7 @@ hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, f
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
 int mse_partial_blocks();
-hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, float, float*, uint32_t*, hipStream_t);
+hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, float, float*, hipStream_t);
 hipError_t launch_mse_scale(float*, int64_t, const float*, hipStream_t);
 hipError_t launch_mse_bwd(const float*, const float*, int64_t, float, const float*, float*, hipStream_t);
 hipError_t launch_camera_fwd(const SpfCamera&, hipStream_t);
@@ -514,26 +514,27 @@ int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh
 
 int spf_mse_partial_blocks(void) { return spf::mse_partial_blocks(); }
 
-static int mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial, float* loss,
-                       float* unit, bool want_unit, uint32_t* ticket, void* stream_) {
-    if (!prediction || !image || !partial || !loss || (want_unit && !unit)) return fail(SPF_E_INVALID, "mse: null pointer");
+int spf_mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial,
+                    float* loss, void* stream_) {
+    if (!prediction || !image || !partial || !loss) return fail(SPF_E_INVALID, "mse: null pointer");
     if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
-    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(unit)) & 15)
-        return fail(SPF_E_INVALID, "mse: tensors must be 16-byte aligned");
-    if (reinterpret_cast<uintptr_t>(ticket) & 3) return fail(SPF_E_INVALID, "mse: ticket must be 4-byte aligned");
-    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss, want_unit ? 2.0f * weight / (float)n : 0.f,
-                                want_unit ? unit : nullptr, ticket, static_cast<hipStream_t>(stream_)));
+    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image)) & 15)
+        return fail(SPF_E_INVALID, "mse: prediction / image must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss, 0.f, nullptr,
+                                static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 
-int spf_mse_forward(const float* prediction, const float* image, int64_t n, float weight, float* partial,
-                    float* loss, uint32_t* ticket, void* stream_) {
-    return mse_forward(prediction, image, n, weight, partial, loss, nullptr, false, ticket, stream_);
-}
-
 int spf_mse_forward_grad(const float* prediction, const float* image, int64_t n, float weight, float* partial,
-                         float* loss, float* dL_dprediction_unit, uint32_t* ticket, void* stream_) {
-    return mse_forward(prediction, image, n, weight, partial, loss, dL_dprediction_unit, true, ticket, stream_);
+                         float* loss, float* dL_dprediction_unit, void* stream_) {
+    if (!prediction || !image || !partial || !loss || !dL_dprediction_unit) return fail(SPF_E_INVALID, "mse: null pointer");
+    if (n <= 0) return fail(SPF_E_INVALID, "mse: n must be positive (got %lld)", (long long)n);
+    if ((reinterpret_cast<uintptr_t>(prediction) | reinterpret_cast<uintptr_t>(image) |
+         reinterpret_cast<uintptr_t>(dL_dprediction_unit)) & 15)
+        return fail(SPF_E_INVALID, "mse: tensors must be 16-byte aligned");
+    SPF_HIP(spf::launch_mse_fwd(prediction, image, n, weight / (float)n, partial, loss, 2.0f * weight / (float)n,
+                                dL_dprediction_unit, static_cast<hipStream_t>(stream_)));
+    return SPF_OK;
 }
 
 int spf_mse_scale_grad(float* dL_dprediction, int64_t n, const float* dL_dloss, void* stream_) {

@@ -10,17 +10,10 @@ namespace spf {
 
 constexpr int kLossBlocks = 1024;
 
-// Sum of squared differences, two levels: every block writes its partial to partial[block]; the partials are then added
-// in a FIXED order (run-to-run identical) and scale * total is written -- by the LAST block to finish (`ticket` != NULL)
-// or by a one-block kernel of its own (`ticket` == NULL).
-// The last-block form (round 4) saves a launch (4.6 us + a kernel boundary on a 13 us kernel).  Round 2 had measured it
-// four times SLOWER: a device-scope release fence per block writes the whole L2 back.  No fence here: the partial leaves
-// through a write-through store (agent scope: `sc1`), the storing lane waits for it (`s_waitcnt vmcnt(0)`), then takes a
-// ticket with a relaxed agent-scope atomic; the last block reads the partials with agent-scope (`sc1`) loads, which do
-// not look at its L1 (MI355X_MICROARCH.md, "inter-workgroup visibility": `sc1` stores + drained flag + `sc1` loads).
-// One ticket word for every block would be a hot word (~11 ns per atomic, serialised: 1,024 blocks that finish together
-// = 11 us): eight shard words (block & 7) and a ninth for the eight shard winners.  `ticket`: 9 words, zero on entry,
-// left zero.
+// Sum of squared differences, two levels: every block writes its partial to partial[block]; a one-block kernel then
+// adds the partials in a FIXED order and writes scale * total -> run-to-run identical.  (A single launch with a
+// "last block finishes" ticket was measured 4x slower: the device-scope fence every block needs for it writes the L2
+// back.)
 // GRAD: the same pass also writes unit[i] = scale2 * (prediction[i] - image[i]) -- the gradient for dL/dloss = 1, which
 // is what `loss.backward()` hands over.  The backward then only has to look at the upstream scalar (spf_mse_scale_kernel):
 // 25 MB more written here, 75 MB less moved there.
@@ -28,10 +21,8 @@ template <bool GRAD>
 __global__ __launch_bounds__(kBlock) void spf_mse_fwd_kernel(const float* __restrict__ pred,
                                                              const float* __restrict__ target, int64_t n,
                                                              float* __restrict__ partial, float scale2,
-                                                             float* __restrict__ unit, uint32_t* __restrict__ ticket,
-                                                             float scale, float* __restrict__ loss) {
+                                                             float* __restrict__ unit) {
     __shared__ float s_w[kBlock / kWave];
-    __shared__ int s_last;
     const int64_t n4 = n >> 2;
     const float4* __restrict__ p4 = reinterpret_cast<const float4*>(pred);
     const float4* __restrict__ t4 = reinterpret_cast<const float4*>(target);
@@ -51,37 +42,7 @@ __global__ __launch_bounds__(kBlock) void spf_mse_fwd_kernel(const float* __rest
     const float w = wave_sum(acc);
     if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (!ticket) {
-        if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
-        return;
-    }
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&partial[blockIdx.x], (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the partial is out before the ticket is taken
-        const uint32_t grid = gridDim.x, sh = blockIdx.x & 7u;
-        const uint32_t in_shard = (grid - sh + 7u) >> 3, shards = grid < 8u ? grid : 8u;
-        int last = 0;
-        if (__hip_atomic_fetch_add(&ticket[sh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1u) {
-            __hip_atomic_store(&ticket[sh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(&ticket[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1u) {
-                __hip_atomic_store(&ticket[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- the last block: every partial is out (its owner took its ticket after the store was acknowledged) ----
-    float tot = 0.f;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += kBlock)
-        tot += __hip_atomic_load(&partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const float wt = wave_sum(tot);
-    __syncthreads();                                     // (s_w is reused)
-    if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x >> 6] = wt;
-    __syncthreads();
-    if (threadIdx.x == 0) *loss = scale * ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+    if (threadIdx.x == 0) partial[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // grad[i] *= dL/dloss, in place -- and nothing at all when dL/dloss is exactly 1 (every block leaves after one scalar
@@ -132,14 +93,12 @@ __global__ __launch_bounds__(kBlock) void spf_mse_bwd_kernel(const float* __rest
 int mse_partial_blocks() { return kLossBlocks; }
 
 hipError_t launch_mse_fwd(const float* pred, const float* target, int64_t n, float scale, float* partial,
-                          float* loss, float scale2, float* unit_grad, uint32_t* ticket, hipStream_t stream) {
+                          float* loss, float scale2, float* unit_grad, hipStream_t stream) {
     const int64_t want = ((n >> 2) + kBlock - 1) / kBlock;
     const int grid = (int)(want < 1 ? 1 : (want > kLossBlocks ? kLossBlocks : want));
-    if (unit_grad)
-        spf_mse_fwd_kernel<true><<<grid, kBlock, 0, stream>>>(pred, target, n, partial, scale2, unit_grad, ticket, scale, loss);
-    else
-        spf_mse_fwd_kernel<false><<<grid, kBlock, 0, stream>>>(pred, target, n, partial, 0.f, nullptr, ticket, scale, loss);
-    if (!ticket) spf_mse_final_kernel<<<1, kBlock, 0, stream>>>(partial, grid, scale, loss);
+    if (unit_grad) spf_mse_fwd_kernel<true><<<grid, kBlock, 0, stream>>>(pred, target, n, partial, scale2, unit_grad);
+    else spf_mse_fwd_kernel<false><<<grid, kBlock, 0, stream>>>(pred, target, n, partial, 0.f, nullptr);
+    spf_mse_final_kernel<<<1, kBlock, 0, stream>>>(partial, grid, scale, loss);
     return hipGetLastError();
 }
 

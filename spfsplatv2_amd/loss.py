@@ -49,22 +49,6 @@ def _kernel_operand(t: Tensor) -> Tensor:
 
 
 _ONES: dict = {}
-_TICKETS: dict = {}
-
-
-def _ticket(dev, stream_id: int):
-    """Nine zeroed words for the forward kernel's last-block reduction: one set per (device, stream) -- two streams may run
-    a loss at the same time -- zeroed once when first asked for, left zero by every launch.  None while a HIP graph is
-    being captured and the set does not exist yet (a zero-fill inside the capture would be replayed every time): the
-    call then takes the two-launch form."""
-    key = (dev, stream_id)
-    t = _TICKETS.get(key)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        t = _TICKETS[key] = torch.zeros(16, dtype=torch.int32, device=dev)
-        torch.cuda.current_stream(dev).synchronize()
-    return t
 
 
 def unit_grad(device) -> Tensor:
@@ -97,19 +81,16 @@ class _Mse(torch.autograd.Function):
         #  evaluation loss on a tensor that requires grad must not pay a batch-sized allocation and write)
         unit = torch.empty_like(p) if (grad_mode and ctx.needs_input_grad[0]) else None
         with torch.cuda.device(dev):
-            cur = torch.cuda.current_stream(dev)
-            stream = C.c_void_p(cur.cuda_stream)
-            tk = _ticket(dev, cur.cuda_stream)
-            tkp = None if tk is None else C.c_void_p(tk.data_ptr())
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             if unit is not None:
                 _lib.check(lib.spf_mse_forward_grad(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
                                                     float(weight), C.c_void_p(partial.data_ptr()),
-                                                    C.c_void_p(loss.data_ptr()), C.c_void_p(unit.data_ptr()), tkp, stream),
+                                                    C.c_void_p(loss.data_ptr()), C.c_void_p(unit.data_ptr()), stream),
                            "spf_mse_forward_grad")
             else:
                 _lib.check(lib.spf_mse_forward(C.c_void_p(p.data_ptr()), C.c_void_p(t.data_ptr()), p.numel(),
                                                float(weight), C.c_void_p(partial.data_ptr()),
-                                               C.c_void_p(loss.data_ptr()), tkp, stream),
+                                               C.c_void_p(loss.data_ptr()), stream),
                            "spf_mse_forward")
         ctx.save_for_backward(p, t)
         ctx.unit = unit
