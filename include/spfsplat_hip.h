@@ -199,8 +199,8 @@ int spf_raster_forward_project(const SpfDims* d, const SpfInputs* in, SpfState* 
  * per step than the calls above.
  *   spf_decoder_prepare           = spf_camera_forward AND the clearing of `zero_bytes` bytes at `zero` in ONE kernel.
  *                                   Pass ONE buffer laid out tile_count | tile_flags | tile_start (R*T+1) | tile_fill |
- *                                   counters (4) [| padding] and clear all of it (16*R*T + 20 bytes rounded up to 16;
- *                                   16-byte aligned);
+ *                                   counters (4) [| pair_cursor (8) | padding] and clear all of it (16*R*T + 20 bytes,
+ *                                   + 32 with the cursors, rounded up to 16; 16-byte aligned);
  *   spf_raster_forward_project_prepared = spf_raster_forward_project without its own clearing.  `cleared_bytes` says how
  *                                   much of that buffer (from tile_count on) the caller cleared: all of it -> the tile scan
  *                                   runs with one block per render instead of a single block; only the first 8*R*T bytes
