@@ -143,6 +143,12 @@ def main():
         r_cur = rounds(192, 1536)
         replay_cost(r_cur, lambda cc: order_hits, "cur")
         replay_cost(r_cur, lambda cc: np.arange(256), "natural")
+        # static lane orders: wave = one 8x8 pixel block / one 16x4 strip (natural) / 4x16 column strip
+        yy, xx = np.divmod(np.arange(256), 16)
+        blk8 = np.argsort(((yy // 8) * 2 + (xx // 8)) * 64 + (yy % 8) * 8 + (xx % 8), kind="stable")
+        col4 = np.argsort((xx // 4) * 64 + yy * 4 + (xx % 4), kind="stable")
+        replay_cost(r_cur, lambda cc: blk8, "block8x8")
+        replay_cost(r_cur, lambda cc: col4, "col4x16")
         replay_cost(r_cur, lambda cc: np.argsort(-cc, kind="stable"), "perround")
         # forward kernel: natural lane order, rounds of kStage entries front to back (no pool)
         for KS in (256, 384, 512):
