@@ -862,13 +862,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         uint32_t gid = 0, pslot = 0;
         int xl = 0, yl = 0, bw = 0, bh = 0;
         if (have) {
-#ifdef SPF_CHECK
-            if (hi > n || (uint64_t)beg + n > capacity) { printf("CHK stage: r %d tile %d tid %d hi %u n %u beg %u cap %llu bmax %u\n", r, tile, tid, hi, n, beg, (unsigned long long)capacity, bmax); return; }
-#endif
             gid = (uint32_t)pairs[beg + (hi - 1u - (uint32_t)tid)];
-#ifdef SPF_CHECK
-            if (gid >= (uint32_t)G) { printf("CHK gid: r %d tile %d tid %d hi %u n %u gid %u\n", r, tile, tid, hi, n, gid); return; }
-#endif
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             a = rp[0]; b = rp[1]; cc = rp[2];
             // (the pair's slot hangs off two more gathers -- rect, pair_off: issued here, next to the record's, they
@@ -1055,9 +1049,6 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
             const v2f Tt = __builtin_elementwise_fma(v0, v2f{M0, M0}, L + L);
             const float Sxx = fmaf(v0.x, Tt.x, Qx.x), Syy = fmaf(v0.y, Tt.y, Qyy);
             const float Sxy = fmaf(v0.x, fmaf(v0.y, M0, L.y), fmaf(v0.y, L.x, Qx.y));
-#ifdef SPF_CHECK
-            if (pair_slot(gid) >= capacity) { printf("CHK slot: r %d tile %d tid %d gid %u slot %u cap %llu hi %u cnt %d\n", r, tile, tid, gid, pair_slot(gid), (unsigned long long)capacity, hi, cnt); return; }
-#endif
             const uint32_t my_slot = DEPTH_GRAD ? pair_slot(gid) : __float_as_uint(s_p1[tid].w);
             store_grec<DEPTH_GRAD>(gpair, my_slot, -o * S1.x, -o * S1.y, 0.5f * o * Sxx, o * Sxy, 0.5f * o * Syy,
                                    M0, c01.x, c01.y, c2s.x, cd);
