@@ -1,4 +1,5 @@
-"""development: per-stage HIP-event times of the default bench step (no planning, results may be garbage in ablation builds)
+"""development: per-stage HIP-event times of the default bench step (planned from the first call like bench.py, so the
+direct bins are used; results may be garbage in ablation builds -- the plan's flags are not looked at)
     SPF_LIB_DIR=_C_xyz python tools/stage_times.py [config] [scenes] [views]"""
 import sys
 from pathlib import Path
@@ -14,6 +15,8 @@ dev = torch.device("cuda:0")
 b = syn.make_batch(cfg, S, V, seed=1000).to(dev)
 leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")}
 bg = torch.zeros(3, device=dev)
+rec = spf.CallRecord()
+plan = None
 
 
 def step():
@@ -21,10 +24,14 @@ def step():
         t.grad = None
     color, _, _ = spf.render_views(leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape, bg, leaves["means"],
                                    leaves["harmonics"], leaves["opacities"], leaves["rotations"], leaves["scales"],
-                                   scale_invariant=True, enable_cov_grad=True, enable_sh_grad=True)
+                                   scale_invariant=True, enable_cov_grad=True, enable_sh_grad=True, record=rec,
+                                   max_pairs=plan)
     spf.mse_loss(color, b.target).backward()
 
 
+step()
+torch.cuda.synchronize()
+plan = spf.plan_pair_budget(rec, slack=1.25, check="deferred")
 for _ in range(3):
     step()
 torch.cuda.synchronize()
