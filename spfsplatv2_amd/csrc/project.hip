@@ -429,6 +429,15 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // numbers its (Gaussian, tile) pairs from a sharded global cursor, and every thread writes its keys
 // (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
+#ifdef SPF_PHASE_CLOCKS
+// profiling build only: 100 MHz wall-clock stamps of every block's wave 0 (start | view loop done | barrier passed |
+// reservations back | second barrier passed | keys written), one 8-word slot per block, plain stores
+constexpr int kPfBlocks = 16384;
+__device__ unsigned long long g_pf_stamp[kPfBlocks * 8];
+#define PF_STAMP(i) do { if (threadIdx.x == 0) { const unsigned b_ = blockIdx.x + blockIdx.y * gridDim.x; if (b_ < kPfBlocks) g_pf_stamp[b_ * 8 + (i)] = (unsigned long long)wall_clock64(); } } while (0)
+#else
+#define PF_STAMP(i) do { } while (0)
+#endif
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
@@ -465,6 +474,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         scale_columns(R, sx, sy, sz, N0);
     }
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
+    PF_STAMP(0);
     if (lds_hist) {
         for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
@@ -631,7 +641,9 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
       }
       if (direct) {
           // ---- direct bins: reserve, number, write keys (see the kernel's header comment) ----
+          PF_STAMP(1);
           __syncthreads();
+          PF_STAMP(2);
           const int nv = vend - v0;
           // (every global round trip of this tail is issued before any of them is waited for: the cursor's atomic by
           //  thread 0 and up to four bin reservations per thread go out together)
@@ -680,11 +692,13 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
               s_vbase[VG] = (uint32_t)shard_base + at;
           }
           longest = wave_max_u32(longest);
+          PF_STAMP(3);
           // (counters[1], the longest list, is NOT maintained with direct bins: one word visited by every wave of the launch
           //  -- 8,192 atomicMax, or even 8,192 write-through loads to look first -- serialises at ~11 ns each: 55 us / 180 us
           //  measured on a 52 us kernel.  The verdict the plan needs is local: a bin that overflows raises flag 2.)
           if (lane == 0 && longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);
           __syncthreads();
+          PF_STAMP(4);
           const uint32_t pbase = s_vbase[VG];
           for (int vi = 0; vi < nv; ++vi) {
               const int r = s * d.V + v0 + vi;
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                           if (pos < (uint32_t)d.bin_cap) bins[(size_t)t * d.bin_cap + pos] = key;
                       }
           }
+          PF_STAMP(5);
           if (vend < d.V) {
               __syncthreads();
               for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
@@ -1246,3 +1261,12 @@ hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfSt
 #undef SPF_DISPATCH_DEG
 
 }  // namespace spf
+
+#ifdef SPF_PHASE_CLOCKS
+// out[nblocks * 8]: the stamps of the last forward projection launch (profiling build only)
+extern "C" int spf_debug_pf_stamps(unsigned long long* out, int nblocks) {
+    (void)hipDeviceSynchronize();
+    if (nblocks > spf::kPfBlocks) nblocks = spf::kPfBlocks;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(spf::g_pf_stamp), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -158,6 +158,15 @@ def main():
                 for w in range(4):
                     itf += int(cc[w * 64:(w + 1) * 64].max())
             add(f"fwd{KS}_B", itf); add(f"fwd{KS}_rounds", (bmax + KS - 1) // KS)
+        # forward, balanced rounds: ceil(n / 256) rounds of equal size instead of 256 + 256 + ... + rest
+        nr = (bmax + 255) // 256
+        per = (bmax + nr - 1) // nr
+        itf = 0
+        for lo in range(0, bmax, per):
+            cc = candb[lo:lo + per].sum(0)
+            for w in range(4):
+                itf += int(cc[w * 64:(w + 1) * 64].max())
+        add("fwd256bal_B", itf)
         r_big = rounds(1 << 30, 1 << 30)
         replay_cost(r_big, lambda cc: order_hits, "whole_hits")
         replay_cost(r_big, lambda cc: np.argsort(-cc, kind="stable"), "whole_cand")
