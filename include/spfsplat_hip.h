@@ -108,8 +108,13 @@ typedef struct SpfState {
     float* zkey;           /* [R*G]     view-space depth again, compact (the binning pass reads 8 B per Gaussian
                                         instead of pulling the 48-byte record through the cache) */
     uint32_t* tile_count;  /* [R*T]     Gaussians per tile */
-    uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D (unused with direct bins) */
-    uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass */
+    uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D.  Direct bins: scratch -- when tile_start |
+                            *            tile_fill are ONE 8-byte aligned piece (tile_fill == tile_start + R*T + 1, as in the
+                            *            one-buffer layout below) and the call has >= 2,048 tiles, the library keeps the
+                            *            composite kernels' launch order there: [R*T][2] = (tile | dense << 31, list length),
+                            *            longest lists first, written by spf_raster_forward_render and read again by
+                            *            spf_raster_backward -- leave it alone between the two */
+    uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass (direct bins: see tile_start) */
     uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
                                         area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
                                         "rows" render kernels, the others the sparse "lists" kernels */

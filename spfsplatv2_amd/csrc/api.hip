@@ -12,11 +12,11 @@ hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&,
 hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, uint32_t, hipStream_t);
-hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, const uint2*, hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
-                             uint32_t, hipStream_t);
+                             uint32_t, bool, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
-                             uint64_t, hipStream_t);
+                             uint64_t, bool, hipStream_t);
 hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
@@ -369,6 +369,12 @@ int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, in
     return SPF_OK;
 }
 
+// SPF_TILE_ORDER=0: the composite lists kernels take their tiles in image order also with direct bins (experiments)
+static bool tile_order_enabled() {
+    const char* e = getenv("SPF_TILE_ORDER");       // (read per call: the tests flip it; a backward follows its forward's)
+    return !(e && e[0] == '0');
+}
+
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out, uint64_t capacity,
                               uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream_) {
     int rc = check_dims(d);
@@ -389,14 +395,17 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
         // is the number of gradient records here; the bins are memory-safe by construction.
         if (max_tile_hint != 0u && (uint32_t)d->bin_cap > max_tile_hint) max_tile_hint = (uint32_t)d->bin_cap;
         const spf::TileLists tl = spf::tile_lists(*st, *d);
+        const bool ordered = tile_order_enabled();
         {
             StageScope t(SPF_STAGE_SORT, stream);
+            // (with `ordered`, eight blocks of the sort's first kernel also write the composite lists kernels' launch order:
+            //  long lists first, see tile_order_ptr)
             SPF_HIP(spf::launch_tile_sort(*st, tl, RT, RT, ~0ull, max_tile_hint ? max_tile_hint : (uint32_t)d->bin_cap,
-                                          dense_tiles_hint, stream));
+                                          dense_tiles_hint, ordered ? spf::tile_order_ptr(*st, *d, RT) : nullptr, stream));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, stream);
-            SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, ~0ull, T, tiles_x, dense_tiles_hint, stream));
+            SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, ~0ull, T, tiles_x, dense_tiles_hint, ordered, stream));
         }
         return SPF_OK;
     }
@@ -422,11 +431,11 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
         {
             StageScope t(SPF_STAGE_SORT, cs);
             SPF_HIP(spf::launch_tile_sort(ch.st, spf::tile_lists(ch.st, ch.d), rt, RT, capacity, max_tile_hint,
-                                          dense_tiles_hint, cs));
+                                          dense_tiles_hint, /*order*/ nullptr, cs));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, cs);
-            SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, dh, cs));
+            SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, dh, false, cs));
         }
         return SPF_OK;
     };
@@ -472,7 +481,8 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         if (c == 1) SPF_HIP(hipStreamWaitEvent(cs, lanes->stagger, 0));     // second lane: one kernel behind the first
         {
             StageScope t(SPF_STAGE_RENDER_BWD, cs);
-            SPF_HIP(spf::launch_render_bwd(ch.d, ch.in, ch.st, ch.g, T, tiles_x, dh, capacity, cs));
+            SPF_HIP(spf::launch_render_bwd(ch.d, ch.in, ch.st, ch.g, T, tiles_x, dh, capacity,
+                                           d->bin_cap > 0 && C == 1 && tile_order_enabled(), cs));
         }
         if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));
         {

@@ -391,6 +391,52 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
     }
 }
 
+// ---- launch order of the composite lists kernels (direct bins; see tile_order_ptr in spf_common.h) --------------------
+// Block x (of eight) sorts the tiles [x * per, (x + 1) * per), per = RT / 8 -- the range xcd_remap gives XCD x -- by
+// list length into 64 classes, longest first (counting sort in LDS: histogram, scan, scatter; the order inside a class
+// is whatever the LDS atomics make it: nothing depends on it).  The eight blocks ride in FRONT of the tile sort's first
+// kernel (they only read the tile counters, and a launch of their own is 4 - 6 us on the critical path; forked beside
+// the sort the two cross-stream edges cost 12).
+constexpr int kOrderClasses = 64;
+constexpr int kOrderBlocks = 8;
+static_assert(kOrderClasses == kWave, "the class bases are one wave's prefix sum");
+__device__ __forceinline__ void tile_order_block(int x, const uint32_t* __restrict__ count,
+                                                 const uint32_t* __restrict__ flags, uint2* __restrict__ order, int RT,
+                                                 uint32_t cap, uint32_t dense_thr) {
+    __shared__ uint32_t s_cnt[kOrderClasses];
+    const int per = RT >> 3, lo = x * per, nthr = (int)blockDim.x;
+    if (threadIdx.x < kOrderClasses) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    // (the key is the list length.  Measured against footprint sum + 8 per entry, scaled to the range's largest: the
+    //  plain length orders better on all four bench configs -- C2 +3.8 % vs +2.5 %, C3 +5.4 / +4.3, C5 +1.5 / +0.9)
+    auto cls = [&](uint32_t n) {      // 0 = the longest lists
+        return (uint32_t)(kOrderClasses - 1) - min((uint32_t)(kOrderClasses - 1), n * (uint32_t)kOrderClasses / (cap + 1u));
+    };
+    for (int i = threadIdx.x; i < per; i += nthr) atomicAdd(&s_cnt[cls(min(count[lo + i], cap))], 1u);
+    __syncthreads();
+    uint32_t base = 0u;
+    if (threadIdx.x < kWave) {
+        const uint32_t c = s_cnt[threadIdx.x];
+        base = wave_iscan_u32(c) - c;
+    }
+    __syncthreads();
+    if (threadIdx.x < kWave) s_cnt[threadIdx.x] = base;          // (now: next free slot of the class)
+    __syncthreads();
+    for (int i = threadIdx.x; i < per; i += nthr) {
+        const int vid = lo + i;
+        const uint32_t n = min(count[vid], cap);
+        const uint32_t pos = atomicAdd(&s_cnt[cls(n)], 1u);
+        order[lo + pos] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
+    }
+}
+// (on its own: when no tile has more than one entry, the sort launches nothing)
+__global__ __launch_bounds__(kBlock) void spf_tile_order_kernel(const uint32_t* __restrict__ count,
+                                                                const uint32_t* __restrict__ flags,
+                                                                uint2* __restrict__ order, int RT, uint32_t cap,
+                                                                uint32_t dense_thr) {
+    tile_order_block((int)blockIdx.x, count, flags, order, RT, cap, dense_thr);
+}
+
 // Direct bins: nobody scans the tiles, so the sparse / dense census of a PLANNED call (dense_hint = 0: no dense tile,
 // = RT: every tile dense) is verified here, by the one sort kernel that visits every tile -- before the render kernels
 // look at the verdict.  One lane per tile; flag bit 4 as in the binning kernels' plan check.
@@ -549,9 +595,13 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(TileLists t
                                                                      uint32_t* __restrict__ counters,
                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                      uint32_t lo, int RT, uint32_t dense_hint,
-                                                                     uint32_t dense_thr) {
+                                                                     uint32_t dense_thr, uint2* __restrict__ order) {
     if (counters[0] > capacity) return;
-    const int tile = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (order && (int)blockIdx.x < kOrderBlocks) {
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        return;
+    }
+    const int tile = ((int)blockIdx.x - (order ? kOrderBlocks : 0)) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
@@ -669,12 +719,18 @@ __device__ __forceinline__ void sort_tile_in_pair(uint64_t* __restrict__ p, uint
 __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                         uint32_t* __restrict__ counters,
                                                                         uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                        uint32_t dense_hint, uint32_t dense_thr) {
+                                                                        int RT, uint32_t dense_hint, uint32_t dense_thr,
+                                                                        uint2* __restrict__ order) {
     __shared__ uint64_t s_x[8 * 2 * kWave];
     if (counters[0] > capacity) return;
+    if (order && (int)blockIdx.x < kOrderBlocks) {
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        return;
+    }
+    const int tile = (int)blockIdx.x - (order ? kOrderBlocks : 0);
     uint32_t b, n;
-    tile_range(tl, blockIdx.x, b, n);
-    census_check(tl, flags, counters, (int)blockIdx.x, n, (int)gridDim.x, dense_hint, dense_thr);
+    tile_range(tl, tile, b, n);
+    census_check(tl, flags, counters, tile, n, RT, dense_hint, dense_thr);
     if (n <= 1u || n > 1024u) return;
     if (n <= 4u * kWave) {                            // one wave is enough (and as fast): the second leaves
         if (threadIdx.x >= kWave) return;
@@ -695,19 +751,25 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
 __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                       uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                      int RT, uint32_t dense_hint, uint32_t dense_thr) {
+                                                                      int RT, uint32_t dense_hint, uint32_t dense_thr,
+                                                                      uint2* __restrict__ order) {
     __shared__ uint64_t s_x[8 * kBlock];
     if (counters[0] > capacity) return;
-    if ((int)blockIdx.x < RT) {
+    if (order && (int)blockIdx.x < kOrderBlocks) {
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        return;
+    }
+    const int blk = (int)blockIdx.x - (order ? kOrderBlocks : 0);
+    if (blk < RT) {
         uint32_t b, n;
-        tile_range(tl, blockIdx.x, b, n);
-        census_check(tl, flags, counters, (int)blockIdx.x, n, RT, dense_hint, dense_thr);
+        tile_range(tl, blk, b, n);
+        census_check(tl, flags, counters, blk, n, RT, dense_hint, dense_thr);
         if (n <= 512u || n > 2048u) return;
         if (n <= 1024u) sort_tile_in_block<4>(pairs + b, n, s_x);
         else sort_tile_in_block<8>(pairs + b, n, s_x);
         return;
     }
-    const int tile = ((int)blockIdx.x - RT) * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int tile = (blk - RT) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
@@ -856,8 +918,12 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 // `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family).
 // `tl`: where the lists are (packed, or direct bins: then the family's first kernel also verifies the planned dense-tile
 // census `dense_hint`, see census_check)
+// `order` (direct bins, or null): eight more blocks in front of the first kernel write the composite lists kernels' launch
+// order there (tile_order_block).
 hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int RT_call, uint64_t capacity,
-                            uint32_t max_tile_hint, uint32_t dense_hint, hipStream_t stream) {
+                            uint32_t max_tile_hint, uint32_t dense_hint, const uint2* order_c, hipStream_t stream) {
+    uint2* order = const_cast<uint2*>(order_c);
+    const int ob = order ? kOrderBlocks : 0;
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
     const uint32_t thr = dense_threshold();
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
@@ -868,23 +934,25 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const char* force = getenv("SPF_SORT_BLOCKS");       // (tests: "0" / "1" pin one of the two families)
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
+    if (order && !(mx > 1))      // nothing to sort: the order on its own
+        spf_tile_order_kernel<<<kOrderBlocks, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, tl.cap, thr);
     if (mixed)
-        spf_sort_tiles_mixed_kernel<<<RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
-                                                                       dense_hint, thr);
+        spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
+                                                                            RT, dense_hint, thr, order);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE");
     if (pairsk)
-        spf_sort_tiles_pair_kernel<<<RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
-                                                                 dense_hint, thr);
+        spf_sort_tiles_pair_kernel<<<ob + RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
+                                                                      dense_hint, thr, order);
     if (mx > 1 && (mx <= 512 || blocks) && !mixed && !pairsk)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
-        spf_sort_tiles_wave_kernel<8, true><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                          capacity, 1, RT, dense_hint, thr);
+        spf_sort_tiles_wave_kernel<8, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                               capacity, 1, RT, dense_hint, thr, order);
     if (mx > 512 && !blocks && !pairsk)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
-        spf_sort_tiles_wave_kernel<16, true><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                           capacity, 1, RT, dense_hint, thr);
+        spf_sort_tiles_wave_kernel<16, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                                capacity, 1, RT, dense_hint, thr, order);
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                            capacity, 1024, RT, dense_hint, thr);
+                                                                            capacity, 1024, RT, dense_hint, thr, nullptr);
     if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
     if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread

@@ -724,13 +724,28 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                   const uint32_t pos = bs[stile] + first + (uint32_t)(lane - run.head);
                   if (pos < (uint32_t)d.bin_cap) bins[(size_t)stile * d.bin_cap + pos] = key;
               }
-              if (cnt > 1u)
-                  for (int ty = y0; ty < y1; ++ty)
-                      for (int tx = x0; tx < x1; ++tx) {
-                          const int t = ty * tiles_x + tx;
-                          const uint32_t pos = bs[t] + atomicAdd(&slots[t], 1u);
-                          if (pos < (uint32_t)d.bin_cap) bins[(size_t)t * d.bin_cap + pos] = key;
+              if (cnt > 1u) {
+                  // several tiles: four slot requests in flight (one at a time, every tile pays the LDS atomic's round
+                  // trip and the wave runs as many of them as its largest rect has tiles)
+                  int tx = x0, ty = y0;
+                  for (uint32_t i0 = 0; i0 < cnt; i0 += 4) {
+                      int tt[4];
+                      uint32_t pos[4];
+#pragma unroll
+                      for (int k = 0; k < 4; ++k) {
+                          tt[k] = ty * tiles_x + tx;
+                          pos[k] = (uint32_t)d.bin_cap;
+                          if (i0 + k < cnt) pos[k] = atomicAdd(&slots[tt[k]], 1u);
+                          if (++tx == x1) { tx = x0; ++ty; }
                       }
+#pragma unroll
+                      for (int k = 0; k < 4; ++k)
+                          if (i0 + k < cnt) {
+                              pos[k] += bs[tt[k]];
+                              if (pos[k] < (uint32_t)d.bin_cap) bins[(size_t)tt[k] * d.bin_cap + pos[k]] = key;
+                          }
+                  }
+              }
           }
           PF_STAMP(5);
           if (vend < d.V) {

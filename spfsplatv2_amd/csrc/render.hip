@@ -268,6 +268,12 @@ static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-thr
 typedef float v2f __attribute__((ext_vector_type(2)));
 #ifdef SPF_PHASE_CLOCKS
 __device__ unsigned long long g_cand_count[2];      // forward lists kernel: candidates (bits set) of live pixels, hits
+// 100 MHz wall-clock stamps (start, end) of every block of the last backward lists launch, plain stores
+constexpr int kStampBlocks = 32768;
+__device__ unsigned long long g_blk_stamp[kStampBlocks][2];
+#define BLK_STAMP(e) do { if (threadIdx.x == 0 && blockIdx.x < spf::kStampBlocks) spf::g_blk_stamp[blockIdx.x][e] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define BLK_STAMP(e) do { } while (0)
 #endif
 
 constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
@@ -367,8 +373,10 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
 
     (void)capacity;
     if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    if (vid >= RT) return;
+    int vid;
+    uint32_t beg, n;
+    bool dense_tile;
+    if (!lists_tile(tl, tile_flags, dense_thr, RT, vid, beg, n, dense_tile)) return;
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x;
@@ -380,9 +388,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const int pid = ly * kTile + lx;            // this thread's pixel inside the tile (row-major): its candidate column
     const int px = X0 + lx, py = Y0 + ly;
     const bool inside = px < W && py < H;
-    uint32_t beg, n;
-    tile_range(tl, (size_t)r * T + tile, beg, n);
-    if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    if (dense_tile) return;                                                          // dense tiles: rows kernel
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
@@ -783,17 +789,19 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     __shared__ uint32_t s_wacc[4];                  // per-wave scratch (accepted-entry counts)
     __shared__ uint32_t s_wmax[4];                  // per-wave last contributor (read once, before the rounds)
 
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    if (vid >= RT) return;
+    int vid;
+    uint32_t beg, n;
+    bool dense_tile;
+    if (!lists_tile(tl, tile_flags, dense_thr, RT, vid, beg, n, dense_tile)) return;
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = tx * kTile, Y0 = ty * kTile;
-    uint32_t beg, n;
-    tile_range(tl, (size_t)r * T + tile, beg, n);
     if (n == 0) return;
-    if (tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;        // dense tiles: rows kernel
+    if (dense_tile) return;                                                          // dense tiles: rows kernel
     PHASE_INIT();
+    BLK_STAMP(0);
+    BLK_STAMP(1);
     if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
     // ---- per-pixel state: thread <-> pixel in the natural order ----
@@ -1058,6 +1066,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         PHASE_MARK(5);
     }
     PHASE_FLUSH();
+    BLK_STAMP(1);
 }
 
 #ifdef SPF_ABLATE
@@ -1067,6 +1076,12 @@ extern "C" int spf_debug_set_ablate(int v) {
 }
 #endif
 #ifdef SPF_PHASE_CLOCKS
+// out[nblocks][2]: (start, end) stamps of the blocks of the last backward lists launch
+extern "C" int spf_debug_block_stamps(unsigned long long* out, int nblocks) {
+    (void)hipDeviceSynchronize();
+    if (nblocks > spf::kStampBlocks) nblocks = spf::kStampBlocks;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(spf::g_blk_stamp), sizeof(unsigned long long) * 2 * (size_t)nblocks) == hipSuccess ? 0 : 1;
+}
 extern "C" int spf_debug_phase_cycles(unsigned long long* out8, int reset) {
     (void)hipDeviceSynchronize();
     static unsigned long long h[spf::kPhaseWaves * 8];
@@ -1139,16 +1154,18 @@ static void join_dense(hipStream_t stream, AuxStream* a) {
 // Every tile is rendered by exactly one of the two kernels (decided per tile from tile_flags / list length);
 // `dense_hint` (number of dense tiles, or SPF_UNKNOWN) only lets the host skip a launch that would find no tile.
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
-                             uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, hipStream_t stream) {
+                             uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const TileLists tl = tile_lists(st, d);
+    TileLists tlo = tl;                           // (the lists kernel only: the rows kernel keeps the image order)
+    if (ordered) tlo.order = tile_order_ptr(st, d, RT);
     const int grid = (RT + 7) / 8 * 8;
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
     if (sparse)
         spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
             out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT,
 #ifdef SPF_ABLATE
             dense_threshold() | ((uint32_t)g_ablate_host << 28));
@@ -1165,16 +1182,18 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
 
 template <bool DG>
 static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                                int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity,
+                                int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity, bool ordered,
                                 hipStream_t stream) {
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
     const TileLists tl = tile_lists(st, d);
+    TileLists tlo = tl;
+    if (ordered) tlo.order = tile_order_ptr(st, d, RT);
     const uint2* const pinfo = reinterpret_cast<const uint2*>(st.pair_off);
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
     if (sparse)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
+            st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
             g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
 #ifdef SPF_ABLATE
             dense_threshold() | ((uint32_t)g_ablate_host << 28),
@@ -1191,11 +1210,11 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                             int tiles_x, uint32_t dense_hint, uint64_t capacity, hipStream_t stream) {
+                             int tiles_x, uint32_t dense_hint, uint64_t capacity, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, stream);
-    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, stream);
+    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
+    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
     return hipGetLastError();
 }
 

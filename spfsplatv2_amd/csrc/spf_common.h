@@ -225,6 +225,7 @@ struct TileLists {
     const uint32_t* __restrict__ start;   // [R*T+1] (packed lists)
     const uint32_t* __restrict__ count;   // [R*T]   (direct bins)
     uint32_t cap;                         // 0: packed lists
+    const uint2* __restrict__ order;      // launch order of the composite lists kernels (see spf_tile_order_kernel), or null
 };
 __device__ __forceinline__ void tile_range(const TileLists& tl, size_t vid, uint32_t& beg, uint32_t& n) {
     if (tl.cap) {
@@ -236,7 +237,22 @@ __device__ __forceinline__ void tile_range(const TileLists& tl, size_t vid, uint
     }
 }
 inline TileLists tile_lists(const SpfState& st, const SpfDims& d) {
-    return TileLists{st.tile_start, st.tile_count, (uint32_t)(d.bin_cap > 0 ? d.bin_cap : 0)};
+    return TileLists{st.tile_start, st.tile_count, (uint32_t)(d.bin_cap > 0 ? d.bin_cap : 0), nullptr};
+}
+// Launch order (direct bins, many tiles): the composite lists kernels run one block per tile, a few rounds of blocks
+// per launch, and the launch ends when the LAST block does -- with the tiles in image order a long list that starts in
+// the last round finishes alone (measured, lists backward: the chip drains for 15 % of the launch on C2, 45 % on C3).
+// spf_tile_order_kernel sorts every XCD's contiguous range of tiles by list length, longest first, into
+// order[slot] = (tile | dense << 31, list length): block b of a lists launch takes slot xcd_remap(b) -- one 8-byte
+// scalar load that also replaces the loads of the tile's count and footprint sum.  The array lives in tile_start |
+// tile_fill, which nothing else uses with direct bins (they have to be one 8-byte aligned piece, as the decoder lays
+// them out).
+constexpr int kOrderMinTiles = 2048;
+inline const uint2* tile_order_ptr(const SpfState& st, const SpfDims& d, int RT) {
+    if (d.bin_cap <= 0 || d.bin_cap > 65536 || RT < kOrderMinTiles || (RT & 7) != 0) return nullptr;
+    if (!st.tile_start || st.tile_fill != st.tile_start + RT + 1 || (reinterpret_cast<uintptr_t>(st.tile_start) & 7) != 0)
+        return nullptr;
+    return reinterpret_cast<const uint2*>(st.tile_start);
 }
 // shards of the direct-bins pair numbering (one cursor each): blocks spread over up to 8 cursors so that the returning
 // atomics of a whole round of blocks do not queue on one address (~88 per us); few blocks -> one shard (no imbalance)
@@ -248,6 +264,25 @@ __host__ __device__ inline int pair_shards(int nblocks) { return nblocks >= 512 
 __device__ __forceinline__ int xcd_remap(int block, int grid) {
     const int per = grid >> 3;
     return (block & 7) * per + (block >> 3);
+}
+// The tile this block of a composite lists launch works on (false: none), where its list is and whether the tile
+// belongs to the dense (rows) kernel: in image order, or from the launch order.
+__device__ __forceinline__ bool lists_tile(const TileLists& tl, const uint32_t* __restrict__ tile_flags,
+                                           uint32_t dense_thr, int RT, int& vid, uint32_t& beg, uint32_t& n, bool& dense) {
+    const int slot = xcd_remap(blockIdx.x, gridDim.x);
+    if (tl.order) {
+        const uint2 o = tl.order[slot];
+        vid = (int)(o.x & 0x7fffffffu);
+        dense = (o.x >> 31) != 0u;
+        n = o.y;
+        beg = (uint32_t)vid * tl.cap;
+        return vid < RT;
+    }
+    vid = slot;
+    if (vid >= RT) return false;
+    tile_range(tl, (size_t)vid, beg, n);
+    dense = tile_is_dense(tile_flags[vid], n, dense_thr);
+    return true;
 }
 
 }  // namespace spf

@@ -255,6 +255,40 @@ def test_direct_bins_give_the_gradients_of_the_classic_chain(hip_lib, monkeypatc
                     assert util.rel_linf(direct["grads"][n], other["grads"][n]) < 1e-5, (cfg, n)
 
 
+def test_longest_first_launch_order_changes_nothing(hip_lib, monkeypatch):
+    """Planned calls of 2,048 tiles or more hand the composite lists kernels their tiles longest list first
+    (spf_common.h::tile_order_ptr; eight blocks in front of the tile sort's first kernel write the order).  Tiles are
+    independent: every output and every gradient must be bit-identical with SPF_TILE_ORDER=0 -- through each of the
+    sort kernels that can carry the order blocks (pair: many tiles; mixed: few tiles, long lists; wave: pinned by
+    SPF_SORT_SINGLE) and with dense tiles in the call."""
+    import spfsplatv2_amd as spf
+    cases = (("C2", 8, 4, {}, {}),                                                  # 8,192 tiles: pair kernel
+             ("C3", 2, 4, dict(G=120000), {}),                                      # 2,048 tiles, lists > 512: mixed kernel
+             ("C2", 3, 4, {}, {"SPF_SORT_SINGLE": "1"}),                            # wave kernels
+             ("C2", 2, 4, dict(s_mult=10.0, G=20000), {}))                          # dense tiles among them
+    for cfg, S, V, kw, env in cases:
+        batch = syn.make_batch(cfg, S, V, seed=91, **kw)
+        exact = util.run_product(batch)
+        plan = spf.plan_pair_budget(exact["stats"], check="deferred")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ordered = util.run_product(batch, max_pairs=plan)
+        assert spf.plan_flags(ordered["decoder"].last_call) == 0
+        monkeypatch.setenv("SPF_TILE_ORDER", "0")
+        plain = util.run_product(batch, max_pairs=plan)
+        monkeypatch.delenv("SPF_TILE_ORDER")
+        for k in env:
+            monkeypatch.delenv(k)
+        dense = exact["stats"]["dense_tiles"] > 0
+        for k in ("color", "depth", "alpha", "radii"):
+            assert torch.equal(ordered[k], plain[k]), (cfg, k)
+        for n in util.GRAD_NAMES:
+            if dense:                                         # (dense tiles: LDS float atomics, run-to-run ~1e-7)
+                assert util.rel_linf(ordered["grads"][n], plain["grads"][n]) < 1e-5, (cfg, n)
+            else:
+                assert torch.equal(ordered["grads"][n], plain["grads"][n]), (cfg, n)
+
+
 # ---- failed plans ----------------------------------------------------------------------------------------------
 def test_failed_plan_is_nan_everywhere_and_raises_without_backward(hip_lib):
     import spfsplatv2_amd as spf
