@@ -392,19 +392,36 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
 }
 
 // ---- launch order of the composite lists kernels (direct bins; see tile_order_ptr in spf_common.h) --------------------
-// Block x (of eight) sorts the tiles [x * per, (x + 1) * per), per = RT / 8 -- the range xcd_remap gives XCD x -- by
-// list length into 64 classes, longest first (counting sort in LDS: histogram, scan, scatter; the order inside a class
-// is whatever the LDS atomics make it: nothing depends on it).  The eight blocks ride in FRONT of the tile sort's first
+// One block per window of an XCD's range [x * per, (x + 1) * per), per = RT / 8 -- the range xcd_remap gives XCD x --
+// sorts its tiles by list length into 64 classes, longest first (counting sort in LDS: histogram, scan, scatter; the order inside a class
+// is whatever the LDS atomics make it: nothing depends on it).  These blocks ride in FRONT of the tile sort's first
 // kernel (they only read the tile counters, and a launch of their own is 4 - 6 us on the critical path; forked beside
 // the sort the two cross-stream edges cost 12).
 constexpr int kOrderClasses = 64;
-constexpr int kOrderBlocks = 8;
+constexpr int kOrderWindow = 256;        // tiles ordered together
 static_assert(kOrderClasses == kWave, "the class bases are one wave's prefix sum");
-__device__ __forceinline__ void tile_order_block(int x, const uint32_t* __restrict__ count,
+// Only the LAST window (256 tiles -- the last round or two of blocks on an XCD) of an XCD's range is ordered, the tiles
+// before it keep the image order: what the order has to fix is the END of the launch, and image order keeps the blocks
+// that run together on neighbouring tiles, whose lists share Gaussians.  Measured on C2 (lists backward, same box):
+// image order 153.9 us / 298 MB of HBM traffic per launch; the whole range of 1,024 tiles ordered 143.8 us / 456 MB;
+// every window of 256 ordered 145.9 / 339; only the last window 142.7 us / 310 MB.  (64 scenes x 4 views with whole
+// ranges of 8,192 tiles ordered: -6 %.)
+__host__ __device__ inline int order_windows(int RT) { return ((RT >> 3) + kOrderWindow - 1) / kOrderWindow; }
+__device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ flags, uint2* __restrict__ order, int RT,
                                                  uint32_t cap, uint32_t dense_thr) {
     __shared__ uint32_t s_cnt[kOrderClasses];
-    const int per = RT >> 3, lo = x * per, nthr = (int)blockDim.x;
+    const int nwin = order_windows(RT), x = id / nwin, w = id - x * nwin;
+    const int per = RT >> 3, lo = x * per + w * kOrderWindow, len = min(kOrderWindow, per - w * kOrderWindow);
+    const int nthr = (int)blockDim.x;
+    if (w + 1 < nwin) {                                            // image order
+        for (int i = threadIdx.x; i < len; i += nthr) {
+            const int vid = lo + i;
+            const uint32_t n = min(count[vid], cap);
+            order[vid] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
+        }
+        return;
+    }
     if (threadIdx.x < kOrderClasses) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     // (the key is the list length.  Measured against footprint sum + 8 per entry, scaled to the range's largest: the
@@ -412,7 +429,7 @@ __device__ __forceinline__ void tile_order_block(int x, const uint32_t* __restri
     auto cls = [&](uint32_t n) {      // 0 = the longest lists
         return (uint32_t)(kOrderClasses - 1) - min((uint32_t)(kOrderClasses - 1), n * (uint32_t)kOrderClasses / (cap + 1u));
     };
-    for (int i = threadIdx.x; i < per; i += nthr) atomicAdd(&s_cnt[cls(min(count[lo + i], cap))], 1u);
+    for (int i = threadIdx.x; i < len; i += nthr) atomicAdd(&s_cnt[cls(min(count[lo + i], cap))], 1u);
     __syncthreads();
     uint32_t base = 0u;
     if (threadIdx.x < kWave) {
@@ -422,7 +439,7 @@ __device__ __forceinline__ void tile_order_block(int x, const uint32_t* __restri
     __syncthreads();
     if (threadIdx.x < kWave) s_cnt[threadIdx.x] = base;          // (now: next free slot of the class)
     __syncthreads();
-    for (int i = threadIdx.x; i < per; i += nthr) {
+    for (int i = threadIdx.x; i < len; i += nthr) {
         const int vid = lo + i;
         const uint32_t n = min(count[vid], cap);
         const uint32_t pos = atomicAdd(&s_cnt[cls(n)], 1u);
@@ -597,11 +614,12 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(TileLists t
                                                                      uint32_t lo, int RT, uint32_t dense_hint,
                                                                      uint32_t dense_thr, uint2* __restrict__ order) {
     if (counters[0] > capacity) return;
-    if (order && (int)blockIdx.x < kOrderBlocks) {
+    const int ob = order ? 8 * order_windows(RT) : 0;
+    if ((int)blockIdx.x < ob) {
         tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
         return;
     }
-    const int tile = ((int)blockIdx.x - (order ? kOrderBlocks : 0)) * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int tile = ((int)blockIdx.x - ob) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
@@ -723,11 +741,12 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
                                                                         uint2* __restrict__ order) {
     __shared__ uint64_t s_x[8 * 2 * kWave];
     if (counters[0] > capacity) return;
-    if (order && (int)blockIdx.x < kOrderBlocks) {
+    const int ob = order ? 8 * order_windows(RT) : 0;
+    if ((int)blockIdx.x < ob) {
         tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
         return;
     }
-    const int tile = (int)blockIdx.x - (order ? kOrderBlocks : 0);
+    const int tile = (int)blockIdx.x - ob;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
     census_check(tl, flags, counters, tile, n, RT, dense_hint, dense_thr);
@@ -755,11 +774,12 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists 
                                                                       uint2* __restrict__ order) {
     __shared__ uint64_t s_x[8 * kBlock];
     if (counters[0] > capacity) return;
-    if (order && (int)blockIdx.x < kOrderBlocks) {
+    const int ob = order ? 8 * order_windows(RT) : 0;
+    if ((int)blockIdx.x < ob) {
         tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
         return;
     }
-    const int blk = (int)blockIdx.x - (order ? kOrderBlocks : 0);
+    const int blk = (int)blockIdx.x - ob;
     if (blk < RT) {
         uint32_t b, n;
         tile_range(tl, blk, b, n);
@@ -923,7 +943,7 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int RT_call, uint64_t capacity,
                             uint32_t max_tile_hint, uint32_t dense_hint, const uint2* order_c, hipStream_t stream) {
     uint2* order = const_cast<uint2*>(order_c);
-    const int ob = order ? kOrderBlocks : 0;
+    const int ob = order ? 8 * order_windows(RT) : 0;
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
     const uint32_t thr = dense_threshold();
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
@@ -935,7 +955,7 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
-        spf_tile_order_kernel<<<kOrderBlocks, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, tl.cap, thr);
+        spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, tl.cap, thr);
     if (mixed)
         spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
                                                                             RT, dense_hint, thr, order);

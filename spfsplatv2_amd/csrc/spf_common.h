@@ -242,8 +242,9 @@ inline TileLists tile_lists(const SpfState& st, const SpfDims& d) {
 // Launch order (direct bins, many tiles): the composite lists kernels run one block per tile, a few rounds of blocks
 // per launch, and the launch ends when the LAST block does -- with the tiles in image order a long list that starts in
 // the last round finishes alone (measured, lists backward: the chip drains for 15 % of the launch on C2, 45 % on C3).
-// spf_tile_order_kernel sorts every XCD's contiguous range of tiles by list length, longest first, into
-// order[slot] = (tile | dense << 31, list length): block b of a lists launch takes slot xcd_remap(b) -- one 8-byte
+// The tile sort's order blocks (binning.hip::tile_order_block) sort the END of every XCD's contiguous range of tiles by
+// list length, longest first, into order[slot] = (tile | dense << 31, list length) -- the slots before it keep the image
+// order --, and block b of a lists launch takes slot xcd_remap(b): one 8-byte
 // scalar load that also replaces the loads of the tile's count and footprint sum.  The array lives in tile_start |
 // tile_fill, which nothing else uses with direct bins (they have to be one 8-byte aligned piece, as the decoder lays
 // them out).
