@@ -289,6 +289,24 @@ def test_longest_first_launch_order_changes_nothing(hip_lib, monkeypatch):
                 assert torch.equal(ordered["grads"][n], plain["grads"][n]), (cfg, n)
 
 
+def test_ordered_planned_call_against_the_oracle(hip_lib):
+    """The path the bench runs -- a planned call on direct bins whose composite kernels take their tiles from the launch
+    order -- held against the float64 oracle itself, not only against the exact-mode call: 32 renders of 128 x 128
+    (2,048 tiles, the smallest call that gets an order), the ordinary gates."""
+    import spfsplatv2_amd as spf
+    batch = syn.make_batch("TEST", 4, 8, seed=57, s_mult=4.0, G=2500, K=4, image_hw=(128, 128))
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True)
+    exact = util.run_product(batch, pixel_mask=ref["pixel_mask"])
+    assert exact["stats"]["tiles"] == 2048
+    plan = spf.plan_pair_budget(exact["stats"], check="deferred")
+    prod = util.run_product(batch, max_pairs=plan, pixel_mask=ref["pixel_mask"])
+    assert spf.plan_flags(prod["decoder"].last_call) == 0
+    rep = util.compare(prod, ref, max_fragile_frac=0.01)
+    from tests.test_gpu_raster import _report
+    _report("ordered_planned_32x128", rep)
+    assert not rep["fails"], rep
+
+
 # ---- failed plans ----------------------------------------------------------------------------------------------
 def test_failed_plan_is_nan_everywhere_and_raises_without_backward(hip_lib):
     import spfsplatv2_amd as spf
