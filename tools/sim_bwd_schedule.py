@@ -124,20 +124,24 @@ def main():
             return out
 
         def replay_cost(rs, order_fn, tag, waves=4):
-            it = 0; itc = 0
+            it = 0; itc = 0; itm = 0
             for (lo, hi_) in rs:
                 cc = candb[lo:hi_].sum(0)                                                      # per pixel
                 order = order_fn(cc)
                 per = 256 // waves
+                wmax = 0
                 for w in range(waves):
                     lanes = cc[order[w * per:(w + 1) * per]]
                     if per > 64:                                                               # several pixels per lane
                         lanes = lanes.reshape(-1, 64).sum(0) if False else lanes
                     it += int(lanes.max())
+                    wmax = max(wmax, int(lanes.max()))
+                itm += wmax                                                                    # the round's barrier waits for the slowest wave
                 # phase C: entries hi-1-i on thread i: waves of 64 entries
                 sz = size[lo:hi_][::-1]
                 for w in range(0, len(sz), 64):
                     itc += int(sz[w:w + 64].max())
+            add(tag + "_Bslowest", itm)
             add(tag + "_B", it); add(tag + "_C", itc); add(tag + "_rounds", len(rs))
 
         r_cur = rounds(192, 1536)
@@ -148,6 +152,8 @@ def main():
         blk8 = np.argsort(((yy // 8) * 2 + (xx // 8)) * 64 + (yy % 8) * 8 + (xx % 8), kind="stable")
         col4 = np.argsort((xx // 4) * 64 + yy * 4 + (xx % 4), kind="stable")
         replay_cost(r_cur, lambda cc: blk8, "block8x8")
+        ilv = np.argsort((yy % 4) * 64 + (yy // 4) * 16 + xx, kind="stable")                   # wave w: rows w, w+4, w+8, w+12
+        replay_cost(r_cur, lambda cc: ilv, "rows_interleaved")
         replay_cost(r_cur, lambda cc: col4, "col4x16")
         replay_cost(r_cur, lambda cc: np.argsort(-cc, kind="stable"), "perround")
         # forward kernel: natural lane order, rounds of kStage entries front to back (no pool)
@@ -190,7 +196,9 @@ def main():
     print(f"{T} tiles: per tile  entries {stats['entries']/T:.0f}  candidates {stats['cands']/T:.0f}  hits {stats['hits']/T:.0f}  "
           f"slots {stats['slots']/T:.0f}   ideal replay iters/wave {stats['cands']/T/256:.1f}")
     for k in sorted(stats):
-        if k.endswith("_B") or k.endswith("_C") or k.endswith("_rounds"):
+        if k.endswith("_Bslowest"):
+            print(f"  {k:26s} {stats[k]/T:8.1f}  (slowest wave, summed over the rounds)")
+        elif k.endswith("_B") or k.endswith("_C") or k.endswith("_rounds"):
             div = 4 if k.endswith("_B") and not k.startswith("pair") else (2 if k.endswith("_B") else 1)
             print(f"  {k:18s} {stats[k]/T/div:8.1f}" + ("  (per wave)" if k.endswith("_B") else ""))
 
