@@ -46,8 +46,11 @@ for name in ("backward lists",):
     buf = (C.c_ulonglong * (2 * nblk))()
     assert lib.spf_debug_block_stamps(buf, nblk) == 0
     t = np.frombuffer(buf, dtype=np.uint64).reshape(nblk, 2).astype(np.int64)
-    t = t[t[:, 0] > 0]
-    t = t[t[:, 1] > t[:, 1].max() - 100000]          # (blocks that leave before their stamps keep an older launch's)
+    xcd = np.arange(nblk) & 7                         # (the dispatcher places block b on XCD b % 8)
+    keep = t[:, 0] > 0
+    t, xcd = t[keep], xcd[keep]
+    keep = t[:, 1] > t[:, 1].max() - 100000           # (blocks that leave before their stamps keep an older launch's)
+    t, xcd = t[keep], xcd[keep]
     t0 = t[:, 0].min()
     st, en = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0
     life = en - st
@@ -58,3 +61,5 @@ for name in ("backward lists",):
     xs = np.arange(0, span, step_us)
     print(f"  in flight every {step_us:.1f} us:", [int(((st <= x) & (en > x)).sum()) for x in xs])
     print("  last block started at %.1f us; blocks ending in the last 10 us: %d" % (st.max(), int((en > span - 10).sum())))
+    print("  per XCD: last block ends at (us)", [round(float(en[xcd == x].max()), 1) for x in range(8)],
+          " sum of block lifetimes (ms)", [round(float(life[xcd == x].sum()) / 1e3, 2) for x in range(8)])
