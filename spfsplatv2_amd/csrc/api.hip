@@ -12,7 +12,8 @@ hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&,
 hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
 hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, uint32_t, hipStream_t);
-hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, const uint2*, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, const uint2*, int,
+                            hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
                              uint32_t, bool, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
@@ -375,6 +376,13 @@ static bool tile_order_enabled() {
     return !(e && e[0] == '0');
 }
 
+// SPF_XCD_DEAL=0: every XCD keeps a contiguous range of renders whatever their number (experiments, tests; see
+// spf_common.h::xcd_map)
+static bool xcd_deal_enabled() {
+    const char* e = getenv("SPF_XCD_DEAL");
+    return !(e && e[0] == '0');
+}
+
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out, uint64_t capacity,
                               uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream_) {
     int rc = check_dims(d);
@@ -401,7 +409,8 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
             // (with `ordered`, eight blocks of the sort's first kernel also write the composite lists kernels' launch order:
             //  long lists first, see tile_order_ptr)
             SPF_HIP(spf::launch_tile_sort(*st, tl, RT, RT, ~0ull, max_tile_hint ? max_tile_hint : (uint32_t)d->bin_cap,
-                                          dense_tiles_hint, ordered ? spf::tile_order_ptr(*st, *d, RT) : nullptr, stream));
+                                          dense_tiles_hint, ordered ? spf::tile_order_ptr(*st, *d, RT) : nullptr,
+                                          xcd_deal_enabled() ? T : 0, stream));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, stream);
@@ -431,7 +440,7 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
         {
             StageScope t(SPF_STAGE_SORT, cs);
             SPF_HIP(spf::launch_tile_sort(ch.st, spf::tile_lists(ch.st, ch.d), rt, RT, capacity, max_tile_hint,
-                                          dense_tiles_hint, /*order*/ nullptr, cs));
+                                          dense_tiles_hint, /*order*/ nullptr, 0, cs));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, cs);

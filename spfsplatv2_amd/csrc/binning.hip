@@ -409,16 +409,17 @@ static_assert(kOrderClasses == kWave, "the class bases are one wave's prefix sum
 __host__ __device__ inline int order_windows(int RT) { return ((RT >> 3) + kOrderWindow - 1) / kOrderWindow; }
 __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ flags, uint2* __restrict__ order, int RT,
-                                                 uint32_t cap, uint32_t dense_thr) {
+                                                 int T, uint32_t cap, uint32_t dense_thr) {
     __shared__ uint32_t s_cnt[kOrderClasses];
     const int nwin = order_windows(RT), x = id / nwin, w = id - x * nwin;
-    const int per = RT >> 3, lo = x * per + w * kOrderWindow, len = min(kOrderWindow, per - w * kOrderWindow);
+    const XcdMap xm = xcd_map(RT, T);                               // (which tiles this XCD's slots stand for)
+    const int per = RT >> 3, j0 = w * kOrderWindow, lo = x * per + j0, len = min(kOrderWindow, per - j0);
     const int nthr = (int)blockDim.x;
     if (w + 1 < nwin) {                                            // image order
         for (int i = threadIdx.x; i < len; i += nthr) {
-            const int vid = lo + i;
+            const int vid = xcd_tile(xm, T, x, j0 + i);
             const uint32_t n = min(count[vid], cap);
-            order[vid] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
+            order[lo + i] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
         }
         return;
     }
@@ -429,7 +430,7 @@ __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restr
     auto cls = [&](uint32_t n) {      // 0 = the longest lists
         return (uint32_t)(kOrderClasses - 1) - min((uint32_t)(kOrderClasses - 1), n * (uint32_t)kOrderClasses / (cap + 1u));
     };
-    for (int i = threadIdx.x; i < len; i += nthr) atomicAdd(&s_cnt[cls(min(count[lo + i], cap))], 1u);
+    for (int i = threadIdx.x; i < len; i += nthr) atomicAdd(&s_cnt[cls(min(count[xcd_tile(xm, T, x, j0 + i)], cap))], 1u);
     __syncthreads();
     uint32_t base = 0u;
     if (threadIdx.x < kWave) {
@@ -440,7 +441,7 @@ __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restr
     if (threadIdx.x < kWave) s_cnt[threadIdx.x] = base;          // (now: next free slot of the class)
     __syncthreads();
     for (int i = threadIdx.x; i < len; i += nthr) {
-        const int vid = lo + i;
+        const int vid = xcd_tile(xm, T, x, j0 + i);
         const uint32_t n = min(count[vid], cap);
         const uint32_t pos = atomicAdd(&s_cnt[cls(n)], 1u);
         order[lo + pos] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
@@ -449,9 +450,9 @@ __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restr
 // (on its own: when no tile has more than one entry, the sort launches nothing)
 __global__ __launch_bounds__(kBlock) void spf_tile_order_kernel(const uint32_t* __restrict__ count,
                                                                 const uint32_t* __restrict__ flags,
-                                                                uint2* __restrict__ order, int RT, uint32_t cap,
+                                                                uint2* __restrict__ order, int RT, int T, uint32_t cap,
                                                                 uint32_t dense_thr) {
-    tile_order_block((int)blockIdx.x, count, flags, order, RT, cap, dense_thr);
+    tile_order_block((int)blockIdx.x, count, flags, order, RT, T, cap, dense_thr);
 }
 
 // Direct bins: nobody scans the tiles, so the sparse / dense census of a PLANNED call (dense_hint = 0: no dense tile,
@@ -612,11 +613,11 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(TileLists t
                                                                      uint32_t* __restrict__ counters,
                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                      uint32_t lo, int RT, uint32_t dense_hint,
-                                                                     uint32_t dense_thr, uint2* __restrict__ order) {
+                                                                     uint32_t dense_thr, uint2* __restrict__ order, int T) {
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
         return;
     }
     const int tile = ((int)blockIdx.x - ob) * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -738,12 +739,12 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
                                                                         uint32_t* __restrict__ counters,
                                                                         uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                         int RT, uint32_t dense_hint, uint32_t dense_thr,
-                                                                        uint2* __restrict__ order) {
+                                                                        uint2* __restrict__ order, int T) {
     __shared__ uint64_t s_x[8 * 2 * kWave];
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
         return;
     }
     const int tile = (int)blockIdx.x - ob;
@@ -771,12 +772,12 @@ __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists 
                                                                       uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                       int RT, uint32_t dense_hint, uint32_t dense_thr,
-                                                                      uint2* __restrict__ order) {
+                                                                      uint2* __restrict__ order, int T) {
     __shared__ uint64_t s_x[8 * kBlock];
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
         return;
     }
     const int blk = (int)blockIdx.x - ob;
@@ -941,7 +942,8 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 // `order` (direct bins, or null): eight more blocks in front of the first kernel write the composite lists kernels' launch
 // order there (tile_order_block).
 hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int RT_call, uint64_t capacity,
-                            uint32_t max_tile_hint, uint32_t dense_hint, const uint2* order_c, hipStream_t stream) {
+                            uint32_t max_tile_hint, uint32_t dense_hint, const uint2* order_c, int T,
+                            hipStream_t stream) {   // T: tiles per render (0: contiguous tile ranges per XCD, see xcd_map)
     uint2* order = const_cast<uint2*>(order_c);
     const int ob = order ? 8 * order_windows(RT) : 0;
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
@@ -955,24 +957,24 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
-        spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, tl.cap, thr);
+        spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr);
     if (mixed)
         spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
-                                                                            RT, dense_hint, thr, order);
+                                                                            RT, dense_hint, thr, order, T);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE");
     if (pairsk)
         spf_sort_tiles_pair_kernel<<<ob + RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
-                                                                      dense_hint, thr, order);
+                                                                      dense_hint, thr, order, T);
     if (mx > 1 && (mx <= 512 || blocks) && !mixed && !pairsk)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                               capacity, 1, RT, dense_hint, thr, order);
+                                                                               capacity, 1, RT, dense_hint, thr, order, T);
     if (mx > 512 && !blocks && !pairsk)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
         spf_sort_tiles_wave_kernel<16, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                                capacity, 1, RT, dense_hint, thr, order);
+                                                                                capacity, 1, RT, dense_hint, thr, order, T);
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                            capacity, 1024, RT, dense_hint, thr, nullptr);
+                                                                            capacity, 1024, RT, dense_hint, thr, nullptr, 0);
     if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
     if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread

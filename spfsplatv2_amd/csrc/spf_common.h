@@ -249,6 +249,33 @@ inline TileLists tile_lists(const SpfState& st, const SpfDims& d) {
 // tile_fill, which nothing else uses with direct bins (they have to be one 8-byte aligned piece, as the decoder lays
 // them out).
 constexpr int kOrderMinTiles = 2048;
+// Which tiles XCD x's blocks work on (slot (x, j), j < per = R*T / 8), before the end of the range is sorted.
+// Normally a contiguous range: XCD x takes renders [x*R/8, (x+1)*R/8) -- with several renders per XCD their differences
+// average out (C2, four views of a scene per XCD: 18.4 - 20.3 ms of block time per XCD in the lists backward).  With
+// exactly ONE render per XCD (8 renders: C5's 1 scene x 8 views, C3's 2 x 4) nothing averages: per-XCD stamps
+// (tools/block_stamps.py) showed 35 - 45 ms on C5, the XCDs finishing between 252 and 330 us.  Then STRIPS of 64 tiles
+// (whole tile rows) are dealt out instead -- strip q of render r goes to XCD (r + q) % 8: every XCD gets a different
+// part of every render.  Measured: C5 lists backward 340 -> 321 us, C3 +-0; with more renders per XCD dealing LOSES
+// (REF2V, two per XCD: 133 -> 139 us; C2 +-0), so it is not done there.
+constexpr int kXcdStrip = 64;
+struct XcdMap { int per, strip, strips_per_render, groups; bool dealt; };
+__host__ __device__ inline XcdMap xcd_map(int RT, int T) {
+    XcdMap m;
+    const int R = T > 0 ? RT / T : 0;
+    m.per = RT >> 3;
+    m.strip = T >= kXcdStrip ? kXcdStrip : (T > 0 ? T : 1);
+    m.strips_per_render = T > 0 ? T / m.strip : 1;
+    m.groups = R >> 3;
+    m.dealt = R == 8 && T % m.strip == 0;
+    return m;
+}
+__host__ __device__ inline int xcd_tile(const XcdMap& m, int T, int x, int j) {
+    if (!m.dealt) return x * m.per + j;
+    const int l = j / m.strip, i = j - l * m.strip;          // l-th strip of this XCD
+    const int q = l / m.groups, g = l - q * m.groups;
+    const int r = ((x - q) & 7) + 8 * g;
+    return r * T + q * m.strip + i;
+}
 inline const uint2* tile_order_ptr(const SpfState& st, const SpfDims& d, int RT) {
     if (d.bin_cap <= 0 || d.bin_cap > 65536 || RT < kOrderMinTiles || (RT & 7) != 0) return nullptr;
     if (!st.tile_start || st.tile_fill != st.tile_start + RT + 1 || (reinterpret_cast<uintptr_t>(st.tile_start) & 7) != 0)

@@ -260,12 +260,14 @@ def test_longest_first_launch_order_changes_nothing(hip_lib, monkeypatch):
     (spf_common.h::tile_order_ptr; eight blocks in front of the tile sort's first kernel write the order).  Tiles are
     independent: every output and every gradient must be bit-identical with SPF_TILE_ORDER=0 -- through each of the
     sort kernels that can carry the order blocks (pair: many tiles; mixed: few tiles, long lists; wave: pinned by
-    SPF_SORT_SINGLE) and with dense tiles in the call."""
+    SPF_SORT_SINGLE), with dense tiles in the call, and when the call has exactly eight renders, whose tiles are dealt
+    out to the XCDs in strips (spf_common.h::xcd_map: the C3 case here, and one 512 x 512 call of eight views)."""
     import spfsplatv2_amd as spf
     cases = (("C2", 8, 4, {}, {}),                                                  # 8,192 tiles: pair kernel
              ("C3", 2, 4, dict(G=120000), {}),                                      # 2,048 tiles, lists > 512: mixed kernel
              ("C2", 3, 4, {}, {"SPF_SORT_SINGLE": "1"}),                            # wave kernels
-             ("C2", 2, 4, dict(s_mult=10.0, G=20000), {}))                          # dense tiles among them
+             ("C2", 2, 4, dict(s_mult=10.0, G=20000), {}),                          # dense tiles among them
+             ("C5", 1, 8, dict(G=80000), {}))                                       # 8 renders of 1,024 tiles: strips dealt
     for cfg, S, V, kw, env in cases:
         batch = syn.make_batch(cfg, S, V, seed=91, **kw)
         exact = util.run_product(batch)
