@@ -183,6 +183,12 @@ const char* spf_last_error(void);
 /* Number of tiles per render and size of the vpartial scratch. */
 int spf_raster_num_tiles(int32_t H, int32_t W);
 int spf_raster_view_partial_blocks(int32_t G);
+/* Which tile (render * T + tile) block slot `slot` (< R*T / 8) of XCD `xcd` (0..7) of a composite lists launch stands for
+ * before the end of every XCD's range is sorted longest list first (planned calls on direct bins of >= 2,048 tiles, R*T
+ * a multiple of 8): a contiguous range of renders per XCD -- or, for calls of exactly eight renders, strips of 64 tiles
+ * dealt out so that no XCD is left with ONE render (strip q of render r -> XCD (r + q) % 8).  A bijection; host-side
+ * arithmetic only (documentation and tests).  -1 for arguments out of range. */
+int spf_raster_launch_slot_tile(int32_t R, int32_t T, int32_t xcd, int32_t slot);
 /* Into how many chunks of renders spf_raster_forward_render (backward = 0) / spf_raster_backward (backward = 1) split a
  * call of S scenes x V views.  1 unless the environment says SPF_CHUNKS=n: then, after the joint tile scan, the chunks
  * (whole scenes each) run as independent launch chains alternating between the caller's stream and one auxiliary stream

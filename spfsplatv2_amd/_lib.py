@@ -54,6 +54,7 @@ SYMBOLS = {
     "spf_last_error": (C.c_char_p, []),
     "spf_raster_num_tiles": (C.c_int, [C.c_int32, C.c_int32]),
     "spf_raster_view_partial_blocks": (C.c_int, [C.c_int32]),
+    "spf_raster_launch_slot_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "spf_raster_chunks": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "spf_camera_forward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p]),
     "spf_camera_backward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_void_p, C.c_void_p]),

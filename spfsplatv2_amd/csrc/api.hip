@@ -255,6 +255,12 @@ int spf_raster_num_tiles(int32_t H, int32_t W) {
     return ((W + SPF_TILE - 1) / SPF_TILE) * ((H + SPF_TILE - 1) / SPF_TILE);
 }
 int spf_raster_view_partial_blocks(int32_t G) { return (G + spf::kBlock - 1) / spf::kBlock; }
+int spf_raster_launch_slot_tile(int32_t R, int32_t T, int32_t xcd, int32_t slot) {
+    if (R < 1 || T < 1 || (int64_t)R * T > (int64_t)1 << 30 || (((int64_t)R * T) & 7) != 0) return -1;
+    const int RT = R * T;
+    if (xcd < 0 || xcd > 7 || slot < 0 || slot >= (RT >> 3)) return -1;
+    return spf::xcd_tile(spf::xcd_map(RT, T), T, xcd, slot);
+}
 int spf_raster_chunks(int32_t S, int32_t V, int32_t H, int32_t W, int32_t backward) {
     if (S < 1 || V < 1 || H < 1 || W < 1) return 1;
     int bounds[kMaxChunks + 1];

@@ -39,6 +39,27 @@ def test_host_helpers_no_gpu(hip_lib):
     assert hip_lib.spf_stage_kernel_name(5) == b"spf_render_bwd_lists_kernel"
 
 
+def test_launch_slots_cover_every_tile_once(hip_lib):
+    """The (XCD, slot) -> tile map of the composite lists launches (spf_common.h::xcd_map) is a bijection for every
+    shape -- contiguous ranges of renders per XCD, and strips dealt out when the call has exactly eight renders."""
+    for R, T in ((32, 256), (16, 256), (8, 256), (8, 1024), (8, 64), (8, 4096), (8, 200), (24, 256), (9, 256), (128, 16)):
+        RT = R * T
+        if RT % 8:
+            assert hip_lib.spf_raster_launch_slot_tile(R, T, 0, 0) == -1
+            continue
+        per = RT // 8
+        seen = set()
+        for x in range(8):
+            for j in range(per):
+                seen.add(hip_lib.spf_raster_launch_slot_tile(R, T, x, j))
+        assert seen == set(range(RT)), (R, T)
+        dealt = R == 8 and T % 64 == 0 and T > 64                 # (T == 64: one strip per render, the same map)
+        contiguous = all(hip_lib.spf_raster_launch_slot_tile(R, T, x, j) == x * per + j
+                         for x in range(8) for j in range(0, per, 61))
+        assert contiguous != dealt, (R, T, dealt, contiguous)
+    assert hip_lib.spf_raster_launch_slot_tile(8, 256, 8, 0) == -1 and hip_lib.spf_raster_launch_slot_tile(8, 256, 0, 256) == -1
+
+
 def test_argument_validation_without_compute(hip_lib):
     """Bad arguments are rejected before anything touches a device."""
     from spfsplatv2_amd import _lib
