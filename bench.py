@@ -59,6 +59,9 @@ WORKLOADS = {
     "REF2V": (16, 1),    # what the shipped 2-view model really renders: 131,072 Gaussians (two 256x256 grids), 25 SH
                          # coefficients per channel (sh_degree 4), batch 16 x 1 target view
                          # (encoder_spfsplatv2.py:240,296-321; config/experiment/spfsplatv2/re10k.yaml:36-37,48)
+    "REF10V": (3, 1),    # what the shipped 10-view model trains on: 655,360 Gaussians (ten 256x256 grids), 25 SH
+                         # coefficients, 3 scenes x 1 target view per step -- 768 tiles with lists of thousands of entries
+                         # (config/experiment/spfsplatv2/re10k_10view.yaml:36-37,48)
 }
 
 
@@ -177,6 +180,10 @@ def parse_args(argv=None):
                     help="measure the LATENCY of one decoder call at the reference's test_step shape instead of the "
                          "training step: b = 1 scene of the 2-view model (131,072 Gaussians, 25 SH coefficients), v = 3 "
                          "target views, 256x256, forward only under no_grad (src/model/model_wrapper.py:415-454)")
+    ap.add_argument("--rope", action="store_true",
+                    help="measure the RoPE-2D kernel (curope's rope_2d, SURVEY.md 8a row A9) instead of the decoder step: "
+                         "fp32 and fp16 at the reference's encoder / decoder attention shapes (48,256,16,64) and "
+                         "(32,258,12,64) on strided q views of a qkv buffer, next to the reference's two CPU paths")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -233,15 +240,19 @@ SECONDARY = (
     ("C5", ["--config", "C5"], {}),
     ("REF2V", ["--config", "REF2V"], {"SPF_SH_BAND4": "0"}),
     ("REF2V_band4", ["--config", "REF2V"], {"SPF_SH_BAND4": "1"}),
+    ("REF10V", ["--config", "REF10V"], {"SPF_SH_BAND4": "0"}),
     ("C2_streams2", ["--config", "C2", "--streams", "2"], {}),
     ("eval_1x3", ["--eval-latency"], {"SPF_SH_BAND4": "0"}),
+    ("rope2d", ["--rope"], {}),
 )
 
 
 def run_secondary(args) -> dict:
     """The other workloads under the same clock as the headline: one child run of this script each (its own process:
-    a failure cannot take the headline down, and every child gets the library state of a fresh start), >= 1 s of timed
-    GPU work per child, no CPU baseline.  Returns {name: trimmed child line + wall_s}."""
+    a failure cannot take the headline's NUMBER down, and every child gets the library state of a fresh start), >= 1 s of
+    timed GPU work per child, no CPU baseline (rope2d carries its own).  Returns {name: trimmed child line + wall_s}; a
+    child that failed leaves {"error": ...} there AND its name in `out["_failed"]`: main() prints the line and then exits
+    non-zero, so a broken secondary workload cannot pass a driver that only looks at the return code."""
     out = {}
     env0 = {k: v for k, v in os.environ.items()
             if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
@@ -252,10 +263,13 @@ def run_secondary(args) -> dict:
                *extra]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, env=dict(env0, **env_extra), capture_output=True, text=True, timeout=120)
+            r = subprocess.run(cmd, env=dict(env0, **env_extra), capture_output=True, text=True, timeout=180)
+            if r.returncode != 0:
+                raise RuntimeError(f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ''}")
             line = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception as e:                                  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300], "wall_s": round(time.perf_counter() - t0, 2)}
+            out.setdefault("_failed", []).append(name)
             log(f"secondary {name}: FAILED ({out[name]['error']})")
             continue
         keep = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better") if k in line}
@@ -265,8 +279,8 @@ def run_secondary(args) -> dict:
             rf = line["roofline"]
             keep["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "launch_ms", "achieved", "frac", "traffic",
                                                                "algorithmic_bytes_per_launch")}
-        for k in ("latency_ms", "timing"):
-            if k in line:
+        for k in ("latency_ms", "timing", "cases", "cpu_baseline", "roofline"):
+            if k in line and not (k == "roofline" and name != "rope2d"):
                 keep[k] = line[k]
         keep["wall_s"] = round(time.perf_counter() - t0, 2)
         out[name] = keep
@@ -277,20 +291,25 @@ def run_secondary(args) -> dict:
 def eval_latency(args, dev) -> dict:
     """One decoder call at the shape the reference evaluates with (`test_step`: b = 1, v = 3 target views rendered from
     the 2-view model's 131,072 Gaussians with 25 SH coefficients, forward only, src/model/model_wrapper.py:415-454):
-    wall time from the call to its result being complete, i.e. with a device synchronisation per call."""
+    wall time from the call to its result being complete, i.e. with a device synchronisation per call.  The call is the
+    reference's own: `decoder.forward(gaussians, extrinsics, intrinsics, near, far, (h, w))` on the decoder MODULE
+    (`DecoderSplattingCUDA` under the registry name "splatting_cuda") -- which, for planned calls that will not be
+    differentiated, keeps its own cache of captured HIP graphs (`planned_median`: what a caller gets without doing
+    anything; `planned_no_graph_cache_median`: the same call launched kernel by kernel; `planned_graph_replay_*`: a graph
+    captured by the CALLER around the call, as round 4 measured it)."""
     import spfsplatv2_amd as spf
-    from spfsplatv2_amd import synthetic as syn
+    from spfsplatv2_amd import decoder as dec, synthetic as syn
     b = syn.make_batch("REF2V", 1, 3, seed=4242).to(dev)
     h, w = b.image_shape
     G, K = b.means.shape[1], b.harmonics.shape[-1]
-    bg = torch.zeros(3, device=dev)
-    rec = spf.CallRecord()
+    decoder = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
+                                                          make_scale_invariant=True, enable_cov_grad=False,
+                                                          enable_sh_grad=False)).to(dev)
+    gaussians = dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
 
-    def call(max_pairs):
+    def call():
         with torch.no_grad():
-            return spf.render_views(b.extrinsics, b.intrinsics, b.near, b.far, (h, w), bg, b.means, b.harmonics,
-                                    b.opacities, b.rotations, b.scales, scale_invariant=True, max_pairs=max_pairs,
-                                    record=rec)
+            return decoder.forward(gaussians, b.extrinsics, b.intrinsics, b.near, b.far, (h, w))
 
     def latency(fn, n):
         ts = []
@@ -305,46 +324,170 @@ def eval_latency(args, dev) -> dict:
 
     n = max(args.steps * 10, 100)
     for _ in range(max(args.warmup, 3)):
-        call(None)
-    exact_med, exact_min = latency(lambda: call(None), n)
-    plan = spf.plan_pair_budget(rec, slack=1.25, check="deferred")
+        call()
+    exact_med, exact_min = latency(call, n)
+    reference_image = call().color.clone()
+    decoder.max_pairs = spf.plan_pair_budget(decoder.last_call, slack=1.25, check="deferred")
+    decoder.eval_graphs = False
     for _ in range(max(args.warmup, 3)):
-        call(plan)
-    plan_med, plan_min = latency(lambda: call(plan), n)
+        call()
+    nograph_med, nograph_min = latency(call, n)
     graph_med = graph_min = None
     try:
         g_ = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_):
-            call(plan)
+            call()
         for _ in range(3):
             g_.replay()
         graph_med, graph_min = latency(g_.replay, n)
+        del g_
     except Exception as e:                                      # noqa: BLE001
         log(f"eval latency: graph capture failed ({type(e).__name__}: {e})")
+    decoder.eval_graphs = True
+    for _ in range(max(args.warmup, 3)):
+        call()
+    if not decoder._graphs:
+        raise RuntimeError("the decoder module did not capture the evaluation call")
+    plan_med, plan_min = latency(call, n)
+    if not torch.equal(call().color, reference_image):
+        raise RuntimeError("the replayed evaluation call does not reproduce the exact-mode image")
     # back-to-back planned calls (no wait between them): what an evaluation loop that only reads the images later sees
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     m = 0
     while m < n or time.perf_counter() - t0 < 1.0:
-        call(plan)
+        call()
         m += 1
     torch.cuda.synchronize(dev)
     stream_ms = (time.perf_counter() - t0) / m * 1e3
-    if spf.plan_flags(rec) != 0:
+    if spf.plan_flags(decoder.last_call) != 0:
         raise RuntimeError("the planned pair budget did not hold in the evaluation-shape run")
-    best = min(x for x in (plan_med, graph_med) if x is not None)
+    best = plan_med
     return {"metric": "decoder forward latency, b=1 x v=3 at 256x256 (test_step shape)", "value": round(best, 4),
             "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": n, "warmup": args.warmup,
             "ms_per_step": round(best, 4), "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"eval_1x3: 1 scene of {G} Gaussians, {K} SH coefficients per channel, 3 target views, "
-                                   f"{h}x{w}, decoder forward only under no_grad",
-                       "launch": "one call, then torch.cuda.synchronize: wall time per call"},
+                                   f"{h}x{w}, DecoderSplattingCUDA.forward under no_grad",
+                       "launch": "one decoder.forward call, then torch.cuda.synchronize: wall time per call; planned "
+                                 "calls are replayed from the module's own HIP-graph cache"},
             "latency_ms": {"exact_mode_median": round(exact_med, 4), "exact_mode_min": round(exact_min, 4),
                            "planned_median": round(plan_med, 4), "planned_min": round(plan_min, 4),
+                           "planned_no_graph_cache_median": round(nograph_med, 4),
+                           "planned_no_graph_cache_min": round(nograph_min, 4),
                            "planned_graph_replay_median": None if graph_med is None else round(graph_med, 4),
                            "planned_graph_replay_min": None if graph_min is None else round(graph_min, 4),
                            "planned_back_to_back": round(stream_ms, 4), "calls_each": n,
                            "Mpixels_per_s_back_to_back": round(3 * h * w / stream_ms / 1e3, 1)}}
+
+
+ROPE_SHAPES = ((48, 256, 16, 64), (32, 258, 12, 64))     # encoder self-attention, decoder
+
+
+def rope_bench(args, dev) -> dict:
+    """RoPE-2D (`curope.rope_2d`, curope.cpp:49-65 / kernels.cu:84-108) under the driver's clock: the HIP kernel in place
+    on strided q views (and q + k in one launch) of a [B,N,3,H,D] qkv buffer, as blocks.py:97-104 calls it.
+
+    `us` = device time per call in a stream of DEPENDENT calls: 50 calls captured in one HIP graph, replayed, HIP events
+    around the replays, / 50 (a Python thread cannot issue a 10 us kernel every 10 us, and an event pair around ONE launch
+    adds the launch latency to it: `us_single_event` reports that too).  Algorithmic bytes:
+    2*B*N*H*D*sizeof + 16*B*N per tensor.  CPU baselines, fp32, same shapes: oracle/rope_ref.c (the restated C++ loop
+    curope.cpp:11-47, one core, as the reference runs it) and oracle/rope_torch_ref.py (the restated PyTorch fallback
+    pos_embed.py:112-159, on up to 16 host cores)."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import _lib
+    cases = []
+    calls = 50
+    for (B, N, H, D) in ROPE_SHAPES:
+        for dt in (torch.float32, torch.float16):
+            gen = torch.Generator().manual_seed(B + N)
+            qkv = torch.randn(B, N, 3, H, D, generator=gen).to(dev, dt)
+            pos = torch.randint(0, 18, (B, N, 2), generator=gen).to(dev)
+            q, k = qkv[:, :, 0], qkv[:, :, 1]                    # strided [B,N,H,D] views, stride(2) = D
+            for pair in (False, True):
+                fn = (lambda: spf.rope_2d_pair(q, k, pos, 100.0, 1.0)) if pair else (lambda: spf.rope_2d(q, pos, 100.0, 1.0))
+                for _ in range(5):
+                    fn()
+                _lib.stage_timing_enable(["rope2d"])
+                for _ in range(20):
+                    fn()
+                torch.cuda.synchronize(dev)
+                ms, cnt = _lib.stage_times()["rope2d"]
+                _lib.stage_timing_enable(False)
+                single = 1e3 * ms / max(cnt, 1)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    for _ in range(calls):
+                        fn()
+                g_.replay()
+                torch.cuda.synchronize(dev)
+                reps = max(args.steps // 2, 10)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ts = []
+                for _ in range(5):
+                    e0.record()
+                    for _ in range(reps):
+                        g_.replay()
+                    e1.record()
+                    torch.cuda.synchronize(dev)
+                    ts.append(e0.elapsed_time(e1) * 1e3 / (reps * calls))
+                us = sorted(ts)[len(ts) // 2]
+                byts = (2 if pair else 1) * 2 * B * N * H * D * qkv.element_size() + 16 * B * N
+                cases.append({"shape": [B, N, H, D], "dtype": str(dt).split(".")[-1],
+                              "tensors": "q+k, one launch" if pair else "q", "us": round(us, 3),
+                              "us_single_event": round(single, 3), "algorithmic_bytes": byts,
+                              "GBs": round(byts / us / 1e3, 1), "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)})
+                log(f"rope2d {cases[-1]}")
+    # CPU baselines (fp32, q only): the reference's two CPU implementations, restated under oracle/
+    from oracle import rope_torch_ref
+    from tests import util
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
+    torch.set_num_threads(cores)
+    lib = util.rope_oracle_lib()
+    cpu = []
+    for (B, N, H, D) in ROPE_SHAPES:
+        gen = torch.Generator().manual_seed(B + N)
+        tok = torch.randn(B, N, H, D, generator=gen)
+        pos = torch.randint(0, 18, (B, N, 2), generator=gen)
+        byts = 2 * B * N * H * D * 4 + 16 * B * N
+        t0 = time.perf_counter()
+        n_c = 0
+        while n_c < 2 or time.perf_counter() - t0 < 2.0:
+            lib.rope2d_ref_f32(tok.data_ptr(), pos.data_ptr(), B, N, H, D, tok.stride(0), tok.stride(1), 100.0, 1.0)
+            n_c += 1
+        t_c = (time.perf_counter() - t0) / n_c
+        bhnd = tok.transpose(1, 2).contiguous()
+        cache = {}
+        rope_torch_ref.rope2d_fallback(bhnd, pos, 100.0, cache)
+        t0 = time.perf_counter()
+        n_t = 0
+        while n_t < 3 or time.perf_counter() - t0 < 2.0:
+            rope_torch_ref.rope2d_fallback(bhnd, pos, 100.0, cache)
+            n_t += 1
+        t_t = (time.perf_counter() - t0) / n_t
+        cpu.append({"shape": [B, N, H, D], "dtype": "float32",
+                    "c_loop": {"us": round(t_c * 1e6, 1), "GBs": round(byts / t_c / 1e9, 3), "cores": 1, "calls": n_c,
+                               "kind": "port", "what": "oracle/rope_ref.c = curope.cpp:11-47 restated"},
+                    "torch_fallback": {"us": round(t_t * 1e6, 1), "GBs": round(byts / t_t / 1e9, 3), "cores": cores,
+                                       "calls": n_t, "kind": "port",
+                                       "what": "oracle/rope_torch_ref.py = pos_embed.py:112-159 restated (out of place)"}})
+        log(f"rope2d cpu {cpu[-1]}")
+    head = cases[0]
+    worst = min(cases, key=lambda c: c["frac"])
+    return {"metric": "RoPE-2D in place, GB/s of algorithmic bytes (fp32 q at (48,256,16,64))", "value": head["GBs"],
+            "unit": "GB/s", "higher_is_better": True, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(head["us"] / 1e3, 6), "scaling": "weak", "vs_baseline": None, "dtype": "f32 / f16",
+            "data": "synthetic",
+            "config": {"workload": "rope2d: curope.rope_2d on strided q (and q + k) views of a [B,N,3,H,D] qkv buffer, "
+                                   "(B,N,H,D) = (48,256,16,64) and (32,258,12,64), float32 and float16, positions 0..17",
+                       "launch": f"{calls} dependent calls per HIP graph, replayed; HIP events around the replays"},
+            "roofline": {"bound": "hbm", "kernel": "spf_rope2d_vec_kernel", "achieved": head["GBs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": head["frac"], "traffic": None, "launch_ms": round(head["us"] / 1e3, 6),
+                         "algorithmic_bytes_per_launch": head["algorithmic_bytes"],
+                         "worst_case": {k: worst[k] for k in ("shape", "dtype", "tensors", "us", "frac")}},
+            "cases": cases,
+            "cpu_baseline": {"value": cpu[0]["c_loop"]["GBs"], "unit": "GB/s", "cores": 1, "host_cores": host_cores,
+                             "kind": "port", "sample": "whole tensors, >= 2 s per implementation and shape", "shapes": cpu}}
 
 
 def main():
@@ -390,10 +533,10 @@ def main():
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
 
-    if args.eval_latency:
+    if args.eval_latency or args.rope:
         if world != 1:
-            sys.exit("bench.py: --eval-latency is a single-GPU measurement")
-        print(json.dumps(eval_latency(args, dev)), flush=True)
+            sys.exit("bench.py: --eval-latency / --rope are single-GPU measurements")
+        print(json.dumps(rope_bench(args, dev) if args.rope else eval_latency(args, dev)), flush=True)
         if launched:
             dist.destroy_process_group()
         return
@@ -634,6 +777,7 @@ def main():
     log(f"timed region: {n_trials} trials x {args.steps} steps = {sum(trials):.3f} s; median trial {dt * 1e3:.3f} ms, "
         f"min {min(trials) * 1e3:.3f}, max {max(trials) * 1e3:.3f}")
 
+    failed_children = []
     if rank == 0:
         P = h * w
         renders = world * S * V
@@ -711,10 +855,14 @@ def main():
         if world == 1 and headline_defaults and not args.no_secondary:
             torch.cuda.empty_cache()
             out["secondary"] = run_secondary(args)
+            failed_children = out["secondary"].pop("_failed", [])
         print(json.dumps(out), flush=True)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+    if failed_children:
+        # the headline line is out (its number is valid on its own); a broken secondary workload still fails the run
+        sys.exit(f"bench.py: secondary workload(s) failed: {', '.join(failed_children)}")
 
 
 if __name__ == "__main__":

@@ -72,7 +72,8 @@ typedef struct SpfDims {
                             needs more than bin_cap entries raises plan flag 2 (see spf_raster_forward_render). */
     int64_t pair_capacity; /* direct bins only: number of gradient records g->gpair will hold (the `capacity` the
                             backward is given); the projection kernel numbers the (Gaussian, tile) pairs and raises plan
-                            flag 1 if they do not fit */
+                            flag 1 if they do not fit -- per SHARD of the numbering when it is sharded: each of the
+                            spf_raster_pair_shards(S, G) shards owns pair_capacity / shards records (see there) */
 } SpfDims;
 
 /* Inputs (all float32, contiguous, row-major). */
@@ -189,6 +190,16 @@ int spf_raster_view_partial_blocks(int32_t G);
  * dealt out so that no XCD is left with ONE render (strip q of render r -> XCD (r + q) % 8).  A bijection; host-side
  * arithmetic only (documentation and tests).  -1 for arguments out of range. */
 int spf_raster_launch_slot_tile(int32_t R, int32_t T, int32_t xcd, int32_t slot);
+/* Direct bins: how the (Gaussian, tile) pair numbering of a call of S scenes x G Gaussians is sharded, and the largest
+ * number of tiles per render whose histogram the projection kernel keeps in LDS (direct bins need it).
+ * spf_raster_pair_shards: 1 or 8.  With 8 shards the blocks of the projection kernel number their pairs from eight
+ * cursors (block b -> shard b % 8; one cursor would be a hot word) and shard i owns the gradient records
+ * [i * pair_capacity / 8, (i + 1) * pair_capacity / 8): plan flag 1 is raised when ONE shard outgrows its eighth, so a
+ * caller that wants "D <= capacity never fails" sizes pair_capacity (and g->gpair) with headroom for the imbalance of a
+ * round-robin deal of blocks -- the Python host passes twice the planned capacity (address space, never touched unless
+ * used). */
+int spf_raster_pair_shards(int32_t S, int32_t G);
+int spf_raster_max_lds_tiles(void);
 /* Into how many chunks of renders spf_raster_forward_render (backward = 0) / spf_raster_backward (backward = 1) split a
  * call of S scenes x V views.  1 unless the environment says SPF_CHUNKS=n: then, after the joint tile scan, the chunks
  * (whole scenes each) run as independent launch chains alternating between the caller's stream and one auxiliary stream

@@ -56,6 +56,8 @@ SYMBOLS = {
     "spf_raster_view_partial_blocks": (C.c_int, [C.c_int32]),
     "spf_raster_launch_slot_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "spf_raster_chunks": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "spf_raster_pair_shards": (C.c_int, [C.c_int32, C.c_int32]),
+    "spf_raster_max_lds_tiles": (C.c_int, []),
     "spf_camera_forward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p]),
     "spf_camera_backward": (C.c_int, [C.POINTER(SpfCamera), C.c_void_p, C.c_void_p, C.c_void_p]),
     "spf_raster_forward_project": (C.c_int, [C.POINTER(SpfDims), C.POINTER(SpfInputs), C.POINTER(SpfState),

@@ -261,6 +261,12 @@ int spf_raster_launch_slot_tile(int32_t R, int32_t T, int32_t xcd, int32_t slot)
     if (xcd < 0 || xcd > 7 || slot < 0 || slot >= (RT >> 3)) return -1;
     return spf::xcd_tile(spf::xcd_map(RT, T), T, xcd, slot);
 }
+int spf_raster_pair_shards(int32_t S, int32_t G) {
+    if (S < 1 || G < 1) return 1;
+    const int64_t nblocks = (int64_t)S * ((G + spf::kBlock - 1) / spf::kBlock);
+    return spf::pair_shards(nblocks > 0x7fffffff ? 0x7fffffff : (int)nblocks);
+}
+int spf_raster_max_lds_tiles(void) { return spf::max_lds_tiles(); }
 int spf_raster_chunks(int32_t S, int32_t V, int32_t H, int32_t W, int32_t backward) {
     if (S < 1 || V < 1 || H < 1 || W < 1) return 1;
     int bounds[kMaxChunks + 1];

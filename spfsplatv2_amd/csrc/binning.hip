@@ -467,6 +467,19 @@ __device__ __forceinline__ void census_check(const TileLists& tl, const uint32_t
     if (dense != (dense_hint != 0u)) atomicOr(&counters[2], 4u);
 }
 
+// The census on its own: a planned call whose longest list is one entry launches no sort kernel at all (nothing to
+// sort), so nobody would visit the tiles -- one lane per tile here (a one-entry tile under a large footprint IS dense).
+__global__ __launch_bounds__(kBlock) void spf_tile_census_kernel(TileLists tl, const uint32_t* __restrict__ flags,
+                                                                 uint32_t* __restrict__ counters, int RT,
+                                                                 uint32_t dense_hint, uint32_t dense_thr) {
+    const int tile = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (tile >= RT) return;
+    uint32_t b, n;
+    tile_range(tl, (size_t)tile, b, n);
+    const bool dense = tile_is_dense(flags[tile], n, dense_thr);
+    if (dense != (dense_hint != 0u)) atomicOr(&counters[2], 4u);
+}
+
 // ---- per-tile sort in LDS ---------------------------------------------------------------------
 // Bitonic network in its "all comparators ascending" form (first step of every merge compares
 // i with i ^ (k-1), the rest with i ^ j): it needs no padding, because a missing partner above n
@@ -958,6 +971,9 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
         spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr);
+    if (tl.cap && !(mx > 1) && (dense_hint == 0u || dense_hint == (uint32_t)RT))   // ... and the census (see the kernel)
+        spf_tile_census_kernel<<<(RT + kBlock - 1) / kBlock, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, RT,
+                                                                                   dense_hint, thr);
     if (mixed)
         spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
                                                                             RT, dense_hint, thr, order, T);

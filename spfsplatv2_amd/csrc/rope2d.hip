@@ -6,8 +6,8 @@
 // and every (u,v) pair with frequency index q is rotated by  angle = pos * fwd / base^(q/Q)
 // where pos is the token's y position for the first half and its x position for the second.
 //
-// Mapping: one lane owns 16 bytes of consecutive frequencies (4 floats, 8 halves) of one (token, half) and walks four
-// heads with them (the angle does not depend on the head: one sincosf per four head rows); consecutive lanes walk q,
+// Mapping: one lane owns 16 bytes of consecutive frequencies (4 floats, 8 halves) of one (token, half) and walks two or
+// four heads with them (the angle does not depend on the head: one evaluation per group of head rows); consecutive lanes walk q,
 // then the half, so a group of lanes covers whole contiguous head rows.  The Q inverse frequencies are computed
 // on the host with libm powf (exactly what the reference's CPU path evaluates,
 // curope/curope.cpp:35) and travel in the kernel-argument segment -- no device powf, no table in HBM.
@@ -63,47 +63,77 @@ template <typename H> struct WideHalf {
 template <> struct Wide<__half> : WideHalf<__half> {};
 template <> struct Wide<__hip_bfloat16> : WideHalf<__hip_bfloat16> {};
 
-// Vector path.  One lane owns EPL = 16 bytes / sizeof(T) consecutive frequencies of one (token, half) and walks kHeads
-// heads with them: the rotation angle depends on (token, half, frequency) only, so its sincosf -- which made the half
-// types compute-bound at one evaluation per element pair (fp16 took as long as fp32 for half the bytes) -- is
-// evaluated once per kHeads head rows.  Consecutive lanes walk the frequencies, then the half, so at every step of the
-// head loop a group of 2*Q/EPL lanes covers one contiguous head row.  `tokens2` (may be null): a second tensor of the
-// same shape / strides / positions rotated in the same launch with the same angles (q and k of one attention layer,
-// croco/blocks.py:102-104).
-constexpr int kRopeHeads = 4;
-template <typename T>
+// sin and cos of a rotation angle: Cody-Waite reduction by pi/2 in three fused steps (pi/2 = hi + mid + lo to ~72 bits;
+// the fma keeps each partial product exact, so the reduced argument is good to half an ulp for |k| < 2^15) and the
+// cephes minimax polynomials on [-pi/4, pi/4]: max abs error 8.9e-8 against float64 over positions 0..30000 x every
+// frequency (checked on the CPU with emulated float32 fmas) -- the libm sincosf this replaces is good to 1 ulp too, at
+// three times the instructions (its Payne-Hanek path for huge arguments is kept for exactly those).  The angle's
+// evaluation was what made the half types compute-bound.
+__device__ __forceinline__ void rope_sincos(float x, float& s, float& c) {
+    if (!(fabsf(x) < 30000.f)) { sincosf(x, &s, &c); return; }           // (huge positions, inf, nan: libm)
+    const float kf = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-kf, 1.5707963705062866f, x);
+    r = fmaf(-kf, -4.371138828673793e-08f, r);
+    r = fmaf(-kf, -1.7763568394002505e-15f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float sr = fmaf(ps * z, r, r);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    const float cr = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const int k = (int)kf;
+    const float a = (k & 1) ? cr : sr, b = (k & 1) ? sr : cr;            // quadrant: (s, c) = (sr, cr), (cr, -sr), (-sr, -cr), (-cr, sr)
+    s = (k & 2) ? -a : a;
+    c = ((k + 1) & 2) ? -b : b;
+}
+
+// Vector path.  One lane owns EPL = 16 bytes / sizeof(T) consecutive frequencies of one (token, half) and walks HEADS
+// heads with them: the rotation angle depends on (token, half, frequency) only, so it is evaluated once per HEADS head
+// rows.  Consecutive lanes walk the frequencies, then the half, so at every step of the head loop a group of 2*Q/EPL
+// lanes covers one contiguous head row.  `tokens2` (may be null): a second tensor of the same shape / strides /
+// positions rotated in the same launch with the same angles (q and k of one attention layer, croco/blocks.py:102-104).
+// HEADS is picked per launch (launch_rope_t): four for tensors that fill the chip with waves anyway, two for the small
+// ones -- the reference's decoder shape (32,258,12,64) in fp16 is 1.5 waves per SIMD at four heads per lane, a launch
+// that runs as long as its memory latency chain.  Every token row a lane will rotate is REQUESTED before the angles are
+// evaluated (the loads do not depend on them), and index arithmetic is 32-bit whenever the launch allows (I).
+template <typename T, int HEADS, typename I>
 __global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ tokens, T* __restrict__ tokens2,
                                                                 const int64_t* __restrict__ pos, int N, int H, int D,
                                                                 int64_t stride_b, int64_t stride_n, int64_t stride_h, int pos_div,
-                                                                RopeFreq f, size_t total) {
+                                                                RopeFreq f, I total) {
     using W = Wide<T>;
     constexpr int EPL = W::N;
-    const size_t item = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const I item = (I)blockIdx.x * (I)kBlock + (I)threadIdx.x;
     if (item >= total) return;
     const int Q = D >> 2, QG = Q / EPL, per_chunk = 2 * QG;
-    const int nchunk = (H + kRopeHeads - 1) / kRopeHeads;
-    const int per_tok = nchunk * per_chunk;
-    const size_t token = item / per_tok;
+    const int nchunk = (H + HEADS - 1) / HEADS;
+    const I per_tok = (I)(nchunk * per_chunk);
+    const I token = item / per_tok;
     const int rem = (int)(item - token * per_tok);
     const int hc = rem / per_chunk, e = rem - hc * per_chunk;
     const int x = e / QG, q0 = (e - x * QG) * EPL;
-    const size_t b = token / N, n = token - b * N;
-    const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
+    const I b = token / (I)N, n = token - b * (I)N;
+    const int64_t pword = pos[((size_t)(b / (I)pos_div) * N + n) * 2 + x];
+    const int h0 = hc * HEADS;
+    const size_t base = (size_t)b * stride_b + (size_t)n * stride_n + (size_t)h0 * stride_h + x * 2 * Q + q0;
+    float u[HEADS][EPL], v[HEADS][EPL];
+#pragma unroll
+    for (int j = 0; j < HEADS; ++j)
+        if (h0 + j < H) { W::load(tokens + base + j * stride_h, u[j]); W::load(tokens + base + j * stride_h + Q, v[j]); }
+    const float p = (float)pword;
     float sn[EPL], cs[EPL];
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) sincosf(p * f.inv[q0 + k], &sn[k], &cs[k]);
-    const int h0 = hc * kRopeHeads;
-    const size_t base = b * stride_b + n * stride_n + (size_t)h0 * stride_h + x * 2 * Q + q0;
+    for (int k = 0; k < EPL; ++k) rope_sincos(p * f.inv[q0 + k], sn[k], cs[k]);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         T* __restrict__ t = pass == 0 ? tokens : tokens2;
         if (!t) break;
-        float u[kRopeHeads][EPL], v[kRopeHeads][EPL];
+        if (pass == 1) {
 #pragma unroll
-        for (int j = 0; j < kRopeHeads; ++j)
-            if (h0 + j < H) { W::load(t + base + j * stride_h, u[j]); W::load(t + base + j * stride_h + Q, v[j]); }
+            for (int j = 0; j < HEADS; ++j)
+                if (h0 + j < H) { W::load(t + base + j * stride_h, u[j]); W::load(t + base + j * stride_h + Q, v[j]); }
+        }
 #pragma unroll
-        for (int j = 0; j < kRopeHeads; ++j)
+        for (int j = 0; j < HEADS; ++j)
             if (h0 + j < H) {
                 float uo[EPL], vo[EPL];
 #pragma unroll
@@ -134,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict
     const size_t b = token / N, n = token - b * N;
     const float p = (float)pos[((b / pos_div) * N + n) * 2 + x];
     float s, c;
-    sincosf(p * f.inv[q], &s, &c);
+    rope_sincos(p * f.inv[q], s, c);
     const size_t o = b * stride_b + n * stride_n + (size_t)h * stride_h + x * 2 * Q + q;
     for (int pass = 0; pass < 2; ++pass) {
         T* __restrict__ up = (pass == 0 ? tokens : tokens2);
@@ -146,6 +176,28 @@ __global__ __launch_bounds__(kBlock) void spf_rope2d_scalar_kernel(T* __restrict
     }
 }
 
+template <typename T, int HEADS>
+static void launch_rope_vec(void* tokens, void* tokens2, const int64_t* pos, int B, int N, int H, int D, int64_t sb,
+                            int64_t sn, int64_t sh, int pos_div, const RopeFreq& f, hipStream_t stream) {
+    constexpr int EPL = Wide<T>::N;
+    const size_t total = (size_t)B * N * ((H + HEADS - 1) / HEADS) * 2 * ((D / 4) / EPL);
+    const unsigned grid = (unsigned)((total + kBlock - 1) / kBlock);
+    if (total < ((size_t)1 << 31))
+        spf_rope2d_vec_kernel<T, HEADS, uint32_t><<<grid, kBlock, 0, stream>>>(
+            static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, (uint32_t)total);
+    else
+        spf_rope2d_vec_kernel<T, HEADS, size_t><<<grid, kBlock, 0, stream>>>(
+            static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, total);
+}
+
+// heads per lane (see the kernel): 4 when that still gives every SIMD of the chip four waves, else 2; SPF_ROPE_HEADS=1/2/4
+// pins it (experiments)
+static int rope_heads(size_t lanes_at_4) {
+    static const int forced = getenv("SPF_ROPE_HEADS") ? atoi(getenv("SPF_ROPE_HEADS")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return lanes_at_4 >= (size_t)256 * 4 * 4 * kWave ? 4 : 2;
+}
+
 template <typename T>
 static hipError_t launch_rope_t(void* tokens, void* tokens2, const int64_t* pos, int B, int N, int H, int D, int64_t sb,
                                 int64_t sn, int64_t sh, int pos_div, const RopeFreq& f, hipStream_t stream) {
@@ -155,9 +207,10 @@ static hipError_t launch_rope_t(void* tokens, void* tokens2, const int64_t* pos,
                      (reinterpret_cast<uintptr_t>(tokens2) % 16 == 0) && (sb % EPL == 0) && (sn % EPL == 0) &&
                      (sh % EPL == 0);
     if (vec) {
-        const size_t total = (size_t)B * N * ((H + kRopeHeads - 1) / kRopeHeads) * 2 * (Q / EPL);
-        spf_rope2d_vec_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(
-            static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, total);
+        const int heads = rope_heads((size_t)B * N * ((H + 3) / 4) * 2 * (Q / EPL));
+        if (heads == 4) launch_rope_vec<T, 4>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        else if (heads == 2) launch_rope_vec<T, 2>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
+        else launch_rope_vec<T, 1>(tokens, tokens2, pos, B, N, H, D, sb, sn, sh, pos_div, f, stream);
     } else {
         const size_t total = (size_t)B * N * H * 2 * Q;
         spf_rope2d_scalar_kernel<T><<<(unsigned)((total + kBlock - 1) / kBlock), kBlock, 0, stream>>>(

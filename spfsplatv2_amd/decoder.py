@@ -34,7 +34,9 @@ from typing import Generic, Literal, Optional, TypeVar
 import torch
 from torch import Tensor, nn
 
-from .rasterizer import CallRecord, rasterize_batch, render_batch
+import os
+
+from .rasterizer import CallRecord, PairBudget, rasterize_batch, render_batch, sh_band4_default
 
 DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
 
@@ -239,6 +241,15 @@ class DecoderSplattingCUDACfg:
     enable_sh_grad: bool
 
 
+class _EvalGraph:
+    """One captured evaluation call of a decoder: the graph, the tensors it writes (color, depth, alpha, radii -- owned
+    by the graph's memory pool) and the call record whose `counters` it refreshes."""
+    __slots__ = ("graph", "outputs", "record")
+
+    def __init__(self, graph, outputs, record):
+        self.graph, self.outputs, self.record = graph, outputs, record
+
+
 class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     """Drop-in for the reference decoder (kept under the reference's registry name
     ``"splatting_cuda"``); the work runs on the MI355X HIP rasterizer."""
@@ -262,26 +273,120 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # statistics / plan counters of THIS decoder's most recent call (two live decoders do not interleave):
         # `spfsplatv2_amd.plan_flags(decoder.last_call)`, `plan_pair_budget(decoder.last_call)`
         self.last_call = CallRecord()
+        # Evaluation-shaped calls (no gradient will be asked for, planned pair budget): the whole call -- camera set-up,
+        # projection + binning, tile sort, compositing, depth x near -- is ~9 launches of a few microseconds each, and a
+        # Python thread needs longer to issue them than the GPU to run them (test_step: b = 1, v = 3,
+        # model_wrapper.py:415-454: 0.154 ms per call launched one by one, 0.093 ms as a replayed HIP graph).  So the
+        # module keeps a small cache of captured graphs, keyed by EVERYTHING a graph bakes in: the addresses, shapes and
+        # strides of all input tensors, the image size, the plan and the band-4 switch.  The first call of a key runs
+        # as usual, the second is captured, later ones are one graph launch; results are copied out of the graph's own
+        # buffers, so what a call returns is the caller's (never overwritten by a later call).  A loop that hands over
+        # fresh addresses every time simply never hits (after `_EVAL_GRAPH_MISSES` captures that were never replayed the
+        # cache stops capturing).  `eval_graphs = False` or SPF_EVAL_GRAPHS=0 switches it off; `clear_eval_graphs()`
+        # releases the captured graphs and their buffers.
+        self.eval_graphs = True
+        self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
+        self._graph_seen: dict = {}      # key -> None: keys seen once, not yet captured
+        self._graph_unused = 0           # captures since the last replay hit
+
+    _EVAL_GRAPH_SLOTS = 4
+    _EVAL_GRAPH_MISSES = 8
+
+    def clear_eval_graphs(self) -> None:
+        self._graphs.clear()
+        self._graph_seen.clear()
+        self._graph_unused = 0
+
+    def _render_eager(self, gaussians, extrinsics, intrinsics, near, far, image_shape, max_pairs, record):
+        color, depth, alpha, radii = render_views(
+            extrinsics, intrinsics, near, far, image_shape, self.background_color,
+            gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
+            scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
+            enable_sh_grad=self.enable_sh_grad, max_pairs=max_pairs, sh_band4=self.sh_band4, return_radii=True,
+            record=record)
+        depth = depth[:, :, 0]                                   # "(b v) 1 h w -> b v h w"
+        if self.make_scale_invariant:
+            depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76
+        return color, depth, alpha, radii
+
+    def _eval_graph_key(self, tensors, image_shape):
+        """None unless this call may run from a captured graph: planned, nothing will be differentiated, every tensor a
+        dense float32 device tensor (what the kernels take without a copy), no capture already going on."""
+        if not (self.eval_graphs and isinstance(self.max_pairs, PairBudget)) or os.environ.get("SPF_EVAL_GRAPHS", "1") == "0":
+            return None
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            return None
+        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
+        return (tuple((t.data_ptr(), tuple(t.shape)) for t in tensors), tuple(image_shape), self.max_pairs, band4,
+                self.background_color.data_ptr(), self.make_scale_invariant)
 
     def render(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                image_shape: tuple[int, int]):
         """``forward`` plus the two rasterizer outputs the reference's decoder drops (cuda_splatting.py:128,141-144):
         returns (DecoderOutput, alpha [b,v,1,h,w], radii [b,v,g] int32)."""
-        color, depth, alpha, radii = render_views(
-            extrinsics, intrinsics, near, far, image_shape, self.background_color,
-            gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
-            scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
-            enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs, sh_band4=self.sh_band4, return_radii=True,
-            record=self.last_call)
-        depth = depth[:, :, 0]                                   # "(b v) 1 h w -> b v h w"
-        if self.make_scale_invariant:
-            depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76
-        return DecoderOutput(color, depth), alpha, radii
+        return self._render(gaussians, extrinsics, intrinsics, near, far, image_shape, True)
+
+    def _render(self, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
+        tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
+                   gaussians.rotations, gaussians.scales)
+        key = self._eval_graph_key(tensors, image_shape)
+        if key is None:
+            color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
+                                                            self.max_pairs, self.last_call)
+            return DecoderOutput(color, depth), alpha, radii
+        entry = self._graphs.get(key)
+        if entry is None:
+            first_sight = key not in self._graph_seen
+            if first_sight or self._graph_unused >= self._EVAL_GRAPH_MISSES:
+                if first_sight:
+                    if len(self._graph_seen) >= 64:
+                        self._graph_seen.clear()
+                    self._graph_seen[key] = None
+                with torch.no_grad():
+                    color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
+                                                                    image_shape, self.max_pairs, self.last_call)
+                return DecoderOutput(color, depth), alpha, radii
+            entry = self._capture(key, gaussians, extrinsics, intrinsics, near, far, image_shape)
+        else:
+            self._graph_unused = 0
+        entry.graph.replay()
+        self.last_call.clear()
+        self.last_call.update(entry.record)
+        if self.max_pairs.check != "deferred":
+            from .rasterizer import plan_flags
+            if plan_flags(entry.record) != 0:
+                # the plan did not hold for THESE inputs (the graph's outputs are NaN): this call in exact mode instead
+                with torch.no_grad():
+                    color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
+                                                                    image_shape, None, self.last_call)
+                return DecoderOutput(color, depth), alpha, radii
+        color, depth, alpha, radii = entry.outputs
+        # (copies: what the caller gets is the caller's; the graph's own buffers are rewritten by its next replay)
+        if not want_extra:
+            return DecoderOutput(color.clone(), depth.clone()), None, None
+        return DecoderOutput(color.clone(), depth.clone()), alpha.clone(), radii.clone()
+
+    def _capture(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "_EvalGraph":
+        while len(self._graphs) >= self._EVAL_GRAPH_SLOTS:
+            self._graphs.pop(next(iter(self._graphs)))
+        record = CallRecord()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            outputs = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape, self.max_pairs, record)
+        entry = _EvalGraph(graph, outputs, record)
+        self._graphs[key] = entry
+        self._graph_seen.pop(key, None)
+        self._graph_unused += 1
+        return entry
 
     def forward(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                 image_shape: tuple[int, int], depth_mode: DepthRenderingMode | None = None) -> DecoderOutput:
         # depth_mode is accepted and ignored, as in the reference (decoder_splatting_cuda.py:49)
-        return self.render(gaussians, extrinsics, intrinsics, near, far, image_shape)[0]
+        return self._render(gaussians, extrinsics, intrinsics, near, far, image_shape, False)[0]
 
 
 DecoderSplattingHIP = DecoderSplattingCUDA

@@ -74,7 +74,9 @@ class PairBudget(NamedTuple):
     capacity       pair-buffer entries to allocate
     max_tile_list  assumed upper bound of the longest tile list (0 = unknown: all sort size classes are launched)
     dense_tiles    None = unknown (both render kernels are launched); 0 = no dense tile; -1 = every tile is dense
-    check          "backward": the backward pass reads the flag (one host sync) and raises if the plan failed;
+    check          "backward": the backward pass reads the flag (one host sync) and raises if the plan failed (a call
+                   that will have no backward verifies at once; ``DecoderSplattingCUDA``'s replayed evaluation graphs
+                   re-run such a call in exact mode instead of raising);
                    "deferred": the library never reads it -- call ``last_plan_flags()`` when convenient
     """
     capacity: int
@@ -240,8 +242,11 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     # DIRECT BINS (planned calls): every tile owns a fixed bin of `bin_cap` keys that the projection kernel fills itself
     # -- no tile scan, no binning pass (SpfDims.bin_cap).  The bin size is the plan's list-length class.
     bin_cap = _direct_bin_cap(max_pairs, R * T, T)
+    # gradient records the backward will allocate: the plan's capacity -- with headroom when the pair numbering is
+    # sharded (each of 8 shards owns an eighth: see _record_capacity)
+    rec_cap = _record_capacity(_plan_numbers(max_pairs, R * T)[0], S, G) if bin_cap else 0
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
-                        bin_cap, _plan_numbers(max_pairs, R * T)[0] if bin_cap else 0)
+                        bin_cap, rec_cap)
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
 
@@ -289,8 +294,11 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
             _last.update(rec_out)
     else:
         capacity, max_tile, dense = _plan_numbers(max_pairs, R * T)
+        if bin_cap:
+            capacity = rec_cap
         rec_out["counters"] = counters
         _last["counters"] = counters
+        rec_out["plan"] = _last["plan"] = (int(bin_cap), int(capacity), lib.spf_raster_pair_shards(S, G) if bin_cap else 1)
     if not bin_cap:
         pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
         st.pairs = _ptr(pairs)
@@ -302,21 +310,38 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
             and not torch.cuda.is_current_stream_capturing():
         # check="backward" promises that a failed plan raises -- but no backward will come (evaluation under
         # no_grad, or nothing requires grad): verify now (one host sync; eval loops should use exact mode anyway)
-        _raise_if_plan_failed(counters, capacity)
+        _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity, rec_out.get("plan"))
     return ((image, depth, alpha, radii.view(S, V, G)),
             (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, bin_cap, max(int(capacity), 1)))
 
 
 def _direct_bin_cap(max_pairs, RT: int, T: int) -> int:
     """Bin size of a planned call that runs with DIRECT BINS (0: packed lists, the classic chain).  Needs a plan with a
-    list-length class (PairBudget.max_tile_list), the per-render tile histogram in LDS (T <= 4096) and R*T*cap keys of
-    memory within reason (<= 2^27 = 1 GiB); `SPF_DIRECT_BINS=0` pins the classic chain (A/B runs)."""
+    list-length class (PairBudget.max_tile_list), the per-render tile histogram in LDS (the library's limit,
+    spf_raster_max_lds_tiles) and bins that stay in proportion to the plan: R*T*cap keys <= 4 x the planned pairs (a
+    coarse list class on a many-tile call would otherwise hold ten times the classic chain's memory until the backward;
+    small calls may use up to 2^22 keys = 32 MiB regardless) and <= 2^27 in any case; `SPF_DIRECT_BINS=0` pins the
+    classic chain (A/B runs)."""
     if max_pairs is None or os.environ.get("SPF_DIRECT_BINS", "1") == "0":
         return 0
     cap = max_pairs.max_tile_list if isinstance(max_pairs, PairBudget) else 0
-    if cap <= 0 or T > 4096 or RT * cap > (1 << 27):
+    if cap <= 0 or T > _lib.load().spf_raster_max_lds_tiles():
+        return 0
+    keys = RT * cap
+    if keys > (1 << 27) or keys > max(4 * int(max_pairs.capacity), 1 << 22):
         return 0
     return int(cap)
+
+
+def _record_capacity(capacity: int, S: int, G: int) -> int:
+    """Gradient records (`gpair`) of a direct-bins call.  The projection kernel numbers the (Gaussian, tile) pairs from
+    up to eight sharded cursors (block b -> shard b % 8; one cursor would be a hot word), each shard owning an eighth of
+    the records, and raises plan flag 1 when ONE shard outgrows its share -- so with the plan's bare capacity a call
+    whose pairs fit in total could fail on the imbalance of the deal.  Twice the planned capacity: every
+    shard may hold double its fair share before anything is flagged, i.e. `D <= capacity` keeps meaning "fits" for any
+    deal that is not adversarial.  The extra records are address space only (never written unless used)."""
+    shards = _lib.load().spf_raster_pair_shards(S, G)
+    return int(capacity) * (2 if shards > 1 else 1)
 
 
 def _plan_numbers(max_pairs, RT: int):
@@ -351,15 +376,26 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(final_T), _ptr(n_contrib), _ptr(cursor))
 
 
-def _raise_if_plan_failed(counters: Tensor, capacity: int) -> None:
+def _raise_if_plan_failed(counters: Tensor, capacity: int, plan=None) -> None:
+    """`plan` = (bin_cap, record capacity, shards) of a direct-bins call (its counters[0] / [1] are not maintained: the
+    message then names what the device actually checked), None for the classic chain."""
     host = counters.cpu()
     flag = int(host[2])
+    direct = plan is not None and plan[0] > 0
     if flag & 1:
+        if direct:
+            cursors = host[4:12] if host.numel() >= 12 else None
+            used = "" if cursors is None else f"; pairs numbered per shard: {[int(c) for c in cursors[:plan[2]]]}"
+            raise _lib.SpfError("pair budget overflow in the forward pass: a shard of the (Gaussian, tile) pair numbering "
+                                f"outgrew its {plan[1] // plan[2]} of {plan[1]} gradient records ({plan[2]} shard(s))"
+                                f"{used}; the outputs are NaN -- plan with a larger capacity")
         raise _lib.SpfError("pair buffer overflow in the forward pass: max_pairs was too small "
                             f"({capacity} < {int(host[0])}); the outputs are NaN")
     if flag:
-        raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = a tile list longer "
-                            f"than planned ({int(host[1])}), 4 = dense-tile assumption wrong); the outputs are NaN")
+        longer = f"a tile needs more than its bin of {plan[0]} entries" if direct else \
+            f"a tile list longer than planned ({int(host[1])})"
+        raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = {longer}, "
+                            "4 = dense-tile assumption wrong); the outputs are NaN")
 
 
 def _plan_mode(max_pairs) -> int:
@@ -382,7 +418,8 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     # (a device->host read is illegal while a HIP graph is being captured: graph users check the flag themselves
     # with `pair_buffer_overflowed` after a replay)
     if capacity_mode == 1 and not torch.cuda.is_current_stream_capturing():
-        _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity)
+        _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity,
+                              (bin_cap, capacity, lib.spf_raster_pair_shards(S, G)) if bin_cap else None)
     from .shard import active_bucket
     bucket = active_bucket()
     fast = _lib.fast() if bucket is None else None      # (a gradient bucket supplies the output buffers: ctypes path)

@@ -52,18 +52,39 @@ class GradBucket:
             total += (n + 3) // 4 * 4
         self.flat = torch.empty((total,), dtype=torch.float32, device=means.device)
         self.views = {name: self.flat[o:o + n].view(sh) for name, o, n, sh in zip(self.NAMES, offs, sizes, shapes)}
+        self.taken: set = set()      # names handed out since the bucket was last entered
 
     def take(self, name: str, like: torch.Tensor) -> Optional[torch.Tensor]:
-        """The view for `name` if it fits `like` (shape, device), else None (the caller allocates as usual)."""
+        """The bucket's view for gradient `name` of a backward that runs inside ``with bucket:``.
+
+        One backward per ``with`` block: the views are the ONLY storage, so a second rasterizer backward under the same
+        block (a per-view loop, a context render next to the target render, a ``retain_graph`` second backward) would
+        overwrite what the first one's ``.grad`` still aliases and autograd would then add two aliases of one buffer --
+        twice the last gradient, silently.  That raises here instead.  A tensor that does not match the view the bucket
+        was built with (shape, device, dtype -- e.g. harmonics handed over as [S,G,K,3] where the bucket was built from
+        the [S,G,3,K] leaf) raises too: falling back to a fresh buffer would leave that leaf out of the all-reduce and
+        put uninitialised bucket memory into it.  Names the bucket does not know (`colors`, ...) return None: the caller
+        allocates as usual."""
         v = self.views.get(name)
-        if v is None or tuple(v.shape) != tuple(like.shape) or v.device != like.device or like.dtype != torch.float32:
+        if v is None:
             return None
+        if tuple(v.shape) != tuple(like.shape) or v.device != like.device or like.dtype != torch.float32:
+            raise RuntimeError(f"GradBucket: the gradient of `{name}` is {tuple(like.shape)} {like.dtype} on {like.device}, "
+                               f"the bucket was built for {tuple(v.shape)} float32 on {v.device}")
+        if name in self.taken:
+            raise RuntimeError(f"GradBucket: `{name}` was already written by a backward inside this `with` block; a second "
+                               "rasterizer backward would overwrite the gradient the first one's .grad aliases "
+                               "(use one bucket per backward, or run the second backward outside the block)")
+        self.taken.add(name)
         # (a fresh alias of the view: autograd keeps a gradient it is handed without copying only when nobody else holds
         #  that tensor object -- the storage is the bucket's either way)
         return v.view(v.shape)
 
     def __enter__(self):
         with _active_lock:
+            if self in _active:
+                raise RuntimeError("GradBucket: already active (nested `with` on the same bucket)")
+            self.taken = set()
             _active.append(self)
         return self
 
@@ -74,7 +95,15 @@ class GradBucket:
 
     def all_reduce(self, group=None, async_op: bool = False, skip_single: bool = True):
         """In-place SUM over the ranks of everything in the bucket; returns the work handle with ``async_op=True``
-        (None when there is nothing to do)."""
+        (None when there is nothing to do).  Views no backward wrote since the bucket was last entered (a gradient that
+        was switched off, e.g. scales / rotations with ``enable_cov_grad=False``) are zero-filled first, so that the
+        collective never sums uninitialised memory; a bucket NO backward wrote into raises."""
+        if not self.taken:
+            raise RuntimeError("GradBucket.all_reduce: no backward wrote into this bucket since it was entered "
+                               "(run loss.backward() inside `with bucket:` first)")
+        for name, v in self.views.items():
+            if name not in self.taken:
+                v.zero_()
         if not dist.is_available() or not dist.is_initialized():
             return None
         if skip_single and dist.get_world_size(group) == 1:

@@ -127,6 +127,11 @@ CONFIGS = {
     # coefficients per channel (/root/reference/src/model/encoder/encoder_spfsplatv2.py:240,296-321;
     # config/model/encoder/spfsplatv2.yaml:20)
     "REF2V": (131072, (256, 256), (256, 256), 2, 25),
+    # what the shipped 10-view model hands its decoder: ten 256x256 context grids = 655,360 Gaussians per scene, 25 SH
+    # coefficients, rendered to ONE target view per scene, three scenes per step
+    # (/root/reference/config/experiment/spfsplatv2/re10k_10view.yaml:36-37,48: num_context_views 10,
+    # num_target_views 1, batch_size 3) -- few tiles (768 per step), lists of thousands of entries
+    "REF10V": (655360, (256, 256), (256, 256), 10, 25),
     # small parity-test scenes (oracle finishes in seconds): up to 2 x 64 x 64 Gaussians
     "TEST": (4096, (64, 64), (64, 64), 2, 1),
     # many Gaussians per tile (exercises the long-list sort classes): up to 2 x 256 x 256 Gaussians

@@ -45,7 +45,7 @@ def test_world_size_mismatch_is_an_error():
 def test_workload_table_covers_baseline_configs():
     b = _bench()
     from spfsplatv2_amd import synthetic as syn
-    assert set(b.WORKLOADS) == {"C2", "C3", "C5", "REF2V"} and all(k in syn.CONFIGS for k in b.WORKLOADS)
+    assert set(b.WORKLOADS) == {"C2", "C3", "C5", "REF2V", "REF10V"} and all(k in syn.CONFIGS for k in b.WORKLOADS)
     assert syn.CONFIGS["REF2V"][0] == 2 * 256 * 256 and syn.CONFIGS["REF2V"][4] == 25
     # byte model: SURVEY 8(d) total = sum of the stages
     S, V, G, K, P, D = 2, 3, 1000, 4, 4096, 5000
@@ -60,9 +60,19 @@ def test_secondary_children_parse_and_cover_the_verdict_list():
     accepted by the script's own parser and must not recurse."""
     b = _bench()
     names = [n for n, _, _ in b.SECONDARY]
-    assert names == ["C3", "C5", "REF2V", "REF2V_band4", "C2_streams2", "eval_1x3"]
+    assert names == ["C3", "C5", "REF2V", "REF2V_band4", "REF10V", "C2_streams2", "eval_1x3", "rope2d"]
     for _name, extra, env in b.SECONDARY:
         a = b.parse_args(["--gpus", "1", "--no-cpu-baseline", "--no-secondary", *extra])
         assert a.no_secondary and a.no_cpu_baseline
         assert all(isinstance(k, str) and isinstance(v, str) for k, v in env.items())
     assert dict((n, e) for n, _, e in b.SECONDARY)["REF2V_band4"] == {"SPF_SH_BAND4": "1"}
+
+
+def test_a_failed_secondary_child_is_recorded_and_named():
+    """VERDICT r4 (robustness 13): a secondary child that dies must not hide in stdout -- run_secondary names it in
+    `_failed`, and main() exits non-zero after printing the headline line.  The child here dies in its argument parser
+    (no GPU needed)."""
+    b = _bench()
+    b.SECONDARY = (("broken", ["--no-such-flag"], {}),)
+    out = b.run_secondary(b.parse_args(["--steps", "2", "--warmup", "1"]))
+    assert out["_failed"] == ["broken"] and "error" in out["broken"] and "exit code" in out["broken"]["error"]

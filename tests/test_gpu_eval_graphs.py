@@ -1,0 +1,95 @@
+"""The decoder module's cache of captured HIP graphs for evaluation-shaped calls (no gradient, planned pair budget):
+DecoderSplattingCUDA.forward at the reference's test_step shape (b = 1, v = 3, model_wrapper.py:415-454) is launch-bound
+from Python, so the second call of a key is captured and later ones are one graph launch (decoder.py)."""
+import pytest
+import torch
+
+from spfsplatv2_amd import synthetic as syn
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=9, **kw):
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    kw = {**dict(s_mult=4.0, G=3000, K=25, image_hw=(96, 80)), **kw}
+    b = syn.make_batch("TEST", 1, 3, seed=seed, **kw).to("cuda")
+    d = util.product_decoder()
+    g = dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
+    args = lambda gg=g, bb=b: (gg, bb.extrinsics, bb.intrinsics, bb.near, bb.far, bb.image_shape)
+    with torch.no_grad():
+        exact = d.forward(*args())                                   # exact mode: no plan, no graph
+    assert not d._graphs
+    d.max_pairs = spf.plan_pair_budget(d.last_call, check="deferred")
+    return spf, dec, b, d, g, args, exact
+
+
+def test_second_call_is_captured_and_results_are_the_callers(hip_lib):
+    spf, dec, b, d, g, args, exact = _setup()
+    with torch.no_grad():
+        o1 = d.forward(*args())                                      # first sight of the key: launched as usual
+        assert not d._graphs
+        o2 = d.forward(*args())                                      # second: captured, then replayed
+        assert len(d._graphs) == 1
+        o3 = d.forward(*args())                                      # replay
+        out4, alpha4, radii4 = d.render(*args())                     # replay, all four outputs
+    assert len(d._graphs) == 1 and spf.plan_flags(d.last_call) == 0
+    for o in (o1, o2, o3, out4):
+        assert torch.equal(o.color, exact.color) and torch.equal(o.depth, exact.depth)
+    # nothing a call returned aliases anything a later call returned or the graph's own buffers
+    ptrs = {o.color.data_ptr() for o in (o1, o2, o3, out4)} | {o.depth.data_ptr() for o in (o1, o2, o3, out4)}
+    assert len(ptrs) == 8
+    held = o2.color.clone()
+    with torch.no_grad():
+        b.extrinsics[0, 0, 0, 3] += 0.05                             # same address, new content: the replay must see it
+        moved = d.forward(*args())
+        d.eval_graphs = False
+        moved_eager = d.forward(*args())
+        d.eval_graphs = True
+    assert torch.equal(o2.color, held)                               # the earlier result did not change under the caller
+    assert torch.equal(moved.color, moved_eager.color) and not torch.equal(moved.color, exact.color)
+    assert float(alpha4.min()) >= 0.0 and radii4.dtype == torch.int32 and radii4.shape == (1, 3, g.means.shape[1])
+
+
+def test_new_addresses_and_gradients_never_replay(hip_lib):
+    spf, dec, b, d, g, args, exact = _setup(seed=10)
+    with torch.no_grad():
+        d.forward(*args()); d.forward(*args())
+        assert len(d._graphs) == 1
+        g2 = dec.Gaussians(*(t.clone() for t in (g.means, g.covariances, g.rotations, g.scales, g.harmonics, g.opacities)))
+        g2.opacities.mul_(0.5)
+        other = d.forward(*args(g2))                                 # other tensors: another key, launched as usual
+        d.eval_graphs = False
+        want = d.forward(*args(g2))
+        d.eval_graphs = True
+    assert len(d._graphs) == 1 and torch.equal(other.color, want.color)
+    # a call that will be differentiated never comes near the cache
+    ext = b.extrinsics.clone().requires_grad_(True)
+    out = d.forward(g, ext, b.intrinsics, b.near, b.far, b.image_shape)
+    out.color.mean().backward()
+    assert ext.grad is not None and bool(torch.isfinite(ext.grad).all()) and len(d._graphs) == 1
+    d.clear_eval_graphs()
+    assert not d._graphs
+
+
+def test_replayed_call_whose_plan_fails_is_rerun_in_exact_mode(hip_lib):
+    """check="backward" plans are verified after the replay (one host read); a plan that does not hold for the inputs
+    of THIS call -- here: bins of 2 entries -- gives the exact-mode result, not NaN."""
+    spf, dec, b, d, g, args, exact = _setup(seed=11)
+    d.max_pairs = d.max_pairs._replace(check="backward")
+    with torch.no_grad():
+        d.forward(*args()); d.forward(*args())
+        ok = d.forward(*args())
+        assert torch.equal(ok.color, exact.color)
+        d.clear_eval_graphs()
+        d.max_pairs = d.max_pairs._replace(max_tile_list=2, check="deferred")
+        d.forward(*args()); bad = d.forward(*args())
+        assert spf.plan_flags(d.last_call) & 2 and len(d._graphs) == 1   # deferred: NaN images, flag readable
+        assert bool(torch.isnan(bad.color).all())
+        d.clear_eval_graphs()
+        d.max_pairs = d.max_pairs._replace(check="backward")
+        with pytest.raises(spf._lib.SpfError):
+            d.forward(*args())                                       # first sight, launched as usual: raises as ever
+        fixed = d.forward(*args())                                   # second: captured, replayed, verified, re-run exactly
+        assert torch.equal(fixed.color, exact.color)

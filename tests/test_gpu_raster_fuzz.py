@@ -26,13 +26,25 @@ def _random_case(seed: int):
     return batch, bg, si, dict(S=S, V=V, K=K, G=G, hw=hw, s_mult=s_mult, si=si)
 
 
+# Knife-edge budget per seed: TWICE the fraction of pixels the float64 oracle flags on that seed (measured on the CPU,
+# round 5; the mask is the oracle's alone), at least 0.2 % (one pixel of a 500-pixel image).  Rounds 2 - 4 allowed every
+# in-suite seed 10 % -- the campaigns' "inconclusive" threshold -- while the fixed cases were capped at 0.2 - 0.5 %.
+FRAGILE_MEASURED = {100: 3.0e-4, 102: 5.6e-4, 104: 1.2e-4, 105: 8.2e-5, 106: 5.7e-3, 111: 1.9e-5, 112: 2.9e-2,
+                    114: 2.2e-4, 115: 5.3e-3, 248: 1.62e-2, 275: 1.21e-2,
+                    "wide2135": 2.02e-2, "wide2195": 1.03e-2, "wide2389": 3.75e-2, "wide170586": 2.5e-2,
+                    "wide260130": 2.43e-2}      # (seeds not listed: nothing flagged)
+
+
+def fragile_cap(key) -> float:
+    return max(2.0 * FRAGILE_MEASURED.get(key, 0.0), 0.002)
+
+
 @pytest.mark.parametrize("seed", list(range(100, 116)) + [204, 248, 275])   # + an empty render, huge splats, an SH clamp edge
 def test_random_configurations(hip_lib, seed):
     batch, bg, si, desc = _random_case(seed)
     ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True)
     prod = util.run_product(batch, background=bg, scale_invariant=si, pixel_mask=ref["pixel_mask"])
-    # (tiny images under splats hundreds of pixels wide: up to a tenth of the pixels can sit on a knife edge)
-    rep = util.compare(prod, ref, max_fragile_frac=0.10)
+    rep = util.compare(prod, ref, max_fragile_frac=fragile_cap(seed))
     assert not rep["fails"], (desc, rep)
 
 
@@ -44,7 +56,7 @@ def _wide_case(seed):
     batch, bg, si, band4, _planned, desc = fc.random_case(seed, wide=True)
     ref = util.run_oracle(batch, torch.float64, background=bg, scale_invariant=si, mask_fragile=True, band4=band4)
     prod = util.run_product(batch, background=bg, scale_invariant=si, pixel_mask=ref["pixel_mask"], band4=band4)
-    rep = util.compare(prod, ref, max_fragile_frac=0.10)
+    rep = util.compare(prod, ref, max_fragile_frac=fragile_cap(f"wide{seed}"))
     return batch, bg, si, band4, desc, ref, rep
 
 
@@ -63,3 +75,23 @@ def test_wide_seeds_that_exposed_the_float32_determinant(hip_lib, seed):
         from tests.test_gpu_raster import _report
         _report("wide_seed_2135", rep)
     assert not rep["fails"], (desc, rep)
+
+
+@pytest.mark.parametrize("seed", [170586, 260130])
+def test_wide_seeds_at_the_edge_of_the_per_element_gate(hip_lib, seed):
+    """The two disagreements of round 4's fuzz campaigns (profiles/r04_fuzz_campaign_b.json, _e.json; 34,909 cases):
+    world scale 250, ONE entry of dL/dmeans that is >= 1 % of the tensor's largest off by 2.9e-2 / 1.6e-2 of itself
+    (gate `gel_means` 1e-2 -- an addition of this suite to north_star's 1e-3-of-scale gate, which both cases meet:
+    7.2e-4 / 1.8e-4), everything else inside its gate.  They lived only in a JSON; here they are named cases that
+    report the product's error NEXT TO the error of the same restatement evaluated in float32 on the CPU
+    (`util.float32_resolvable`: same masks, same gates), and every gate except that one is enforced.  The float32
+    oracle's own `gel_means` on these inputs depends on the summation order (6.7e-3 / 1.0e-3 with 8 threads; above the
+    gate on the 256-core host that classified them "unresolvable" in round 4), so it is reported, not used as a bound;
+    the product's entry is held at 1.5 x what the campaigns measured."""
+    batch, bg, si, band4, desc, ref, rep = _wide_case(seed)
+    f32 = util.float32_resolvable(batch, ref, background=bg, scale_invariant=si, band4=band4)
+    from tests.test_gpu_raster import _report
+    _report(f"wide_seed_{seed}", {**rep, **{"oracle_f32_" + k: v for k, v in f32.items() if k.startswith(("g_", "gel_", "rgb_max"))}})
+    assert set(rep["fails"]) <= {"gel_means"}, (desc, rep)
+    assert rep["gel_means"] <= 1.5 * {170586: 2.9e-2, 260130: 1.6e-2}[seed], (desc, rep, f32)
+    assert rep["g_means"] <= 1e-3

@@ -54,3 +54,17 @@ def test_oracle_matches_vggt_reference_rope(goldens):
         tok = c["tokens_BHND"].transpose(1, 2).contiguous()
         got = util.rope_oracle(tok, c["positions"], c["frequency"], 1.0).transpose(1, 2)
         assert float((got - c["out_BHND"]).abs().max()) <= 1e-5, name
+
+
+def test_torch_restatement_of_the_fallback_matches_the_reference_module(goldens):
+    """oracle/rope_torch_ref.py (bench.py's second rope2d CPU baseline) restates the reference's fallback class
+    pos_embed.py:112-159; the goldens hold that class's own outputs -- same torch ops, so bit-near identical."""
+    from oracle import rope_torch_ref
+    for name, c in goldens["cases"].items():
+        if c["F0"] != 1.0:
+            continue                                 # (the fallback module ignores F0 in its tables: pos_embed.py:120-129)
+        cache = {}
+        got = rope_torch_ref.rope2d_fallback(c["tokens_BHND"], c["positions"], c["base"], cache)
+        assert float((got - c["out_fallback_BHND"]).abs().max()) <= 1e-6, name
+        again = rope_torch_ref.rope2d_fallback(c["tokens_BHND"], c["positions"], c["base"], cache)   # cached tables
+        assert torch.equal(again, got) and len(cache) == 1

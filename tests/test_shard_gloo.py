@@ -123,7 +123,9 @@ def test_single_process_is_a_no_op():
 
 def test_grad_bucket_layout():
     """Five contiguous, 16-byte aligned views of one flat buffer, in the documented order; `take` hands out aliases of
-    them only for a matching shape; nothing is active outside a `with` block."""
+    them -- each ONCE per `with` block, and only for the tensor the bucket was built for (a second backward
+    under one block used to overwrite the first one's gradient silently, a mismatched shape used to fall back to a
+    fresh buffer that the all-reduce never saw); nothing is active outside a `with` block."""
     S, G, K = 2, 5, 4
     t = [torch.zeros(S, G, 3), torch.zeros(S, G, 3), torch.zeros(S, G, 4), torch.zeros(S, G), torch.zeros(S, G, 3, K)]
     b = shard.GradBucket(*t)
@@ -135,8 +137,21 @@ def test_grad_bucket_layout():
         assert v.shape == like.shape and v.is_contiguous() and (v.data_ptr() - base) % 16 == 0
         a = b.take(name, like)
         assert a is not v and a.data_ptr() == v.data_ptr()
-    assert b.take("means", torch.zeros(S, G + 1, 3)) is None
+    import pytest
+    with pytest.raises(RuntimeError, match="already written"):
+        b.take("means", t[0])                                   # a second backward under the same block
+    assert b.take("colors", torch.zeros(S, G, 3)) is None       # not a bucket tensor: the caller allocates
     assert shard.active_bucket() is None
     with b:
-        assert shard.active_bucket() is b
+        assert shard.active_bucket() is b and not b.taken       # entering the block starts a new backward
+        with pytest.raises(RuntimeError, match="built for"):
+            b.take("harmonics", torch.zeros(S, G, K, 3))        # the other SH layout: loud, not a silent fresh buffer
+        with pytest.raises(RuntimeError, match="no backward wrote"):
+            b.all_reduce()
+        b.flat.fill_(7.0)
+        assert b.take("means", t[0]) is not None
+        b.all_reduce()                                          # (no process group here: returns after the zero fill)
+        assert float(b.views["means"].min()) == 7.0 and float(b.views["scales"].abs().max()) == 0.0
+        with pytest.raises(RuntimeError, match="already active"):
+            b.__enter__()
     assert shard.active_bucket() is None

@@ -149,8 +149,8 @@ def main():
         # `disagreements` is the number to read: every case in which the product misses a gate the float64 oracle sets,
         # whether or not a float32 evaluation of the oracle misses it too (`of_which_float32_unresolvable` says how many
         # of them no float32 evaluation resolves -- an explanation, not an exemption)
-        summary = {"summary": True, "cases": n, "disagreements": bad + unres, "failed": bad,
-                   "of_which_float32_unresolvable": unres, "inconclusive": vague,
+        summary = {"summary": True, "cases": n, "disagreements": bad + unres, "failed_or_unresolvable": bad + unres,
+                   "failed": bad, "of_which_float32_unresolvable": unres, "inconclusive": vague,
                    "seconds": round(time.time() - t0, 1), "worst": worst}
         f.write(json.dumps(summary) + "\n")
     print(json.dumps(summary))
