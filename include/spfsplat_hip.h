@@ -47,7 +47,11 @@ extern "C" {
 #define SPF_E_CAPACITY (-3)  /* pair buffer smaller than the number of (Gaussian, tile) pairs */
 
 #define SPF_UNKNOWN 0xffffffffu
-#define SPF_TILE 16          /* square tile edge in pixels */
+#ifndef SPF_TILE
+#define SPF_TILE 16          /* square tile edge in pixels: 16 (four waves per tile, render.hip) or 8 (one wave per tile,
+                                render_wave.hip; -DSPF_TILE=8 builds the whole library -- projection, bins, sort, compositing
+                                -- on the 8 px grid).  spf_raster_num_tiles() tells a host which grid the library was built for */
+#endif
 #define SPF_DENSE_AREA 26    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
 
 /* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.

@@ -420,7 +420,8 @@ constexpr uint32_t kHistCountShift = 20u, kHistAreaMask = (1u << 20) - 1u;
 // views whose histograms fit the LDS budget at once (the loop flushes between groups)
 // (direct bins: a group also holds the bins' base offsets [VG][T] and every thread's (rect, depth) per view)
 __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false) {
-    const int fit = direct ? (36 * 1024) / (8 * T + 2048) : (32 * 1024) / (4 * T);
+    // (8 px grid: four times the tiles per render -- a budget that still holds the four views of the headline batch)
+    const int fit = direct ? ((kTile == 8 ? 44 : 36) * 1024) / (8 * T + 2048) : (32 * 1024) / (4 * T);
     return fit < 1 ? 1 : (fit < V ? fit : V);
 }
 

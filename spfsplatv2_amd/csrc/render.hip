@@ -1104,6 +1104,10 @@ extern "C" int spf_debug_phase_cycles(unsigned long long* out8, int reset) {
 #endif
 
 // ---- launchers ------------------------------------------------------------------------------------
+hipError_t launch_render_fwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, int, int,
+                                  const TileLists&, hipStream_t);                     // render_wave.hip
+hipError_t launch_render_bwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int,
+                                  const TileLists&, hipStream_t);
 uint32_t dense_threshold() {
     static const uint32_t v = getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA;
     return v;
@@ -1159,6 +1163,7 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     const TileLists tl = tile_lists(st, d);
     TileLists tlo = tl;                           // (the lists kernel only: the rows kernel keeps the image order)
     if (ordered) tlo.order = tile_order_ptr(st, d, RT);
+    if (kTile == 8) return launch_render_fwd_wave(d, in, st, out, T, tiles_x, tlo, stream);   // one wave per 8x8 tile
     const int grid = (RT + 7) / 8 * 8;
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
     AuxStream* a = nullptr;
@@ -1213,6 +1218,11 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
                              int tiles_x, uint32_t dense_hint, uint64_t capacity, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
+    if (kTile == 8) {
+        TileLists tlo = tile_lists(st, d);
+        if (ordered) tlo.order = tile_order_ptr(st, d, RT);
+        return launch_render_bwd_wave(d, in, st, g, T, tiles_x, tlo, stream);
+    }
     if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
     else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
     return hipGetLastError();

@@ -91,10 +91,9 @@ __device__ __forceinline__ void rope_sincos(float x, float& s, float& c) {
 // rows.  Consecutive lanes walk the frequencies, then the half, so at every step of the head loop a group of 2*Q/EPL
 // lanes covers one contiguous head row.  `tokens2` (may be null): a second tensor of the same shape / strides /
 // positions rotated in the same launch with the same angles (q and k of one attention layer, croco/blocks.py:102-104).
-// HEADS is picked per launch (launch_rope_t): four for tensors that fill the chip with waves anyway, two for the small
-// ones -- the reference's decoder shape (32,258,12,64) in fp16 is 1.5 waves per SIMD at four heads per lane, a launch
-// that runs as long as its memory latency chain.  Every token row a lane will rotate is REQUESTED before the angles are
-// evaluated (the loads do not depend on them), and index arithmetic is 32-bit whenever the launch allows (I).
+// HEADS is picked per launch (launch_rope_t: four, see rope_heads).  Every token row a lane will rotate is REQUESTED
+// before the angles are evaluated (the loads do not depend on them), and index arithmetic is 32-bit whenever the launch
+// allows (I).
 template <typename T, int HEADS, typename I>
 __global__ __launch_bounds__(kBlock) void spf_rope2d_vec_kernel(T* __restrict__ tokens, T* __restrict__ tokens2,
                                                                 const int64_t* __restrict__ pos, int N, int H, int D,
@@ -190,12 +189,15 @@ static void launch_rope_vec(void* tokens, void* tokens2, const int64_t* pos, int
             static_cast<T*>(tokens), static_cast<T*>(tokens2), pos, N, H, D, sb, sn, sh, pos_div, f, total);
 }
 
-// heads per lane (see the kernel): 4 when that still gives every SIMD of the chip four waves, else 2; SPF_ROPE_HEADS=1/2/4
-// pins it (experiments)
+// heads per lane (see the kernel): 4.  Measured (round 5, 50 dependent calls per HIP graph, us per call, heads 1 / 2 / 4):
+// (32,258,12,64) fp16 8.4 / 7.6 / 7.2, fp32 9.4 / 7.5 / 7.6; (48,256,16,64) fp16 12.3 / 10.3 / 10.1, fp32 19.4 / 16.8 / 15.9 --
+// fewer, fatter lanes win or tie everywhere, also where four heads per lane leave the chip 1.5 waves per SIMD (the small
+// shapes run at the ~7 us floor of a dependent launch either way).  SPF_ROPE_HEADS=1/2/4 pins it (experiments).
 static int rope_heads(size_t lanes_at_4) {
     static const int forced = getenv("SPF_ROPE_HEADS") ? atoi(getenv("SPF_ROPE_HEADS")) : 0;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return lanes_at_4 >= (size_t)256 * 4 * 4 * kWave ? 4 : 2;
+    (void)lanes_at_4;
+    return 4;
 }
 
 template <typename T>

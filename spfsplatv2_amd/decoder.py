@@ -242,8 +242,9 @@ class DecoderSplattingCUDACfg:
 
 
 class _EvalGraph:
-    """One captured evaluation call of a decoder: the graph, the tensors it writes (color, depth, alpha, radii -- owned
-    by the graph's memory pool) and the call record whose `counters` it refreshes."""
+    """One captured evaluation call of a decoder: the graph, the tensors it writes (colour and depth packed into one
+    flat buffer, alpha, radii -- owned by the graph's memory pool) and the call record whose `counters` it
+    refreshes."""
     __slots__ = ("graph", "outputs", "record")
 
     def __init__(self, graph, outputs, record):
@@ -314,15 +315,15 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         dense float32 device tensor (what the kernels take without a copy), no capture already going on."""
         if not (self.eval_graphs and isinstance(self.max_pairs, PairBudget)) or os.environ.get("SPF_EVAL_GRAPHS", "1") == "0":
             return None
-        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-            return None
-        if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
-            return None
+        grad = torch.is_grad_enabled()
+        for t in tensors:
+            if (grad and t.requires_grad) or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                return None
         if torch.cuda.is_current_stream_capturing():
             return None
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
-        return (tuple((t.data_ptr(), tuple(t.shape)) for t in tensors), tuple(image_shape), self.max_pairs, band4,
-                self.background_color.data_ptr(), self.make_scale_invariant)
+        return (tuple([t.data_ptr() for t in tensors]), tuple([t.shape for t in tensors]), tuple(image_shape),
+                self.max_pairs, band4, self.background_color.data_ptr(), self.make_scale_invariant)
 
     def render(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
                image_shape: tuple[int, int]):
@@ -354,8 +355,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         else:
             self._graph_unused = 0
         entry.graph.replay()
-        self.last_call.clear()
-        self.last_call.update(entry.record)
+        self.last_call = entry.record
         if self.max_pairs.check != "deferred":
             from .rasterizer import plan_flags
             if plan_flags(entry.record) != 0:
@@ -364,11 +364,17 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
                                                                     image_shape, None, self.last_call)
                 return DecoderOutput(color, depth), alpha, radii
-        color, depth, alpha, radii = entry.outputs
-        # (copies: what the caller gets is the caller's; the graph's own buffers are rewritten by its next replay)
+        flat, alpha, radii = entry.outputs
+        # ONE copy-out: what the caller gets is the caller's (the graph's own buffers are rewritten by its next replay);
+        # colour and depth were packed into one flat buffer inside the graph
+        mine = flat.clone()
+        b, v = extrinsics.shape[:2]
+        h, w = image_shape
+        nc = b * v * 3 * h * w
+        out = DecoderOutput(mine[:nc].view(b, v, 3, h, w), mine[nc:].view(b, v, h, w))     # both contiguous, as ever
         if not want_extra:
-            return DecoderOutput(color.clone(), depth.clone()), None, None
-        return DecoderOutput(color.clone(), depth.clone()), alpha.clone(), radii.clone()
+            return out, None, None
+        return out, alpha.clone(), radii.clone()
 
     def _capture(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "_EvalGraph":
         while len(self._graphs) >= self._EVAL_GRAPH_SLOTS:
@@ -376,8 +382,10 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         record = CallRecord()
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            outputs = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape, self.max_pairs, record)
-        entry = _EvalGraph(graph, outputs, record)
+            color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
+                                                            self.max_pairs, record)
+            flat = torch.cat((color.reshape(-1), depth.reshape(-1)))     # one buffer to copy out per call
+        entry = _EvalGraph(graph, (flat, alpha, radii), record)
         self._graphs[key] = entry
         self._graph_seen.pop(key, None)
         self._graph_unused += 1
