@@ -513,12 +513,23 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             radius = ceilf(3.0f * sqrtf(lam));
             ok = isfinite(pr.px) && isfinite(pr.py) && isfinite(radius);
             if (ok) {
-                const float fgx = (float)tiles_x, fgy = (float)tiles_y;
-                x0 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px - radius) * (1.0f / kTile))));
-                y0 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py - radius) * (1.0f / kTile))));
-                x1 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px + radius + (kTile - 1)) * (1.0f / kTile))));
-                y1 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py + radius + (kTile - 1)) * (1.0f / kTile))));
+                // The 3-sigma rect is part of the SEMANTICS: a Gaussian reaches exactly the pixels
+                // of the 16 px tiles its radius box touches -- also pixels beyond the radius inside those tiles -- and is
+                // culled (radii = 0) when it touches none.  So the rect is always taken on the 16 px grid; a build on the
+                // 8 px grid (kTile == 8) then covers the same pixels with twice the tiles per side (the cull-disc shrink
+                // below is exact at any granularity).
+                constexpr int kSemTile = 16;
+                const float fgx = (float)((d.W + kSemTile - 1) / kSemTile), fgy = (float)((d.H + kSemTile - 1) / kSemTile);
+                x0 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px - radius) * (1.0f / kSemTile))));
+                y0 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py - radius) * (1.0f / kSemTile))));
+                x1 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px + radius + (kSemTile - 1)) * (1.0f / kSemTile))));
+                y1 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py + radius + (kSemTile - 1)) * (1.0f / kSemTile))));
                 ok = (x1 - x0) * (y1 - y0) > 0;
+                if (kTile != kSemTile) {
+                    constexpr int f = kSemTile / kTile;
+                    x0 = min(tiles_x, f * x0); x1 = min(tiles_x, f * x1);
+                    y0 = min(tiles_y, f * y0); y1 = min(tiles_y, f * y1);
+                }
             }
         }
         float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = make_float4(0.f, 0.f, 0.f, -1.f), rec2 = rec0;

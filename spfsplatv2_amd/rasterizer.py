@@ -85,7 +85,7 @@ class PairBudget(NamedTuple):
     check: str = "backward"
 
 
-_SORT_CLASSES = (128, 256, 512, 1024, 2048, 8192, 16384)
+_SORT_CLASSES = (128, 256, 512, 1024, 2048, 4096, 8192, 16384)
 
 
 def plan_pair_budget(stats: Optional[dict] = None, slack: float = 1.25, check: str = "backward") -> PairBudget:
@@ -318,17 +318,18 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 def _direct_bin_cap(max_pairs, RT: int, T: int) -> int:
     """Bin size of a planned call that runs with DIRECT BINS (0: packed lists, the classic chain).  Needs a plan with a
     list-length class (PairBudget.max_tile_list), the per-render tile histogram in LDS (the library's limit,
-    spf_raster_max_lds_tiles) and bins that stay in proportion to the plan: R*T*cap keys <= 4 x the planned pairs (a
-    coarse list class on a many-tile call would otherwise hold ten times the classic chain's memory until the backward;
-    small calls may use up to 2^22 keys = 32 MiB regardless) and <= 2^27 in any case; `SPF_DIRECT_BINS=0` pins the
-    classic chain (A/B runs)."""
+    spf_raster_max_lds_tiles) and bins that stay in proportion to the plan: R*T*cap keys <= 8 x the planned pairs (a
+    coarse list class on a many-tile call would otherwise hold far more than the classic chain's memory until the
+    backward; calls may use up to 2^24 keys = 128 MiB regardless: BASELINE config 3's eight renders of ~1,700-entry lists
+    sit in 4,096-entry bins, 6 x their pairs) and <= 2^27 in any case; `SPF_DIRECT_BINS=0` pins the classic chain (A/B
+    runs)."""
     if max_pairs is None or os.environ.get("SPF_DIRECT_BINS", "1") == "0":
         return 0
     cap = max_pairs.max_tile_list if isinstance(max_pairs, PairBudget) else 0
     if cap <= 0 or T > _lib.load().spf_raster_max_lds_tiles():
         return 0
     keys = RT * cap
-    if keys > (1 << 27) or keys > max(4 * int(max_pairs.capacity), 1 << 22):
+    if keys > (1 << 27) or keys > max(8 * int(max_pairs.capacity), 1 << 24):
         return 0
     return int(cap)
 
