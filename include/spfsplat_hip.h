@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SPF_ABI_VERSION 4
+#define SPF_ABI_VERSION 5
 
 #define SPF_OK 0
 #define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
@@ -138,6 +138,13 @@ typedef struct SpfState {
     uint32_t* pair_cursor; /* [8]       direct bins only (may be NULL otherwise): cursors of the pair numbering, ZERO on
                                         entry of spf_raster_forward_project* (spf_decoder_prepare clears them when they
                                         lie inside the buffer it is given) */
+    uint8_t* sh_clamp;     /* [R*G]     SH colours only (may be NULL with colors_precomp): bit c = colour channel c of this
+                                        (render, Gaussian) was clamped at 0 by the forward (such a
+                                        channel passes no gradient).  Written by spf_raster_forward_project*, read by
+                                        spf_raster_backward for sh_degree >= 1 -- the backward contracts dL/dcolour with the
+                                        coefficients BEFORE the basis derivatives (three accumulators instead of twelve: the
+                                        degree-4 kernel fits two waves per SIMD) and so needs the clamp decision up front
+                                        instead of re-evaluating the colour */
 } SpfState;
 
 typedef struct SpfOutputs {

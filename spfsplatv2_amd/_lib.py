@@ -12,7 +12,7 @@ from pathlib import Path
 
 # SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
 LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
                "project_bwd", "rope2d")
@@ -34,7 +34,7 @@ SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opaciti
                                       "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
-                                    "n_contrib", "pair_cursor"])
+                                    "n_contrib", "pair_cursor", "sh_clamp"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
 SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",

@@ -174,6 +174,7 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
     c.st.tile_flags = off(st.tile_flags, r * T); c.st.pair_off = off(st.pair_off, 2 * r * G);
     c.st.blk_total = off(st.blk_total, r * nblk); c.st.blk_base = off(st.blk_base, r * nblk);
     c.st.final_T = off(st.final_T, r * P); c.st.n_contrib = off(st.n_contrib, r * P);
+    c.st.sh_clamp = off(st.sh_clamp, r * G);
     if (out) {
         c.out.image = off(out->image, 3 * r * P); c.out.depth = off(out->depth, r * P);
         c.out.alpha = off(out->alpha, r * P);
@@ -309,6 +310,7 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     if (!st || !st->rec || !st->radii || !st->rect || !st->zkey || !st->tile_count || !st->tile_start ||
         !st->tile_fill || !st->tile_flags || !st->counters || !st->blk_total || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
+    if (in->shs && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp is needed by forward_project when shs are given");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
@@ -480,6 +482,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
     if (!g || !g->gpair || !g->dL_dmeans3D || !g->dL_dopacities)
         return fail(SPF_E_INVALID, "gpair, dL_dmeans3D and dL_dopacities are required");
+    if (in->shs && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp (written by the forward) is needed by backward when shs are given");
     if (g->dL_dviewmatrix && !g->vpartial) return fail(SPF_E_INVALID, "vpartial is required with dL_dviewmatrix");
     if ((g->dL_dscales == nullptr) != (g->dL_drotations == nullptr))
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");

@@ -946,8 +946,8 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
     return hipGetLastError();
 }
 
-// Size classes: (1, 512]: one wave per tile, list in registers; (512, 1024], (1024, 2048]: one 256-thread block per tile, list in
-// registers, three LDS exchanges; (2048, 8192], (8192, 16384]: one 1024-thread
+// Size classes: (1, 512]: one wave per tile, list in registers; (512, 1024], (1024, 2048], (2048, 4096]: one 256-thread block
+// per tile, list in registers, three LDS exchanges; (4096, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 // `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family).
 // `tl`: where the lists are (packed, or direct bins: then the family's first kernel also verifies the planned dense-tile
@@ -996,8 +996,16 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
     if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread
         spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 1024);
-    if (mx > 2048)
+    // 2049 .. 4096: one 256-thread block per tile, SIXTEEN keys per thread in registers (each wave sorts its 1,024 keys
+    // with lane exchanges, the last two merges start with three exchanges through LDS) -- round 5: the reference's
+    // 10-view shape is 768 tiles of ~2,800 entries, ALL in this class, and the all-LDS network below took 74 us for them
+    // (78 barrier-separated passes of 1,024 threads); 4097 .. 8192 stay with it
+    if (mx > 2048 && !getenv("SPF_SORT_LDS_2K"))
+        spf_sort_tiles_block_kernel<16><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 2048);
+    if (mx > 2048 && getenv("SPF_SORT_LDS_2K"))
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 2048, 8192);
+    else if (mx > 4096)
+        spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 4096, 8192);
     if (mx > 8192) {
         // the opt-in to 128 KB of dynamic LDS is a per-DEVICE function attribute: remember it per device
         static std::atomic<bool> attr_set[64];          // (zero-initialised; the attribute is idempotent, so two host

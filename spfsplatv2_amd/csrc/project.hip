@@ -298,10 +298,35 @@ __device__ __forceinline__ void sh_accumulate(int k, const ShDir& dir, const flo
         }
     }
 }
-template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD>
+#ifndef SPF_SH_BURST
+#define SPF_SH_BURST 0      // (experiment, forward kernel only: 1 = request a Gaussian's whole coefficient block at once)
+#endif
+template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD, bool BURST = false>
 __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const ShDir& dir, float col[3],
                                             float Dx[3], float Dy[3], float Dz[3]) {
     constexpr int NV = NB / 4;
+    if (BURST && NV > 1) {
+        // Every 16-byte piece of the block requested back to back (3 * NB registers: the forward kernel has them at two
+        // waves per SIMD).  A lane's block is 12 * K bytes at a 12 * K byte stride: group by group, double-buffered, a
+        // 128-byte line is asked for again a whole group later -- after it has left the 32 KB L1 (eight waves x 64 rows
+        // of ~2.3 lines each) -- and comes from the L2 up to eight times.
+        float v[NV > 0 ? NV : 1][4][3];
+#pragma unroll
+        for (int k4 = 0; k4 < NV; ++k4) sh_load4<NATIVE, ALIGNED>(sh, K, k4, v[k4]);
+        float tail[NB - 4 * NV > 0 ? NB - 4 * NV : 1][3];
+#pragma unroll
+        for (int k = 4 * NV; k < NB; ++k) {
+            tail[k - 4 * NV][0] = sh_at<NATIVE>(sh, K, k, 0); tail[k - 4 * NV][1] = sh_at<NATIVE>(sh, K, k, 1);
+            tail[k - 4 * NV][2] = sh_at<NATIVE>(sh, K, k, 2);
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < NV; ++k4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[k4][i], col, Dx, Dy, Dz);
+#pragma unroll
+        for (int k = 4 * NV; k < NB; ++k) sh_accumulate<WITH_GRAD>(k, dir, tail[k - 4 * NV], col, Dx, Dy, Dz);
+        return;
+    }
     if (NV <= 1) {
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
@@ -328,6 +353,39 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K,
     for (int k = 4 * NV; k < NB; ++k) {
         const float v[3] = {sh_at<NATIVE>(sh, K, k, 0), sh_at<NATIVE>(sh, K, k, 1), sh_at<NATIVE>(sh, K, k, 2)};
         sh_accumulate<WITH_GRAD>(k, dir, v, col, Dx, Dy, Dz);
+    }
+}
+// Direction gradient of the SH colour with dL/dcolour contracted FIRST:  dd = sum_k grad basis_k(dir) * (sh_k . g).
+// Three accumulators (sh_contract<WITH_GRAD> carries sum_k grad basis_k sh_k[c] per channel -- nine -- plus the colour
+// itself, because it learns which channels the forward clamped only at the end of the pass; here `g` already has those
+// channels zeroed, from SpfState.sh_clamp).  Round 5: 255 -> 227 VGPRs at degree 3, 348 -> 256 at degree 4 (two waves
+// per SIMD instead of one).
+template <int NB, bool NATIVE, bool ALIGNED>
+__device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ sh, int K, const ShDir& dir,
+                                                      const float g[3], float dd[3]) {
+    constexpr int NV = NB / 4;
+    auto acc = [&](int k, const float v[3]) {
+        float gx, gy, gz;
+        (void)sh_term<true>(k, dir, gx, gy, gz);
+        const float sk = v[0] * g[0] + v[1] * g[1] + v[2] * g[2];
+        if (sh_has_gx(k)) dd[0] += gx * sk;
+        if (sh_has_gy(k)) dd[1] += gy * sk;
+        if (sh_has_gz(k)) dd[2] += gz * sk;
+    };
+    // groups of four coefficients, double-buffered by hand behind a compiler barrier (see sh_contract)
+    float v[2][4][3];
+    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, K, 0, v[0]);
+#pragma unroll
+    for (int k4 = 0; k4 < NV; ++k4) {
+        if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, K, k4 + 1, v[(k4 + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc(4 * k4 + i, v[k4 & 1][i]);
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int k = 4 * NV; k < NB; ++k) {
+        const float t[3] = {sh_at<NATIVE>(sh, K, k, 0), sh_at<NATIVE>(sh, K, k, 1), sh_at<NATIVE>(sh, K, k, 2)};
+        acc(k, t);
     }
 }
 // dL/dsh_k = sum over the parked views of basis_k(direction_v) * dL/dcolour_v: evaluated group by group at the END of
@@ -409,7 +467,7 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #define SPF_PFWD_BPC 1
 #endif
 #ifndef SPF_PBWD_DEG4_BPC
-#define SPF_PBWD_DEG4_BPC 1   // (experiment: 2 caps the degree-4 backward at 256 VGPRs -- 96 of them spilled)
+#define SPF_PBWD_DEG4_BPC 2   // (round 4: 348 VGPRs, the cap spilled 96 of them; round 5: 256 with the contracted direction gradient)
 #endif
 #ifndef SPF_PABL
 #define SPF_PABL 0      // profiling builds of the BACKWARD kernel only (-DSPF_PABL=5..9: gather / partials / stores / SH cut out)
@@ -535,6 +593,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = make_float4(0.f, 0.f, 0.f, -1.f), rec2 = rec0;
         uint32_t rect_w = 0u, area = 0u;
         float zk = 0.f;
+        int clamp_out = 0;                  // colour channels clamped at 0 (SpfState.sh_clamp: the backward's copy)
         if (ok) {
             // colour
             float col[3];
@@ -551,8 +610,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 const ShDir sd = sh_dir(dir[0] * inv, dir[1] * inv, dir[2] * inv);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
                 col[0] = col[1] = col[2] = 0.f;
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
-                else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false, SPF_SH_BURST != 0>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false, SPF_SH_BURST != 0>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -592,6 +651,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             rec0 = make_float4(pr.px, pr.py, cA, cB);
             rec1 = make_float4(cC, opac, pr.tz, cull_r2);
             rec2 = make_float4(col[0], col[1], col[2], __int_as_float(clampmask));
+            clamp_out = clampmask;
             area = disc_area_capped_fast(pr.px, pr.py, cull_r2);
         }
         if (live) {
@@ -599,6 +659,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             //  instructions but measured 10 % SLOWER on the SH-heavy forwards -- K = 16: 139 -> 152 us, K = 25: 167 -> 187)
             const size_t rg_ = (size_t)r * d.G + g;
             st.radii[rg_] = ok ? (int)radius : 0;
+            if (DEG >= 1) st.sh_clamp[rg_] = (uint8_t)clamp_out;            // (degree 0: the backward re-evaluates the one term)
             if (!direct) { st.rect[rg_] = rect_w; st.zkey[rg_] = zk; }      // (direct bins: parked below, binned by this block)
         }
         if (direct) s_park[(v - v0) * kBlock + threadIdx.x] = make_uint2(rect_w, __float_as_uint(zk));
@@ -966,16 +1027,26 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                 const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
                 const ShDir sd = sh_dir(x, y, z);
                 const float* __restrict__ sh = in.shs + (SPF_PABL == 9 ? (size_t)s * d.G : sg) * (size_t)d.K * 3;
-                // One pass over the coefficient block: re-evaluate the colour exactly as the forward kernel does
-                // (colours clamped at 0 pass no gradient; cheaper than re-reading the 48-byte record) and collect
-                // s_k = sh_k . dL/dcolour for the direction gradient.
-                float col[3] = {0.f, 0.f, 0.f};
-                float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};  // sum_k dbasis_k sh_k[c]
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, (DEG > 0)>(sh, d.K, sd, col, Dx, Dy, Dz);
-                else sh_contract<NB, NATIVE, false, (DEG > 0)>(sh, d.K, sd, col, Dx, Dy, Dz);
+                float dd[3] = {0.f, 0.f, 0.f};
+                if (DEG == 0) {
+                    // one term: re-evaluate the colour exactly as the forward kernel does (a colour clamped at 0 passes
+                    // no gradient)
+                    float col[3] = {0.f, 0.f, 0.f};
+                    if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                    else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
+                    for (int ch = 0; ch < 3; ++ch)
+                        if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
+                } else {
+                    // the forward's clamp decision (one byte per (render, Gaussian)), then ONE pass over the coefficient
+                    // block for the direction gradient, dL/dcolour contracted first (sh_direction_gradient)
+                    const uint32_t cm = st.sh_clamp[rg];
+                    if (cm & 1u) gcol[0] = 0.f;
+                    if (cm & 2u) gcol[1] = 0.f;
+                    if (cm & 4u) gcol[2] = 0.f;
+                    if (d.K % 4 == 0) sh_direction_gradient<NB, NATIVE, true>(sh, d.K, sd, gcol, dd);
+                    else sh_direction_gradient<NB, NATIVE, false>(sh, d.K, sd, gcol, dd);
+                }
                 sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
                 if (!kPark) {
 #pragma unroll
@@ -985,9 +1056,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                         dsh[k][0] += bk * gcol[0]; dsh[k][1] += bk * gcol[1]; dsh[k][2] += bk * gcol[2];
                     }
                 }
-                const float dd[3] = {Dx[0] * gcol[0] + Dx[1] * gcol[1] + Dx[2] * gcol[2],
-                                     Dy[0] * gcol[0] + Dy[1] * gcol[1] + Dy[2] * gcol[2],
-                                     Dz[0] * gcol[0] + Dz[1] * gcol[1] + Dz[2] * gcol[2]};
                 if (DEG > 0) {
                     const float dot = dd[0] * x + dd[1] * y + dd[2] * z;
                     float dv[3] = {(dd[0] - x * dot) * inv, (dd[1] - y * dot) * inv, (dd[2] - z * dot) * inv};

@@ -69,6 +69,7 @@ SpfState make_state(const Tensor& rec, const Tensor& radii, const Tensor& rect, 
     st.pairs = pairs.defined() ? reinterpret_cast<uint64_t*>(pairs.data_ptr()) : nullptr;
     st.pair_off = pi; st.blk_total = pi + 2 * RG; st.blk_base = pi + 2 * RG + RB;      // pair_off: (rect, first pair) per (render, Gaussian)
     st.final_T = ptr<float>(final_T); st.n_contrib = ptr<uint32_t>(n_contrib);
+    st.sh_clamp = rect.numel() > 2 * RG ? reinterpret_cast<uint8_t*>(ptr<uint32_t>(rect) + 2 * RG) : nullptr;   // SH clamp masks ride behind rect | zkey
     return st;
 }
 
@@ -111,7 +112,7 @@ std::tuple<std::vector<Tensor>, std::vector<int64_t>> raster_forward(
     const int64_t nblk = spf_raster_view_partial_blocks((int32_t)G), RB = R * nblk;
     const auto i32 = means3D.options().dtype(at::kInt), f32 = means3D.options().dtype(at::kFloat);
 
-    Tensor rec = at::empty({RG, 12}, f32), radii = at::empty({RG}, i32), rect = at::empty({2 * RG}, i32);
+    Tensor rec = at::empty({RG, 12}, f32), radii = at::empty({RG}, i32), rect = at::empty({2 * RG + (RG + 3) / 4}, i32);
     Tensor pair_idx = at::empty({2 * RG + 2 * RB}, i32), tiles = at::empty({4 * RT + 16}, i32);
     Tensor final_T = at::empty({R * P}, f32), n_contrib = at::empty({R * P}, i32);
     Tensor image = at::empty({S, V, 3, H, W}, f32), depth = at::empty({S, V, 1, H, W}, f32),

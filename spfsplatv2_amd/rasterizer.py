@@ -252,7 +252,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
     rec = torch.empty((R * G, _REC), **f32)
     radii = torch.empty((R * G,), **i32)
-    rect = torch.empty((2 * R * G,), **i32)        # packed tile rect | depth key (float bits)
+    rect = torch.empty((2 * R * G + (R * G + 3) // 4,), **i32)   # packed tile rect | depth key (float bits) | SH clamp masks (bytes)
     nblk = lib.spf_raster_view_partial_blocks(G)
     pair_idx = torch.empty((2 * R * G + 2 * R * nblk,), **i32)   # pair_off (rect, first pair) | blk_total | blk_base
     # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | pair cursors (8) | padding to 16 bytes
@@ -374,7 +374,8 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(tiles[3 * RT + 1:4 * RT + 1]), _ptr(tiles[RT:2 * RT]),
                          _ptr(tiles[4 * RT + 1:4 * RT + 5]), _ptr(pairs),
                          _ptr(pair_idx[:2 * RG]), _ptr(pair_idx[2 * RG:2 * RG + RB]), _ptr(pair_idx[2 * RG + RB:]),
-                         _ptr(final_T), _ptr(n_contrib), _ptr(cursor))
+                         _ptr(final_T), _ptr(n_contrib), _ptr(cursor),
+                         _ptr(rect[2 * RG:]) if rect.numel() > 2 * RG else None)
 
 
 def _raise_if_plan_failed(counters: Tensor, capacity: int, plan=None) -> None:
