@@ -298,35 +298,10 @@ __device__ __forceinline__ void sh_accumulate(int k, const ShDir& dir, const flo
         }
     }
 }
-#ifndef SPF_SH_BURST
-#define SPF_SH_BURST 0      // (experiment, forward kernel only: 1 = request a Gaussian's whole coefficient block at once)
-#endif
-template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD, bool BURST = false>
+template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD>
 __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const ShDir& dir, float col[3],
                                             float Dx[3], float Dy[3], float Dz[3]) {
     constexpr int NV = NB / 4;
-    if (BURST && NV > 1) {
-        // Every 16-byte piece of the block requested back to back (3 * NB registers: the forward kernel has them at two
-        // waves per SIMD).  A lane's block is 12 * K bytes at a 12 * K byte stride: group by group, double-buffered, a
-        // 128-byte line is asked for again a whole group later -- after it has left the 32 KB L1 (eight waves x 64 rows
-        // of ~2.3 lines each) -- and comes from the L2 up to eight times.
-        float v[NV > 0 ? NV : 1][4][3];
-#pragma unroll
-        for (int k4 = 0; k4 < NV; ++k4) sh_load4<NATIVE, ALIGNED>(sh, K, k4, v[k4]);
-        float tail[NB - 4 * NV > 0 ? NB - 4 * NV : 1][3];
-#pragma unroll
-        for (int k = 4 * NV; k < NB; ++k) {
-            tail[k - 4 * NV][0] = sh_at<NATIVE>(sh, K, k, 0); tail[k - 4 * NV][1] = sh_at<NATIVE>(sh, K, k, 1);
-            tail[k - 4 * NV][2] = sh_at<NATIVE>(sh, K, k, 2);
-        }
-#pragma unroll
-        for (int k4 = 0; k4 < NV; ++k4)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[k4][i], col, Dx, Dy, Dz);
-#pragma unroll
-        for (int k = 4 * NV; k < NB; ++k) sh_accumulate<WITH_GRAD>(k, dir, tail[k - 4 * NV], col, Dx, Dy, Dz);
-        return;
-    }
     if (NV <= 1) {
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
@@ -469,9 +444,6 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #ifndef SPF_PBWD_DEG4_BPC
 #define SPF_PBWD_DEG4_BPC 2   // (round 4: 348 VGPRs, the cap spilled 96 of them; round 5: 256 with the contracted direction gradient)
 #endif
-#ifndef SPF_PABL
-#define SPF_PABL 0      // profiling builds of the BACKWARD kernel only (-DSPF_PABL=5..9: gather / partials / stores / SH cut out)
-#endif
 // Per-tile bookkeeping of a block: one packed word per (view of the group, tile) in LDS -- pairs in the top 12 bits
 // (a block holds 256 Gaussians), footprint load (sum of cull-box areas capped at 256 each: <= 65,536) in the low 20.
 constexpr uint32_t kHistCountShift = 20u, kHistAreaMask = (1u << 20) - 1u;
@@ -488,15 +460,6 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // numbers its (Gaussian, tile) pairs from a sharded global cursor, and every thread writes its keys
 // (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
-#ifdef SPF_PHASE_CLOCKS
-// profiling build only: 100 MHz wall-clock stamps of every block's wave 0 (start | view loop done | barrier passed |
-// reservations back | second barrier passed | keys written), one 8-word slot per block, plain stores
-constexpr int kPfBlocks = 16384;
-__device__ unsigned long long g_pf_stamp[kPfBlocks * 8];
-#define PF_STAMP(i) do { if (threadIdx.x == 0) { const unsigned b_ = blockIdx.x + blockIdx.y * gridDim.x; if (b_ < kPfBlocks) g_pf_stamp[b_ * 8 + (i)] = (unsigned long long)wall_clock64(); } } while (0)
-#else
-#define PF_STAMP(i) do { } while (0)
-#endif
 template <int DEG, bool NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
@@ -533,7 +496,6 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
         scale_columns(R, sx, sy, sz, N0);
     }
     constexpr int NB = DEG < 0 ? 1 : (DEG + 1) * (DEG + 1);
-    PF_STAMP(0);
     if (lds_hist) {
         for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
         __syncthreads();
@@ -610,8 +572,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 const ShDir sd = sh_dir(dir[0] * inv, dir[1] * inv, dir[2] * inv);
                 const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
                 col[0] = col[1] = col[2] = 0.f;
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false, SPF_SH_BURST != 0>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
-                else sh_contract<NB, NATIVE, false, false, SPF_SH_BURST != 0>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -714,9 +676,7 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
       }
       if (direct) {
           // ---- direct bins: reserve, number, write keys (see the kernel's header comment) ----
-          PF_STAMP(1);
           __syncthreads();
-          PF_STAMP(2);
           const int nv = vend - v0;
           // (every global round trip of this tail is issued before any of them is waited for: the cursor's atomic by
           //  thread 0 and up to four bin reservations per thread go out together)
@@ -765,13 +725,11 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
               s_vbase[VG] = (uint32_t)shard_base + at;
           }
           longest = wave_max_u32(longest);
-          PF_STAMP(3);
           // (counters[1], the longest list, is NOT maintained with direct bins: one word visited by every wave of the launch
           //  -- 8,192 atomicMax, or even 8,192 write-through loads to look first -- serialises at ~11 ns each: 55 us / 180 us
           //  measured on a 52 us kernel.  The verdict the plan needs is local: a bin that overflows raises flag 2.)
           if (lane == 0 && longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);
           __syncthreads();
-          PF_STAMP(4);
           const uint32_t pbase = s_vbase[VG];
           for (int vi = 0; vi < nv; ++vi) {
               const int r = s * d.V + v0 + vi;
@@ -820,7 +778,6 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                   }
               }
           }
-          PF_STAMP(5);
           if (vend < d.V) {
               __syncthreads();
               for (int t = threadIdx.x; t < VG * T; t += kBlock) s_hist[t] = 0;
@@ -953,7 +910,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     if (live && d.V > 1) { const uint2 pi = pinfo[rg0 + d.G]; rc_nxt = pi.x; po_nxt = pi.y; }
     f4a q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
     float q8 = 0.f, q9 = 0.f;
-    if (pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
+    if (pairs_of(rc_cur) > 0) {
         const float* __restrict__ gp = gr.gpair + (size_t)po_cur * gs;
         q0 = *reinterpret_cast<const f4u*>(gp); q1 = *reinterpret_cast<const f4u*>(gp + 4); q8 = gp[8];
         if (gs == 10) q9 = gp[9];
@@ -983,7 +940,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         rc_cur = rc_nxt; po_cur = po_nxt;
         if (live && v + 2 < d.V) { const uint2 pi = pinfo[rg + 2 * (size_t)d.G]; rc_nxt = pi.x; po_nxt = pi.y; }
         q0 = f4a{0.f, 0.f, 0.f, 0.f}; q1 = q0; q8 = 0.f; q9 = 0.f;
-        if (v + 1 < d.V && pairs_of(rc_cur) > 0 && SPF_PABL != 5) {
+        if (v + 1 < d.V && pairs_of(rc_cur) > 0) {
             const float* __restrict__ gp = gr.gpair + (size_t)po_cur * gs;
             q0 = *reinterpret_cast<const f4u*>(gp); q1 = *reinterpret_cast<const f4u*>(gp + 4); q8 = gp[8];
             if (gs == 10) q9 = gp[9];
@@ -993,7 +950,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             // the rest of this Gaussian's (Gaussian, tile) pairs: their screen-space gradient records add up
             {
                 const float* __restrict__ gp = gr.gpair + (size_t)po * gs;
-                for (int i = 1; i < (SPF_PABL == 5 ? 0 : npair); ++i) {
+                for (int i = 1; i < npair; ++i) {
                     const f4a a0 = *reinterpret_cast<const f4u*>(gp + gs * i);
                     const f4a a1 = *reinterpret_cast<const f4u*>(gp + gs * i + 4);
                     g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w;
@@ -1026,7 +983,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                 const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
                 const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
                 const ShDir sd = sh_dir(x, y, z);
-                const float* __restrict__ sh = in.shs + (SPF_PABL == 9 ? (size_t)s * d.G : sg) * (size_t)d.K * 3;
+                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
                 float dd[3] = {0.f, 0.f, 0.f};
                 if (DEG == 0) {
                     // one term: re-evaluate the colour exactly as the forward kernel does (a colour clamped at 0 passes
@@ -1134,7 +1091,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             float* __restrict__ pk = s_park + (size_t)(6 * (v % kShChunk)) * kBlock;
             pk[0] = sh_x; pk[kBlock] = sh_y; pk[2 * kBlock] = sh_z;
             pk[3 * kBlock] = sh_g0; pk[4 * kBlock] = sh_g1; pk[5 * kBlock] = sh_g2;
-            if (live && !stage_out && SPF_PABL != 8 && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
+            if (live && !stage_out && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
                 const int nv = v % kShChunk + 1;
                 const bool first = v < kShChunk;
                 if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, d.K, s_park, nv, first);
@@ -1142,7 +1099,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             }
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
-        if (gr.vpartial && SPF_PABL != 6) {
+        if (gr.vpartial) {
             float tot[3];
             wave_sum12(dV, tot);                       // tot[j] = total of dV[4j + (lane & 3)], in every lane
             if (lane < 4) {
@@ -1163,7 +1120,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             }
         }
     }
-    if (stage_out && SPF_PABL != 8) {
+    if (stage_out) {
         const int row = 3 * d.K;
         float* __restrict__ s_out = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + d.V * 6 * kBlock;
         for (int half = 0; half < 2; ++half) {
@@ -1188,8 +1145,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         }
     }
     if (!live) return;
-    if (SPF_PABL == 7 && dp0[0] != 123.f) return;
-
     gr.dL_dmeans3D[3 * sg] = dp0[0]; gr.dL_dmeans3D[3 * sg + 1] = dp0[1]; gr.dL_dmeans3D[3 * sg + 2] = dp0[2];
     gr.dL_dopacities[sg] = dopac;
     if (DEG < 0) {
@@ -1356,12 +1311,3 @@ hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfSt
 #undef SPF_DISPATCH_DEG
 
 }  // namespace spf
-
-#ifdef SPF_PHASE_CLOCKS
-// out[nblocks * 8]: the stamps of the last forward projection launch (profiling build only)
-extern "C" int spf_debug_pf_stamps(unsigned long long* out, int nblocks) {
-    (void)hipDeviceSynchronize();
-    if (nblocks > spf::kPfBlocks) nblocks = spf::kPfBlocks;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(spf::g_pf_stamp), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? 0 : 1;
-}
-#endif

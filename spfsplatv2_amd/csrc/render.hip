@@ -16,17 +16,9 @@
 // would have skipped anyway, so results are identical to the un-culled loop.
 //
 // Semantics: SURVEY.md Appendix B #10/#11 (restated in oracle/splat_ref.py::composite).
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "spf_common.h"
-
-// (profiling builds -- SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS -- count a pixel's contributors in the forward lists kernel)
-#ifdef SPF_PHASE_CLOCKS
-#define SPF_COUNT_HITS 1
-#else
-#define SPF_COUNT_HITS 0
-#endif
 
 namespace spf {
 
@@ -245,13 +237,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
     }
 }
 
-#ifdef SPF_ABLATE
-// profiling build only (SPF_HIPCC_EXTRA=-DSPF_ABLATE): cut the kernel short at run time to time its parts
-static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-threshold argument
-#define ABLATE(n) ((int)(dense_thr_arg >> 28) == (n))
-#else
-#define ABLATE(n) false
-#endif
 // ------------------------------------------------------------------------------------------------
 // Forward for sparse tiles ("lists"): Gaussian-parallel footprint scatter + pixel-parallel private lists.
 //
@@ -266,15 +251,6 @@ static int g_ablate_host = 0;      // travels in the top 4 bits of the dense-thr
 // C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
 // spelled out so that the forward and the backward replay evaluate it identically (same hit decisions).
 typedef float v2f __attribute__((ext_vector_type(2)));
-#ifdef SPF_PHASE_CLOCKS
-__device__ unsigned long long g_cand_count[2];      // forward lists kernel: candidates (bits set) of live pixels, hits
-// 100 MHz wall-clock stamps (start, end) of every block of the last backward lists launch, plain stores
-constexpr int kStampBlocks = 32768;
-__device__ unsigned long long g_blk_stamp[kStampBlocks][2];
-#define BLK_STAMP(e) do { if (threadIdx.x == 0 && blockIdx.x < spf::kStampBlocks) spf::g_blk_stamp[blockIdx.x][e] = (unsigned long long)wall_clock64(); } while (0)
-#else
-#define BLK_STAMP(e) do { } while (0)
-#endif
 
 constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
 constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
@@ -364,7 +340,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
     int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
-    const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;   // (the top bits carry the ablation code of profiling builds)
+    const uint32_t dense_thr = dense_thr_arg;
     __shared__ float4 s_p0[kStage];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
     __shared__ float2 s_p1[kStage];   // B', opacity   (8 bytes: with a float4 here the block is 20,752 bytes of LDS -- 7 per CU instead of 8)
     __shared__ float4 s_p2z[kStage + 1];   // r, g | b, depth; record 0 is all zeros (see `next` below), entry i is record i + 1
@@ -396,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
 
     float Tr = 1.0f;
     v2f c01 = {0.f, 0.f}, c2d = {0.f, 0.f};      // (r, g), (b, depth) accumulators
-    uint32_t last16 = 0, hits = 0;               // 16 * (list position + 1) of the last contributor; contributors
+    uint32_t last16 = 0;                         // 16 * (list position + 1) of the last contributor
     // Lane predicates that live across candidates are kept as WAVE MASKS in scalar registers (`dm`: the lanes whose
     // pixel is finished) and combined with scalar instructions; lane_ballot / inverse_ballot move between the two
     // views for free.  As per-lane bools they cost three vector instructions per candidate.
@@ -413,9 +389,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         const uint32_t idx = base + tid;
         float gx = 0.f, gy = 0.f, r2 = -1.f;
         if (idx < n) {
-            uint32_t gid = (uint32_t)pairs[beg + idx];
-            if (ABLATE(10)) gid = (uint32_t)(beg + idx) % (uint32_t)G;       // (profiling: coalesced instead of gathered)
-            if (ABLATE(11)) gid = (uint32_t)tid;                             // (profiling: always the same 12 KB)
+            const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
             s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
@@ -423,19 +397,12 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
             gx = a.x; gy = a.y; r2 = b.w;
         }
-        if (!ABLATE(8) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
+        {
             const TileBox tb = clipped_box(gx, gy, r2, X0, Y0);
             scatter_box(s_pm, tid, gx, gy, r2, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
         }
         __syncthreads();
-#ifdef SPF_PHASE_CLOCKS
-        if (inside) {
-            unsigned c_ = 0;
-            for (int w = 0; w < kStage / 32; ++w) c_ += __popc(s_pm[w][pid]);
-            atomicAdd(&g_cand_count[0], (unsigned long long)c_);
-        }
-#endif
-        if (!wave_done && !ABLATE(8) && !ABLATE(9) && !ABLATE(10) && !ABLATE(11) && !ABLATE(12)) {
+        if (!wave_done) {
             const char* __restrict__ wcol = reinterpret_cast<const char*>(&s_pm[0][pid]);   // word w: wcol + 1024 w
             uint32_t m = *reinterpret_cast<const uint32_t*>(wcol);
             // which of the later words of this pixel's column hold a candidate at all (most are empty: a pixel has ~9
@@ -482,11 +449,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
                 c2d = __builtin_elementwise_fma(v2f{p2.z, p2.w}, ww, c2d);
                 Tr = take ? test_T : Tr;
                 last16 = take ? (uint32_t)j + base16 : last16;
-                // hits += take: one add-with-carry whose carry-in is the wave mask (a select and an add otherwise)
-                if (SPF_COUNT_HITS) {
-                    uint64_t carry_out;
-                    asm("v_addc_co_u32 %0, %1, 0, %0, %2" : "+v"(hits), "=s"(carry_out) : "s"(hitm & ~stopm));
-                }
             };
             auto rec0 = [&](int j) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_p0) + j); };
             auto rec1 = [&](int j) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(s_p1) + (j >> 1)); };
@@ -518,10 +480,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
         if (__syncthreads_and(wave_done)) break;
     }
     const uint32_t last = last16 >> 4;
-#ifdef SPF_PHASE_CLOCKS
-    if (inside) atomicAdd(&g_cand_count[1], (unsigned long long)hits);
-#endif
-    if (inside && !(ABLATE(12) && Tr == 123.f)) {
+    if (inside) {
         const float* __restrict__ bg = bg_all + 3 * r;
         const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
         float* __restrict__ img = image + (size_t)r * 3 * P;
@@ -746,20 +705,6 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 //            and writes the pair's 48-byte record.
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
-#ifdef SPF_PHASE_CLOCKS
-// profiling build only (SPF_HIPCC_EXTRA=-DSPF_PHASE_CLOCKS): shader-clock cycles per phase; every wave stores its own
-// eight words (no atomics: 260k same-address atomics per launch made the kernel ten times slower and the numbers useless)
-constexpr int kPhaseWaves = 32768;
-__device__ unsigned long long g_phase_buf[kPhaseWaves * 8];
-#define PHASE_INIT() long long ph_t = clock64(); const long long ph_w0 = wall_clock64(); unsigned long long ph_acc[6] = {0, 0, 0, 0, 0, 0}
-#define PHASE_MARK(i) do { const long long t_ = clock64(); ph_acc[i] += (unsigned long long)(t_ - ph_t); ph_t = t_; } while (0)
-#define PHASE_FLUSH() do { if ((threadIdx.x & 63) == 0) { unsigned long long* o_ = spf::g_phase_buf + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) % spf::kPhaseWaves) * 8; for (int i_ = 0; i_ < 6; ++i_) o_[i_] += ph_acc[i_]; o_[6] += (unsigned long long)(wall_clock64() - ph_w0); o_[7] += 1ull; } } while (0)
-#else
-#define PHASE_INIT()
-#define PHASE_MARK(i)
-#define PHASE_FLUSH()
-#endif
-
 #ifndef SPF_POOL
 #define SPF_POOL 1536
 #define SPF_ROUNDL 192
@@ -778,7 +723,7 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const uint32_t* __restrict__ counters, uint64_t capacity) {
     (void)capacity;
     if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
-    const uint32_t dense_thr = dense_thr_arg & 0x0fffffffu;
+    const uint32_t dense_thr = dense_thr_arg;
     __shared__ float4 s_p0[kRoundL];                 // x, y | A', C'   (as in the forward)
     __shared__ float4 s_p1[kRoundL];                 // B', opacity, box width (int), depth
     __shared__ float4 s_p2[kRoundL];                 // r, g, b, box (int bits: xl | yl<<4 | (bw-1)<<8 | off<<12)
@@ -799,10 +744,6 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     const int X0 = tx * kTile, Y0 = ty * kTile;
     if (n == 0) return;
     if (dense_tile) return;                                                          // dense tiles: rows kernel
-    PHASE_INIT();
-    BLK_STAMP(0);
-    BLK_STAMP(1);
-    if (ABLATE(1)) return;
     const size_t P = (size_t)H * W;
     // ---- per-pixel state: thread <-> pixel in the natural order ----
     // (Rounds 1 - 3 put the pixels on lanes by the number of contributors the forward recorded -- an LDS counting sort,
@@ -847,15 +788,12 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
     const uint32_t bmax = min(n, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));   // (clamp: see the rows kernel)
-    if (ABLATE(2)) { if (tail == 123.f) gpair[0] = T_final; return; }
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
         for (uint32_t idx = bmax + tid; idx < n; idx += kBlock)
             store_grec<DEPTH_GRAD>(gpair, pair_slot((uint32_t)pairs[beg + idx]), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                    0.f, 0.f);
     }
     if (bmax == 0) return;
-    PHASE_MARK(0);
-    if (ABLATE(3)) { if (tail == 123.f) gpair[0] = T_final; return; }
 
     float Tr = T_final;
     float sB = -tail * T_final;          // running "behind" scalar of the replay (see phase B)
@@ -884,7 +822,6 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         // (the barrier that closed the previous round makes s_w / s_wacc / s_pool / s_p* reusable here)
         if (lane == kWave - 1) s_w[wave] = inc;
         __syncthreads();
-        PHASE_MARK(1);
         uint32_t off = inc - size;
         for (int w = 0; w < wave; ++w) off += s_w[w];
         // accepted = a prefix of the threads: thread t is in iff the slot demand of threads 0..t fits the pool; the
@@ -905,14 +842,12 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
 #pragma unroll
         for (int k = 0; k < kPool / kBlock; ++k) s_pool[k * kBlock + tid] = make_float2(0.f, 0.f);
         // ---- phase A (the candidate words were cleared before the prefix-sum barrier above) ----
-        if (acc && !ABLATE(4)) scatter_box(s_pm, tid, a.x, a.y, b.w, X0, Y0, xl, yl, bw, bh);
+        if (acc) scatter_box(s_pm, tid, a.x, a.y, b.w, X0, Y0, xl, yl, bw, bh);
         __syncthreads();
         const int cnt = (int)(s_wacc[0] + s_wacc[1] + s_wacc[2] + s_wacc[3]);   // >= 1: one entry needs <= 256 slots
-        PHASE_MARK(2);
-        if (ABLATE(5)) { hi -= (uint32_t)cnt; __syncthreads(); continue; }
         // ---- phase B: ascending bits = descending list position ----
         const int nw = (cnt + 31) >> 5;
-        if (hi - (uint32_t)cnt < wmax && !ABLATE(7)) {
+        if (hi - (uint32_t)cnt < wmax) {
             // contributors of this pixel are entries < ncon, i.e. thread indices >= hi - ncon =: jmin.  The walk starts
             // at the word that holds bit jmin (only that word needs masking) and refills are plain loads.
             const uint32_t jmin = ncon < hi ? hi - ncon : 0u;
@@ -993,11 +928,9 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
                 replay(hb, b0, b1, b2);
             }
         }
-        PHASE_MARK(3);
         __syncthreads();
-        PHASE_MARK(4);
         // ---- phase C: packed fp32 (v_pk_fma_f32), six arithmetic instructions per slot ----
-        if (acc && !ABLATE(6)) {
+        if (acc) {
             v2f c01 = {0.f, 0.f}, c2s = {0.f, 0.f};      // (dL/dr, dL/dg), (dL/db, sum u)
             v2f s1 = {0.f, 0.f}, s2 = {0.f, 0.f};        // (sum u dx, sum u dy), (sum u dx^2, sum u dy^2)
             float sxy = 0.f, cd = 0.f;
@@ -1063,45 +996,8 @@ __global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
         }
         hi -= (uint32_t)cnt;
         __syncthreads();                         // round over: LDS scratch may be reused
-        PHASE_MARK(5);
     }
-    PHASE_FLUSH();
-    BLK_STAMP(1);
 }
-
-#ifdef SPF_ABLATE
-extern "C" int spf_debug_set_ablate(int v) {
-    spf::g_ablate_host = v & 15;
-    return 0;
-}
-#endif
-#ifdef SPF_PHASE_CLOCKS
-// out[nblocks][2]: (start, end) stamps of the blocks of the last backward lists launch
-extern "C" int spf_debug_block_stamps(unsigned long long* out, int nblocks) {
-    (void)hipDeviceSynchronize();
-    if (nblocks > spf::kStampBlocks) nblocks = spf::kStampBlocks;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(spf::g_blk_stamp), sizeof(unsigned long long) * 2 * (size_t)nblocks) == hipSuccess ? 0 : 1;
-}
-extern "C" int spf_debug_phase_cycles(unsigned long long* out8, int reset) {
-    (void)hipDeviceSynchronize();
-    static unsigned long long h[spf::kPhaseWaves * 8];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(spf::g_phase_buf), sizeof(h)) != hipSuccess) return 1;
-    {
-        unsigned long long cc[2] = {0, 0}, zz[2] = {0, 0};
-        (void)hipMemcpyFromSymbol(cc, HIP_SYMBOL(spf::g_cand_count), sizeof(cc));
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(spf::g_cand_count), zz, sizeof(zz));
-        fprintf(stderr, "forward lists kernel since the last call: %llu candidates, %llu hits\n", cc[0], cc[1]);
-    }
-    for (int j = 0; j < 8; ++j) out8[j] = 0;
-    for (int i = 0; i < spf::kPhaseWaves; ++i)
-        for (int j = 0; j < 8; ++j) out8[j] += h[i * 8 + j];
-    if (reset) {
-        static unsigned long long z[spf::kPhaseWaves * 8];
-        if (hipMemcpyToSymbol(HIP_SYMBOL(spf::g_phase_buf), z, sizeof(z)) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
 
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t launch_render_fwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, int, int,
@@ -1171,12 +1067,7 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     if (sparse)
         spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT,
-#ifdef SPF_ABLATE
-            dense_threshold() | ((uint32_t)g_ablate_host << 28));
-#else
-            dense_threshold());
-#endif
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
     if (dense)
         spf_render_fwd_rows_kernel<<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
@@ -1199,13 +1090,7 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
     if (sparse)
         spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT,
-#ifdef SPF_ABLATE
-            dense_threshold() | ((uint32_t)g_ablate_host << 28),
-#else
-            dense_threshold(),
-#endif
-            st.counters, capacity);
+            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters, capacity);
     if (dense)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,

@@ -241,11 +241,14 @@ class DecoderSplattingCUDACfg:
     enable_sh_grad: bool
 
 
+_data_ptr = torch.Tensor.data_ptr
+
+
 class _EvalGraph:
     """One captured evaluation call of a decoder: the graph, the tensors it writes (colour and depth packed into one
     flat buffer, alpha, radii -- owned by the graph's memory pool) and the call record whose `counters` it
     refreshes."""
-    __slots__ = ("graph", "outputs", "record")
+    __slots__ = ("graph", "outputs", "record", "sizes", "color_shape", "depth_shape")
 
     def __init__(self, graph, outputs, record):
         self.graph, self.outputs, self.record = graph, outputs, record
@@ -322,7 +325,9 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         if torch.cuda.is_current_stream_capturing():
             return None
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
-        return (tuple([t.data_ptr() for t in tensors]), tuple([t.shape for t in tensors]), tuple(image_shape),
+        # (addresses of all nine tensors; the shapes of three of them fix the others' -- (b, v), G and d_sh --, anything
+        #  else would have failed the rasterizer's own shape checks on the call that was captured)
+        return (tuple(map(_data_ptr, tensors)), tensors[0].shape, tensors[4].shape, tensors[5].shape, tuple(image_shape),
                 self.max_pairs, band4, self.background_color.data_ptr(), self.make_scale_invariant)
 
     def render(self, gaussians: Gaussians, extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor,
@@ -367,11 +372,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         flat, alpha, radii = entry.outputs
         # ONE copy-out: what the caller gets is the caller's (the graph's own buffers are rewritten by its next replay);
         # colour and depth were packed into one flat buffer inside the graph
-        mine = flat.clone()
-        b, v = extrinsics.shape[:2]
-        h, w = image_shape
-        nc = b * v * 3 * h * w
-        out = DecoderOutput(mine[:nc].view(b, v, 3, h, w), mine[nc:].view(b, v, h, w))     # both contiguous, as ever
+        color, depth = flat.clone().split_with_sizes(entry.sizes)
+        out = DecoderOutput(color.view(entry.color_shape), depth.view(entry.depth_shape))   # both contiguous, as ever
         if not want_extra:
             return out, None, None
         return out, alpha.clone(), radii.clone()
@@ -386,6 +388,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                                                             self.max_pairs, record)
             flat = torch.cat((color.reshape(-1), depth.reshape(-1)))     # one buffer to copy out per call
         entry = _EvalGraph(graph, (flat, alpha, radii), record)
+        entry.sizes = [color.numel(), depth.numel()]
+        entry.color_shape, entry.depth_shape = tuple(color.shape), tuple(depth.shape)
         self._graphs[key] = entry
         self._graph_seen.pop(key, None)
         self._graph_unused += 1
