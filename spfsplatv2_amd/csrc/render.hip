@@ -705,16 +705,17 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
 //            and writes the pair's 48-byte record.
 // Work is proportional to real (pixel, Gaussian) contributions and no cross-lane reduction is needed.
 // ------------------------------------------------------------------------------------------------
-#ifndef SPF_POOL
-#define SPF_POOL 1536
-#define SPF_ROUNDL 192
-#define SPF_BPC 5
-#endif
-constexpr int kPool = SPF_POOL;    // (w, u) slots per round: 12 KB
-constexpr int kRoundL = SPF_ROUNDL;  // candidate entries per round (6 mask words); LDS total ~31 KB -> 5 blocks per CU
-
-template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock, SPF_BPC) void spf_render_bwd_lists_kernel(
+// Round shapes: kRoundL candidate entries per round (kRoundL / 32 mask words), a pool of kPool (w, u) slots, BPC blocks
+// per CU.  Many tiles (the chip runs several rounds of blocks): 192 entries / 1,536 slots (12 KB) -- ~31 KB of LDS, five
+// blocks per CU; every other shape measured slower there (DESIGN_EXPERIMENTS.md).  FEW tiles with long lists are another
+// regime: the launch is one round (or two) of blocks that run as long as their own chain of rounds, LDS is free, and
+// longer rounds are fewer barriers per entry -- round 5, same box: the reference's 10-view shape (768 tiles of ~2,800
+// entries) 176 -> 149 us with 256 / 2,560 at three blocks per CU (224 / 1,792: 169); BASELINE config 3 (2,048 tiles of
+// ~1,300) 144.8 -> 139.5 us with 224 / 1,792 at four (256 / 2,560: 150); config 5 (8,192 tiles) loses with either
+// (326 -> 343 / 381).  launch_render_bwd_t picks by the number of tiles.  (Requesting the next round's entries a round
+// ahead, forward or backward, bought nothing in either regime: +-0 backward, +2 ... +7 us forward.)
+template <bool DEPTH_GRAD, int kRoundL, int kPool, int BPC>
+__global__ __launch_bounds__(kBlock, BPC) void spf_render_bwd_lists_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth,
@@ -1087,10 +1088,20 @@ static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const Spf
     const uint2* const pinfo = reinterpret_cast<const uint2*>(st.pair_off);
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
-    if (sparse)
-        spf_render_bwd_lists_kernel<DG><<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters, capacity);
+    if (sparse) {
+        // round shape by the number of tiles (see the kernel); SPF_BWD_ROUNDS=192 / 224 / 256 pins one (experiments, tests)
+        const char* const fe = getenv("SPF_BWD_ROUNDS");      // (read per call: the tests flip it)
+        const int forced = fe ? atoi(fe) : 0;
+        const int shape = forced ? forced : (RT <= 768 ? 256 : (RT <= 2048 ? 224 : 192));
+#define SPF_BWD_LISTS(RL, PL, BPC)                                                                                      \
+        spf_render_bwd_lists_kernel<DG, RL, PL, BPC><<<grid, kBlock, 0, stream>>>(                                        \
+            st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha, \
+            pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters, capacity)
+        if (shape == 256) SPF_BWD_LISTS(256, 2560, 3);
+        else if (shape == 224) SPF_BWD_LISTS(224, 1792, 4);
+        else SPF_BWD_LISTS(192, 1536, 5);
+#undef SPF_BWD_LISTS
+    }
     if (dense)
         spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,

@@ -295,6 +295,28 @@ def test_longest_first_launch_order_changes_nothing(hip_lib, monkeypatch):
                 assert torch.equal(ordered["grads"][n], plain["grads"][n]), (cfg, n)
 
 
+def test_backward_round_shapes_give_identical_gradients(hip_lib, monkeypatch):
+    """The lists backward comes in three round shapes (entries per round / slot pool / blocks per CU: 192 / 1,536 / 5 for
+    many tiles, 224 / 1,792 / 4 up to 2,048 tiles, 256 / 2,560 / 3 up to 768: render.hip) picked by the number of tiles of
+    the call.  A pixel replays its contributors in list order and an entry sums its slots in pixel order whatever the
+    round boundaries are: every gradient must be bit-identical across the three -- on a call of few tiles with lists of
+    thousands of entries (the regime the long rounds are for) and on an ordinary one."""
+    for cfg, S, V, kw in (("TESTBIG", 1, 2, dict(G=60000, image_hw=(48, 64))), ("C2", 2, 2, {})):
+        batch = syn.make_batch(cfg, S, V, seed=123, **kw)
+        got = {}
+        for shape in ("192", "224", "256"):
+            monkeypatch.setenv("SPF_BWD_ROUNDS", shape)
+            got[shape] = util.run_product(batch)
+        monkeypatch.delenv("SPF_BWD_ROUNDS")
+        default = util.run_product(batch)
+        assert default["stats"]["dense_tiles"] == 0
+        for shape in ("224", "256"):
+            for n in util.GRAD_NAMES:
+                assert torch.equal(got[shape]["grads"][n], got["192"]["grads"][n]), (cfg, shape, n)
+        for n in util.GRAD_NAMES:
+            assert torch.equal(default["grads"][n], got["192"]["grads"][n]), (cfg, n)
+
+
 def test_ordered_planned_call_against_the_oracle(hip_lib):
     """The path the bench runs -- a planned call on direct bins whose composite kernels take their tiles from the launch
     order -- held against the float64 oracle itself, not only against the exact-mode call: 32 renders of 128 x 128
