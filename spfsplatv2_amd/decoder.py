@@ -384,9 +384,23 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         record = CallRecord()
         graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(graph):
-            color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
-                                                            self.max_pairs, record)
-            flat = torch.cat((color.reshape(-1), depth.reshape(-1)))     # one buffer to copy out per call
+            color, depth4, alpha, radii = render_views(
+                extrinsics, intrinsics, near, far, image_shape, self.background_color,
+                gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
+                scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
+                enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs, sh_band4=self.sh_band4, return_radii=True,
+                record=record)
+            if self.make_scale_invariant:
+                depth4.mul_(near[:, :, None, None, None])            # decoder_splatting_cuda.py:72-76, in place: the buffer is ours
+            depth = depth4[:, :, 0]
+            # the rasterizer hands out colour and depth as two views of one allocation (rasterizer._forward_impl): that
+            # allocation is the one buffer copied out per call; anything else (another binding) is packed here
+            if (depth4.untyped_storage().data_ptr() == color.untyped_storage().data_ptr() and color.is_contiguous()
+                    and depth4.is_contiguous() and depth4.data_ptr() == color.data_ptr() + 4 * color.numel()):
+                flat = color.new_empty(0).set_(color.untyped_storage(), color.storage_offset(),
+                                               (color.numel() + depth4.numel(),))
+            else:
+                flat = torch.cat((color.reshape(-1), depth.reshape(-1)))
         entry = _EvalGraph(graph, (flat, alpha, radii), record)
         entry.sizes = [color.numel(), depth.numel()]
         entry.color_shape, entry.depth_shape = tuple(color.shape), tuple(depth.shape)

@@ -260,8 +260,11 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
     final_T = torch.empty((R * P,), **f32)
     n_contrib = torch.empty((R * P,), **i32)
-    image = torch.empty((S, V, 3, H, W), **f32)
-    depth = torch.empty((S, V, 1, H, W), **f32)
+    # colour and depth in ONE allocation, colour first (two contiguous tensors as ever: the decoder module's captured
+    # evaluation graphs copy both out with a single clone)
+    img_dep = torch.empty((R * 4 * P,), **f32)
+    image = img_dep[:R * 3 * P].view(S, V, 3, H, W)
+    depth = img_dep[R * 3 * P:].view(S, V, 1, H, W)
     alpha = torch.empty((S, V, 1, H, W), **f32)
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/refresh
 rm -rf "$OUT"; mkdir -p "$OUT"
 ERR="$OUT/bench.err"
-for cfg in ${CONFIGS:-C2 REF2V C3 C5}; do
+for cfg in ${CONFIGS:-C2 REF2V C3 C5 REF10V}; do
   extra=""; [ "$cfg" != "C2" ] && extra="--no-cpu-baseline"
   # the bench line itself (graph replay, default batch of the config)
   # (C2 with default arguments is the driver's command: it carries the `secondary` object too)
@@ -37,7 +37,10 @@ if [ -z "${CONFIGS:-}" ]; then
   SPF_DIRECT_BINS=0 python bench.py --no-cpu-baseline --no-secondary > "$OUT/bench_C2_classic_bins.json" 2>> "$ERR"
   python bench.py --eval-latency > "$OUT/bench_eval_1x3.json" 2>> "$ERR"
   python bench.py --api per-view --no-cpu-baseline --steps 5 --warmup 2 --min-trials 5 --min-seconds 0 > "$OUT/bench_perview.json" 2>> "$ERR"
-  python tools/bench_rope.py > "$OUT/rope_bench.txt" 2>> "$ERR"; cp gpurun_out/rope_bench.json "$OUT/rope_bench.json"
+  python bench.py --rope > "$OUT/rope_bench.json" 2>> "$ERR"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_rope" -o stats -- python bench.py --rope > "$OUT/stats_rope.log" 2>&1
+  find "$OUT/stats_rope" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_rope.csv" \;
+  rm -rf "$OUT/stats_rope"
 fi
 find "$OUT" -name '*.log' -size +200k -delete
 ls -la "$OUT"
