@@ -22,7 +22,8 @@
 
 namespace spf {
 
-constexpr int kStage = 256;  // list entries staged per round (one per thread)
+constexpr int kStage = 256;  // list entries staged per round (one per thread) of the rows kernels
+constexpr int kFwdLongRoundsMaxTiles = 768;    // calls of at most this many tiles: 512-entry rounds in the forward lists kernel
 
 struct BlockCtx {
     int r, tile, tx, ty, wave, lane, row, l16, beta, px, py;
@@ -281,7 +282,7 @@ __device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs,
 #ifndef SPF_SCATTER4
 #define SPF_SCATTER4 1
 #endif
-__device__ __forceinline__ void scatter_box(uint32_t (*s_pm)[kStage], int i, float gx, float gy, float r2, int X0, int Y0,
+__device__ __forceinline__ void scatter_box(uint32_t (*s_pm)[kBlock], int i, float gx, float gy, float r2, int X0, int Y0,
                                             int xl, int yl, int bw, int bh) {
     uint32_t* __restrict__ wp = s_pm[i >> 5] + yl * kTile + xl;
     const uint32_t bit = 1u << (i & 31);
@@ -334,6 +335,13 @@ __device__ __forceinline__ TileBox clipped_box(float gx, float gy, float r2, int
     return t;
 }
 
+// STAGE = list entries staged per round: 256 (one per thread; 18.7 KB of LDS, eight blocks per CU) for calls of many tiles,
+// 512 (two per thread; 37 KB) for calls of few tiles with long lists -- there the launch is one or two rounds of blocks that
+// run as long as their own chain of rounds, and half as many rounds are half as many barriers and trips to memory.
+// Measured (round 5, same box, forward stage): the reference's 10-view shape (768 tiles of ~2,800 entries) 98.9 -> 89.0 us;
+// but BASELINE config 3 (2,048 tiles) 59.8 -> 71.6, REF2V (4,096) 66.8 -> 78.9, C2 (8,192) 66.4 -> 87.6: four blocks per
+// CU instead of eight costs more than the rounds save as soon as the chip is full -- 512 only up to 768 tiles.
+template <int STAGE>
 __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
@@ -341,10 +349,10 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
     int T, int tiles_x, int RT, uint32_t dense_thr_arg) {
     const uint32_t dense_thr = dense_thr_arg;
-    __shared__ float4 s_p0[kStage];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
-    __shared__ float2 s_p1[kStage];   // B', opacity   (8 bytes: with a float4 here the block is 20,752 bytes of LDS -- 7 per CU instead of 8)
-    __shared__ float4 s_p2z[kStage + 1];   // r, g | b, depth; record 0 is all zeros (see `next` below), entry i is record i + 1
-    __shared__ uint32_t s_pm[kStage / 32][kStage];   // [32-entry word][pixel]: candidate bits
+    __shared__ float4 s_p0[STAGE];   // x, y | A', C'   (conic pre-scaled, see lists_power2)
+    __shared__ float2 s_p1[STAGE];   // B', opacity   (8 bytes: with a float4 here the block is 20,752 bytes of LDS -- 7 per CU instead of 8)
+    __shared__ float4 s_p2z[STAGE + 1];   // r, g | b, depth; record 0 is all zeros (see `next` below), entry i is record i + 1
+    __shared__ uint32_t s_pm[STAGE / 32][kBlock];   // [32-entry word][pixel]: candidate bits
     float4* const s_p2 = s_p2z + 1;
 
     (void)capacity;
@@ -382,24 +390,32 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     // (candidate words: every thread keeps ITS pixel's column clear -- before the first round here, afterwards right
     // after it has consumed it -- so that staging and scatter of a round need no barrier between them)
 #pragma unroll
-    for (int w = 0; w < kStage / 32; ++w) s_pm[w][pid] = 0u;
+    for (int w = 0; w < STAGE / 32; ++w) s_pm[w][pid] = 0u;
     __syncthreads();
-    for (uint32_t base = 0; base < n; base += kStage) {
-        const int nw = (int)((min((uint32_t)kStage, n - base) + 31u) >> 5);
-        const uint32_t idx = base + tid;
-        float gx = 0.f, gy = 0.f, r2 = -1.f;
-        if (idx < n) {
-            const uint32_t gid = (uint32_t)pairs[beg + idx];
-            const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
-            const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[tid] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);
-            s_p1[tid] = make_float2(kLog2e * a.w, b.y);
-            s_p2[tid] = make_float4(cc.x, cc.y, cc.z, b.z);
-            gx = a.x; gy = a.y; r2 = b.w;
+    for (uint32_t base = 0; base < n; base += STAGE) {
+        const int nw = (int)((min((uint32_t)STAGE, n - base) + 31u) >> 5);
+        constexpr int EPT = STAGE / kBlock;                  // entries per thread: e = tid, tid + 256
+        float4 ea[EPT], eb[EPT], ec[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {                      // (all gathers of the round in flight together)
+            const uint32_t idx = base + q * kBlock + tid;
+            ea[q] = make_float4(0.f, 0.f, 0.f, 0.f); eb[q] = make_float4(0.f, 0.f, 0.f, -1.f); ec[q] = ea[q];
+            if (idx < n) {
+                const uint32_t gid = (uint32_t)pairs[beg + idx];
+                const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
+                ea[q] = rp[0]; eb[q] = rp[1]; ec[q] = rp[2];
+            }
         }
-        {
-            const TileBox tb = clipped_box(gx, gy, r2, X0, Y0);
-            scatter_box(s_pm, tid, gx, gy, r2, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = q * kBlock + tid;
+            if (base + e < n) {
+                s_p0[e] = make_float4(ea[q].x, ea[q].y, kHalfLog2e * ea[q].z, kHalfLog2e * eb[q].x);
+                s_p1[e] = make_float2(kLog2e * ea[q].w, eb[q].y);
+                s_p2[e] = make_float4(ec[q].x, ec[q].y, ec[q].z, eb[q].z);
+            }
+            const TileBox tb = clipped_box(ea[q].x, ea[q].y, eb[q].w, X0, Y0);      // (no entry: r2 = -1 -> empty box)
+            scatter_box(s_pm, e, ea[q].x, ea[q].y, eb[q].w, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
         }
         __syncthreads();
         if (!wave_done) {
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
             // candidates among the round's 256 entries); words >= nw are clear
             uint32_t nz = 0u;
 #pragma unroll
-            for (int k = 1; k < kStage / 32; ++k)
+            for (int k = 1; k < STAGE / 32; ++k)
                 nz |= min(*reinterpret_cast<const uint32_t*>(wcol + 1024 * k), 1u) << k;
             int wb = 0;                                  // 512 * word = byte offset of entry 32 w in the staged arrays
             // next candidate of this lane as the byte offset of its staged record.  has = false: none left -- the
@@ -1065,10 +1081,18 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
     AuxStream* a = nullptr;
     const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
-    if (sparse)
-        spf_render_fwd_lists_kernel<<<grid, kBlock, 0, stream>>>(
-            st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    if (sparse) {
+        const char* const fe = getenv("SPF_FWD_STAGE");       // ("256" / "512" pins the instantiation: experiments, tests)
+        const int stage = fe ? atoi(fe) : (RT <= kFwdLongRoundsMaxTiles ? 512 : 256);
+        if (stage == 512)
+            spf_render_fwd_lists_kernel<512><<<grid, kBlock, 0, stream>>>(
+                st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+                out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+        else
+            spf_render_fwd_lists_kernel<256><<<grid, kBlock, 0, stream>>>(
+                st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+                out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
+    }
     if (dense)
         spf_render_fwd_rows_kernel<<<grid, kBlock, 0, ds>>>(
             st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,

@@ -315,6 +315,16 @@ def test_backward_round_shapes_give_identical_gradients(hip_lib, monkeypatch):
                 assert torch.equal(got[shape]["grads"][n], got["192"]["grads"][n]), (cfg, shape, n)
         for n in util.GRAD_NAMES:
             assert torch.equal(default["grads"][n], got["192"]["grads"][n]), (cfg, n)
+        # the forward lists kernel stages 256 or 512 entries per round (calls of <= 2,048 tiles: 512): same pixels, same
+        # last contributors, hence the same gradients, bit for bit
+        for stage in ("256", "512"):
+            monkeypatch.setenv("SPF_FWD_STAGE", stage)
+            other = util.run_product(batch)
+            monkeypatch.delenv("SPF_FWD_STAGE")
+            for k in ("color", "depth", "alpha"):
+                assert torch.equal(other[k], default[k]), (cfg, stage, k)
+            for n in util.GRAD_NAMES:
+                assert torch.equal(other["grads"][n], default["grads"][n]), (cfg, stage, n)
 
 
 def test_ordered_planned_call_against_the_oracle(hip_lib):
