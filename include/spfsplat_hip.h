@@ -52,7 +52,11 @@ extern "C" {
                                 render_wave.hip; -DSPF_TILE=8 builds the whole library -- projection, bins, sort, compositing
                                 -- on the 8 px grid).  spf_raster_num_tiles() tells a host which grid the library was built for */
 #endif
-#define SPF_DENSE_AREA 26    /* mean cull-box area (px) above which a tile is rendered by the dense kernels */
+#define SPF_DENSE_AREA 26    /* mean cull-box area (px) above which a tile's BACKWARD takes the dense "rows" form inside the
+                                compositing kernel (and what the dense-tile census, counters[3], counts) */
+#define SPF_DENSE_AREA_FWD 120 /* the same for the FORWARD: the sparse "lists" form stays ahead of the rows form up to much
+                                denser tiles than in the backward (round 5 sweep), so a tile may composite forward through
+                                lists and backward through rows -- both write / read the same per-pixel state */
 
 /* Geometry of one batched call: S scenes, V views each => R = S*V renders of H x W pixels.
  * All scenes hold G Gaussians with K SH coefficients per colour channel (stride); the SH basis is
@@ -116,13 +120,13 @@ typedef struct SpfState {
     uint32_t* tile_start;  /* [R*T+1]   exclusive scan of tile_count; last = D.  Direct bins: scratch -- when tile_start |
                             *            tile_fill are ONE 8-byte aligned piece (tile_fill == tile_start + R*T + 1, as in the
                             *            one-buffer layout below) and the call has >= 2,048 tiles, the library keeps the
-                            *            composite kernels' launch order there: [R*T][2] = (tile | dense << 31, list length),
+                            *            composite kernels' launch order there: [R*T][2] = (tile | dense-backward << 31 | dense-forward << 30, list length),
                             *            longest lists first, written by spf_raster_forward_render and read again by
                             *            spf_raster_backward -- leave it alone between the two */
     uint32_t* tile_fill;   /* [R*T]     scratch cursor for the binning pass (direct bins: see tile_start) */
     uint32_t* tile_flags;  /* [R*T]     footprint load of the tile: sum over its list of min(cull-disc bounding-box
-                                        area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA take the dense
-                                        "rows" render kernels, the others the sparse "lists" kernels */
+                                        area in pixels, 256); tiles whose mean exceeds SPF_DENSE_AREA(_FWD) take the dense
+                                        "rows" form of the compositing kernels, the others the sparse "lists" form */
     uint32_t* counters;    /* [4]       0: D (total pairs) 1: max tile_count 2: plan verdict (0 = held) 3: number of dense tiles
                                         (direct bins: 0 and 3 are not maintained) */
     uint64_t* pairs;       /* [capacity] per-tile lists, each sorted by (depth bits << 32 | Gaussian id)
@@ -251,20 +255,20 @@ int spf_camera_backward_partials(const SpfCamera* cam, const float* vpartial, in
 /* Forward, stage 2: bin (Gaussian, tile) pairs into per-tile lists, depth-sort every list and
  * composite.  `capacity` = number of uint64 entries st->pairs can hold.  `max_tile_hint` = upper bound of the
  * longest tile list the caller assumes (exact mode: host copy of counters[1]; 0 = unknown: every sort size class
- * is launched).  `dense_tiles_hint` = number of dense tiles the caller assumes (exact mode: host copy of
- * counters[3]; 0 = none, S*V*tiles = all, SPF_UNKNOWN or anything in between: both the sparse and the dense render
- * kernels are launched; each tile is rendered by exactly one of them either way).
+ * is launched).  `dense_tiles_hint` is IGNORED (pass SPF_UNKNOWN): up to round 4 sparse and dense tiles had a kernel
+ * each and the hint let the host skip one; since round 5 one kernel composites every tile in the form that suits it.
  * A caller that PLANS the call from an earlier one instead of reading the counters back (no device->host
  * synchronisation; capturable in a HIP graph) passes its assumptions here and they are checked on the device:
  * counters[2] = 0 if the plan held, else a bit mask: 1 = D > capacity, 2 = a tile list longer than max_tile_hint
- * (it could not be sorted), 4 = dense_tiles_hint of 0 / all was wrong (some tiles have no kernel).  A failed plan is
+ * (it could not be sorted); bit 4 (a wrong dense_tiles_hint, rounds 2 - 4) is never set.  A failed plan is
  * never silent and never undefined: with a non-zero flag EVERY output of this call (image, depth, alpha) and every
  * gradient of the matching backward is filled with NaN -- deterministic, and caught by the reference's own
  * NaN-gradient guard (src/model/model_wrapper.py:1117-1151) even if the caller never reads the flag. */
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out,
                               uint64_t capacity, uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream);
 
-/* Backward of both stages.  `capacity` = number of 10-float records g->gpair can hold (>= D). */
+/* Backward of both stages.  `capacity` = number of 10-float records g->gpair can hold (>= D); `dense_tiles_hint`: ignored,
+ * as in spf_raster_forward_render. */
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st,
                         const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
 

@@ -11,13 +11,13 @@ hipError_t launch_project_fwd(const SpfDims&, const SpfInputs&, const SpfState&,
 hipError_t launch_project_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, uint64_t, hipStream_t);
 hipError_t launch_tile_scan(const SpfState&, int, int, int, uint32_t, bool, hipStream_t);
 uint32_t dense_threshold();
-hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, uint32_t, uint32_t, hipStream_t);
-hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, uint32_t, const uint2*, int,
+hipError_t launch_bin_pairs(const SpfDims&, const SpfState&, uint64_t, int, int, uint32_t, hipStream_t);
+hipError_t launch_tile_sort(const SpfState&, const TileLists&, int, int, uint64_t, uint32_t, const uint2*, int,
                             hipStream_t);
 hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, uint64_t, int, int,
-                             uint32_t, bool, hipStream_t);
-hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint32_t,
-                             uint64_t, bool, hipStream_t);
+                             bool, hipStream_t);
+hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint64_t, bool,
+                             hipStream_t);
 hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
 hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
                               float*, hipStream_t);
@@ -198,11 +198,6 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
     }
     return c;
 }
-// dense-tile assumption of the whole call -> of a chunk of `rt` tiles ("none" and "all" carry over)
-uint32_t chunk_dense_hint(uint32_t hint, uint32_t RT, uint32_t rt) {
-    return hint == 0u ? 0u : (hint == RT ? rt : SPF_UNKNOWN);
-}
-
 const char* kStageKernel[SPF_STAGE_COUNT] = {
     "spf_project_fwd_kernel", "spf_tile_scan_kernel",  "spf_bin_pairs_kernel",   "spf_sort_tiles_wave_kernel",
     "spf_render_fwd_lists_kernel", "spf_render_bwd_lists_kernel", "spf_project_bwd_kernel", "spf_rope2d_vec_kernel"};
@@ -399,6 +394,7 @@ static bool xcd_deal_enabled() {
 
 int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* st, SpfOutputs* out, uint64_t capacity,
                               uint32_t max_tile_hint, uint32_t dense_tiles_hint, void* stream_) {
+    (void)dense_tiles_hint;       // (ignored: one kernel composites sparse and dense tiles -- see the header)
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -423,12 +419,12 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
             // (with `ordered`, eight blocks of the sort's first kernel also write the composite lists kernels' launch order:
             //  long lists first, see tile_order_ptr)
             SPF_HIP(spf::launch_tile_sort(*st, tl, RT, RT, ~0ull, max_tile_hint ? max_tile_hint : (uint32_t)d->bin_cap,
-                                          dense_tiles_hint, ordered ? spf::tile_order_ptr(*st, *d, RT) : nullptr,
+                                          ordered ? spf::tile_order_ptr(*st, *d, RT) : nullptr,
                                           xcd_deal_enabled() ? T : 0, stream));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, stream);
-            SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, ~0ull, T, tiles_x, dense_tiles_hint, ordered, stream));
+            SPF_HIP(spf::launch_render_fwd(*d, *in, *st, *out, ~0ull, T, tiles_x, ordered, stream));
         }
         return SPF_OK;
     }
@@ -443,22 +439,20 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
         const hipStream_t cs = (c & 1) ? lanes->s : stream;
         const Chunk ch = make_chunk(*d, *in, *st, out, nullptr, bounds[c], bounds[c + 1], -1, 0);
         const int rt = (bounds[c + 1] - bounds[c]) * T;
-        const uint32_t dh = chunk_dense_hint(dense_tiles_hint, (uint32_t)RT, (uint32_t)rt);
         if (c == 1) SPF_HIP(hipStreamWaitEvent(cs, lanes->stagger, 0));     // second lane: one kernel behind the first
         {
             StageScope t(SPF_STAGE_BIN, cs);
-            SPF_HIP(spf::launch_bin_pairs(ch.d, ch.st, capacity, T, tiles_x, max_tile_hint, dense_tiles_hint,
-                                          (uint32_t)RT, cs));
+            SPF_HIP(spf::launch_bin_pairs(ch.d, ch.st, capacity, T, tiles_x, max_tile_hint, cs));
         }
         if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));
         {
             StageScope t(SPF_STAGE_SORT, cs);
             SPF_HIP(spf::launch_tile_sort(ch.st, spf::tile_lists(ch.st, ch.d), rt, RT, capacity, max_tile_hint,
-                                          dense_tiles_hint, /*order*/ nullptr, 0, cs));
+                                          /*order*/ nullptr, 0, cs));
         }
         {
             StageScope t(SPF_STAGE_RENDER_FWD, cs);
-            SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, dh, false, cs));
+            SPF_HIP(spf::launch_render_fwd(ch.d, ch.in, ch.st, ch.out, capacity, T, tiles_x, false, cs));
         }
         return SPF_OK;
     };
@@ -473,6 +467,7 @@ int spf_raster_forward_render(const SpfDims* d, const SpfInputs* in, SpfState* s
 
 int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* st, const SpfGrads* g,
                         uint64_t capacity, uint32_t dense_tiles_hint, void* stream_) {
+    (void)dense_tiles_hint;
     int rc = check_dims(d);
     if (rc) return rc;
     rc = check_inputs(d, in);
@@ -488,7 +483,7 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
-    const int T = tiles_x * tiles_y, RT = d->S * d->V * T;
+    const int T = tiles_x * tiles_y;
     // (every pair record is written exactly once by its tile: no memset of gpair)
     int bounds[kMaxChunks + 1];
     bool by_scene = false;
@@ -500,12 +495,10 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         const int s0 = bounds[c] / d->V, ns = (bounds[c + 1] - bounds[c]) / d->V;
         const Chunk ch = C > 1 ? make_chunk(*d, *in, *st, nullptr, g, bounds[c], bounds[c + 1], s0, ns)
                                : Chunk{*d, *in, *st, SpfOutputs{nullptr, nullptr, nullptr}, *g};
-        const int rt = (bounds[c + 1] - bounds[c]) * T;
-        const uint32_t dh = chunk_dense_hint(dense_tiles_hint, (uint32_t)RT, (uint32_t)rt);
         if (c == 1) SPF_HIP(hipStreamWaitEvent(cs, lanes->stagger, 0));     // second lane: one kernel behind the first
         {
             StageScope t(SPF_STAGE_RENDER_BWD, cs);
-            SPF_HIP(spf::launch_render_bwd(ch.d, ch.in, ch.st, ch.g, T, tiles_x, dh, capacity,
+            SPF_HIP(spf::launch_render_bwd(ch.d, ch.in, ch.st, ch.g, T, tiles_x, capacity,
                                            d->bin_cap > 0 && C == 1 && tile_order_enabled(), cs));
         }
         if (c == 0 && C > 1) SPF_HIP(hipEventRecord(lanes->stagger, cs));

@@ -17,6 +17,7 @@
 namespace spf {
 
 uint32_t dense_threshold();     // render.hip
+uint32_t dense_threshold_fwd();
 
 // ---- scan of tile counts: single block, n = R*T is small (<= a few 10^5) --------------------
 constexpr int kScanThreads = 1024;
@@ -166,8 +167,7 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
                                                                const uint32_t* __restrict__ blk_base,
                                                                uint32_t* __restrict__ pair_off,
                                                                int G, int T, int tiles_x, int lds,
-                                                               uint32_t max_tile_hint, uint32_t dense_hint,
-                                                               uint32_t RT) {
+                                                               uint32_t max_tile_hint) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [T] counts, [T] bases
     __shared__ uint32_t s_wtot[4];
     uint32_t* s_cnt = s_bin;
@@ -181,7 +181,6 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     if (r == 0 && g == 0) {
         uint32_t flag = counters[0] > capacity ? 1u : 0u;
         if (max_tile_hint != 0u && counters[1] > max_tile_hint) flag |= 2u;
-        if ((dense_hint == 0u && counters[3] != 0u) || (dense_hint == RT && counters[3] != RT)) flag |= 4u;
         if (flag) counters[2] = flag;
     }
     if (counters[0] > capacity) return;
@@ -289,8 +288,7 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
                                                                      const uint32_t* __restrict__ blk_base,
                                                                      uint32_t* __restrict__ pair_off,
                                                                      int G, int T, int tiles_x, int V, int nvb,
-                                                                     uint32_t max_tile_hint, uint32_t dense_hint,
-                                                                     uint32_t RT) {
+                                                                     uint32_t max_tile_hint) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_bin[];   // [VB][T] counts, [VB][T] bases
     __shared__ uint32_t s_wtot[VB][4];
     uint32_t* const s_cnt = s_bin;
@@ -302,7 +300,6 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_views_kernel(const float
     if (blockIdx.y == 0 && g == 0) {                                   // the plan check (see the kernel above)
         uint32_t flag = counters[0] > capacity ? 1u : 0u;
         if (max_tile_hint != 0u && counters[1] > max_tile_hint) flag |= 2u;
-        if ((dense_hint == 0u && counters[3] != 0u) || (dense_hint == RT && counters[3] != RT)) flag |= 4u;
         if (flag) counters[2] = flag;
     }
     if (counters[0] > capacity) return;
@@ -409,7 +406,10 @@ static_assert(kOrderClasses == kWave, "the class bases are one wave's prefix sum
 __host__ __device__ inline int order_windows(int RT) { return ((RT >> 3) + kOrderWindow - 1) / kOrderWindow; }
 __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restrict__ count,
                                                  const uint32_t* __restrict__ flags, uint2* __restrict__ order, int RT,
-                                                 int T, uint32_t cap, uint32_t dense_thr) {
+                                                 int T, uint32_t cap, uint32_t dense_thr, uint32_t dense_thr_fwd) {
+    auto dense_bits = [&](uint32_t f, uint32_t n) {
+        return (tile_is_dense(f, n, dense_thr) ? kOrderDenseBwd : 0u) | (tile_is_dense(f, n, dense_thr_fwd) ? kOrderDenseFwd : 0u);
+    };
     __shared__ uint32_t s_cnt[kOrderClasses];
     const int nwin = order_windows(RT), x = id / nwin, w = id - x * nwin;
     const XcdMap xm = xcd_map(RT, T);                               // (which tiles this XCD's slots stand for)
@@ -419,7 +419,7 @@ __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restr
         for (int i = threadIdx.x; i < len; i += nthr) {
             const int vid = xcd_tile(xm, T, x, j0 + i);
             const uint32_t n = min(count[vid], cap);
-            order[lo + i] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
+            order[lo + i] = make_uint2((uint32_t)vid | dense_bits(flags[vid], n), n);
         }
         return;
     }
@@ -444,40 +444,15 @@ __device__ __forceinline__ void tile_order_block(int id, const uint32_t* __restr
         const int vid = xcd_tile(xm, T, x, j0 + i);
         const uint32_t n = min(count[vid], cap);
         const uint32_t pos = atomicAdd(&s_cnt[cls(n)], 1u);
-        order[lo + pos] = make_uint2((uint32_t)vid | (tile_is_dense(flags[vid], n, dense_thr) ? 0x80000000u : 0u), n);
+        order[lo + pos] = make_uint2((uint32_t)vid | dense_bits(flags[vid], n), n);
     }
 }
 // (on its own: when no tile has more than one entry, the sort launches nothing)
 __global__ __launch_bounds__(kBlock) void spf_tile_order_kernel(const uint32_t* __restrict__ count,
                                                                 const uint32_t* __restrict__ flags,
                                                                 uint2* __restrict__ order, int RT, int T, uint32_t cap,
-                                                                uint32_t dense_thr) {
-    tile_order_block((int)blockIdx.x, count, flags, order, RT, T, cap, dense_thr);
-}
-
-// Direct bins: nobody scans the tiles, so the sparse / dense census of a PLANNED call (dense_hint = 0: no dense tile,
-// = RT: every tile dense) is verified here, by the one sort kernel that visits every tile -- before the render kernels
-// look at the verdict.  One lane per tile; flag bit 4 as in the binning kernels' plan check.
-__device__ __forceinline__ void census_check(const TileLists& tl, const uint32_t* __restrict__ flags,
-                                             uint32_t* __restrict__ counters, int tile, uint32_t n, int RT,
-                                             uint32_t dense_hint, uint32_t dense_thr) {
-    if (!tl.cap || (threadIdx.x & (kWave - 1)) != 0) return;
-    if (dense_hint != 0u && dense_hint != (uint32_t)RT) return;            // both render kernels run: nothing assumed
-    const bool dense = tile_is_dense(flags[tile], n, dense_thr);
-    if (dense != (dense_hint != 0u)) atomicOr(&counters[2], 4u);
-}
-
-// The census on its own: a planned call whose longest list is one entry launches no sort kernel at all (nothing to
-// sort), so nobody would visit the tiles -- one lane per tile here (a one-entry tile under a large footprint IS dense).
-__global__ __launch_bounds__(kBlock) void spf_tile_census_kernel(TileLists tl, const uint32_t* __restrict__ flags,
-                                                                 uint32_t* __restrict__ counters, int RT,
-                                                                 uint32_t dense_hint, uint32_t dense_thr) {
-    const int tile = (int)(blockIdx.x * kBlock + threadIdx.x);
-    if (tile >= RT) return;
-    uint32_t b, n;
-    tile_range(tl, (size_t)tile, b, n);
-    const bool dense = tile_is_dense(flags[tile], n, dense_thr);
-    if (dense != (dense_hint != 0u)) atomicOr(&counters[2], 4u);
+                                                                uint32_t dense_thr, uint32_t dense_thr_fwd) {
+    tile_order_block((int)blockIdx.x, count, flags, order, RT, T, cap, dense_thr, dense_thr_fwd);
 }
 
 // ---- per-tile sort in LDS ---------------------------------------------------------------------
@@ -625,19 +600,18 @@ template <int E, bool SMALL>
 __global__ __launch_bounds__(kBlock) void spf_sort_tiles_wave_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                      uint32_t* __restrict__ counters,
                                                                      uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                     uint32_t lo, int RT, uint32_t dense_hint,
-                                                                     uint32_t dense_thr, uint2* __restrict__ order, int T) {
+                                                                     uint32_t lo, int RT,
+                                                                     uint32_t dense_thr, uint2* __restrict__ order, int T, uint32_t dense_thr_fwd) {
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr, dense_thr_fwd);
         return;
     }
     const int tile = ((int)blockIdx.x - ob) * (kBlock / kWave) + (threadIdx.x >> 6);
     if (tile >= RT) return;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
-    if (SMALL) census_check(tl, flags, counters, tile, n, RT, dense_hint, dense_thr);
     if (n <= lo || n > (uint32_t)(kWave * E)) return;
     if (SMALL) {
         if (n <= 2u * kWave) sort_tile_in_wave<2>(pairs + b, n);
@@ -751,19 +725,18 @@ __device__ __forceinline__ void sort_tile_in_pair(uint64_t* __restrict__ p, uint
 __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                         uint32_t* __restrict__ counters,
                                                                         uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                        int RT, uint32_t dense_hint, uint32_t dense_thr,
-                                                                        uint2* __restrict__ order, int T) {
+                                                                        int RT, uint32_t dense_thr,
+                                                                        uint2* __restrict__ order, int T, uint32_t dense_thr_fwd) {
     __shared__ uint64_t s_x[8 * 2 * kWave];
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr, dense_thr_fwd);
         return;
     }
     const int tile = (int)blockIdx.x - ob;
     uint32_t b, n;
     tile_range(tl, tile, b, n);
-    census_check(tl, flags, counters, tile, n, RT, dense_hint, dense_thr);
     if (n <= 1u || n > 1024u) return;
     if (n <= 4u * kWave) {                            // one wave is enough (and as fast): the second leaves
         if (threadIdx.x >= kWave) return;
@@ -784,20 +757,19 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
 __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                       uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
-                                                                      int RT, uint32_t dense_hint, uint32_t dense_thr,
-                                                                      uint2* __restrict__ order, int T) {
+                                                                      int RT, uint32_t dense_thr,
+                                                                      uint2* __restrict__ order, int T, uint32_t dense_thr_fwd) {
     __shared__ uint64_t s_x[8 * kBlock];
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
-        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr);
+        tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr, dense_thr_fwd);
         return;
     }
     const int blk = (int)blockIdx.x - ob;
     if (blk < RT) {
         uint32_t b, n;
         tile_range(tl, blk, b, n);
-        census_check(tl, flags, counters, blk, n, RT, dense_hint, dense_thr);
         if (n <= 512u || n > 2048u) return;
         if (n <= 1024u) sort_tile_in_block<4>(pairs + b, n, s_x);
         else sort_tile_in_block<8>(pairs + b, n, s_x);
@@ -919,10 +891,9 @@ hipError_t launch_tile_scan(const SpfState& st, int R, int T, int nblk, uint32_t
     return hipGetLastError();
 }
 
-// `dense_hint` / `RT_total`: the WHOLE call's dense-tile assumption and tile count (the plan check compares them with the
-// joint scan's census); `d` may describe a chunk of the call's renders.
+// (`d` may describe a chunk of the call's renders)
 hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capacity, int T, int tiles_x,
-                            uint32_t max_tile_hint, uint32_t dense_hint, uint32_t RT_total, hipStream_t stream) {
+                            uint32_t max_tile_hint, hipStream_t stream) {
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S * d.V);
     const int lds = T <= max_lds_tiles() ? 1 : 0;
     // Two views of a scene per block when a render has many blocks (measured, views per block 1 / 2 / 4: 320,000 Gaussians
@@ -937,12 +908,12 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
         dim3 vgrid(nblk, d.S * nvb);
         spf_bin_pairs_views_kernel<2><<<vgrid, kBlock, (size_t)4 * T * sizeof(uint32_t), stream>>>(
             st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
-            d.G, T, tiles_x, d.V, nvb, max_tile_hint, dense_hint, RT_total);
+            d.G, T, tiles_x, d.V, nvb, max_tile_hint);
         return hipGetLastError();
     }
     spf_bin_pairs_kernel<<<grid, kBlock, lds ? 2 * sizeof(uint32_t) * T : 0, stream>>>(
         st.zkey, st.rect, st.tile_start, st.tile_fill, st.counters, st.pairs, capacity, st.blk_base, st.pair_off,
-        d.G, T, tiles_x, lds, max_tile_hint, dense_hint, RT_total);
+        d.G, T, tiles_x, lds, max_tile_hint);
     return hipGetLastError();
 }
 
@@ -950,17 +921,16 @@ hipError_t launch_bin_pairs(const SpfDims& d, const SpfState& st, uint64_t capac
 // per tile, list in registers, three LDS exchanges; (4096, 8192], (8192, 16384]: one 1024-thread
 // block per tile in LDS; > 16384: chunked LDS sort with a few global merge passes.  `max_tile_hint` (0 = unknown) lets the host skip empty classes.
 // `RT`: tiles of this launch; `RT_call`: tiles of the whole call it is a chunk of (picks the kernel family).
-// `tl`: where the lists are (packed, or direct bins: then the family's first kernel also verifies the planned dense-tile
-// census `dense_hint`, see census_check)
+// `tl`: where the lists are (packed, or direct bins)
 // `order` (direct bins, or null): eight more blocks in front of the first kernel write the composite lists kernels' launch
 // order there (tile_order_block).
 hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int RT_call, uint64_t capacity,
-                            uint32_t max_tile_hint, uint32_t dense_hint, const uint2* order_c, int T,
+                            uint32_t max_tile_hint, const uint2* order_c, int T,
                             hipStream_t stream) {   // T: tiles per render (0: contiguous tile ranges per XCD, see xcd_map)
     uint2* order = const_cast<uint2*>(order_c);
     const int ob = order ? 8 * order_windows(RT) : 0;
     const uint32_t mx = max_tile_hint ? max_tile_hint : 0xffffffffu;
-    const uint32_t thr = dense_threshold();
+    const uint32_t thr = dense_threshold(), thr_f = dense_threshold_fwd();
     const int wgrid = (RT + kBlock / kWave - 1) / (kBlock / kWave);
     // Lists of 513 .. 2048 entries: one wave per tile (16 / 32 keys per lane) when there are enough tiles to fill the
     // chip with single waves, one 256-thread block per tile when there are not (measured: 2,048 tiles of ~1,000 entries
@@ -970,28 +940,25 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
-        spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr);
-    if (tl.cap && !(mx > 1) && (dense_hint == 0u || dense_hint == (uint32_t)RT))   // ... and the census (see the kernel)
-        spf_tile_census_kernel<<<(RT + kBlock - 1) / kBlock, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, RT,
-                                                                                   dense_hint, thr);
+        spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr, thr_f);
     if (mixed)
         spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
-                                                                            RT, dense_hint, thr, order, T);
+                                                                            RT, thr, order, T, thr_f);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     // (8 px grid: lists are a quarter as long -- up to 512 entries one wave per tile, four tiles per block, is the better fit)
     const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE") && (kTile == 16 || mx > 512);
     if (pairsk)
         spf_sort_tiles_pair_kernel<<<ob + RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
-                                                                      dense_hint, thr, order, T);
+                                                                      thr, order, T, thr_f);
     if (mx > 1 && (mx <= 512 || blocks) && !mixed && !pairsk)  // lists of 2 .. 512: four tiles per block, one wave each, 2 / 4 / 8 keys per lane
         spf_sort_tiles_wave_kernel<8, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                               capacity, 1, RT, dense_hint, thr, order, T);
+                                                                               capacity, 1, RT, thr, order, T, thr_f);
     if (mx > 512 && !blocks && !pairsk)     // 2 .. 1024 with one wave per tile (up to 16 keys per lane)
         spf_sort_tiles_wave_kernel<16, true><<<ob + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                                capacity, 1, RT, dense_hint, thr, order, T);
+                                                                                capacity, 1, RT, thr, order, T, thr_f);
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
-                                                                            capacity, 1024, RT, dense_hint, thr, nullptr, 0);
+                                                                            capacity, 1024, RT, thr, nullptr, 0, thr_f);
     if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
     if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread

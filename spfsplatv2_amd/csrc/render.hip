@@ -26,19 +26,16 @@ constexpr int kStage = 256;  // list entries staged per round (one per thread) o
 constexpr int kFwdLongRoundsMaxTiles = 768;    // calls of at most this many tiles: 512-entry rounds in the forward lists kernel
 
 struct BlockCtx {
-    int r, tile, tx, ty, wave, lane, row, l16, beta, px, py;
+    int r, tx, ty, wave, lane, row, l16, beta, px, py;
     bool inside;
 };
 
 // Work decomposition shared by forward and backward: block = tile, wave = 8x8 sub-tile, DPP row (16 lanes)
 // = 4x4 pixel block `beta` (row-major over the tile's 4x4 grid of blocks).
-__device__ __forceinline__ bool block_ctx(BlockCtx& c, int RT, int T, int tiles_x, int H, int W) {
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    if (vid >= RT) return false;
-    c.r = vid / T;
-    c.tile = vid - c.r * T;
-    c.ty = c.tile / tiles_x;
-    c.tx = c.tile - c.ty * tiles_x;
+__device__ __forceinline__ void block_ctx_at(BlockCtx& c, int r, int tx, int ty, int H, int W) {
+    c.r = r;
+    c.ty = ty;
+    c.tx = tx;
     c.wave = threadIdx.x >> 6;
     c.lane = threadIdx.x & 63;
     c.row = c.lane >> 4;
@@ -48,7 +45,6 @@ __device__ __forceinline__ bool block_ctx(BlockCtx& c, int RT, int T, int tiles_
     c.px = c.tx * kTile + bx * 4 + (c.l16 & 3);
     c.py = c.ty * kTile + by * 4 + (c.l16 >> 2);
     c.inside = c.px < W && c.py < H;
-    return true;
 }
 
 // First three steps of the row reduction (lane i <- x[i] + x[i-1] + x[i-2] + x[i-3]); hipcc fuses each
@@ -137,27 +133,18 @@ __device__ __forceinline__ void poison_tile(int RT, int T, int tiles_x, int H, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Forward: front-to-back compositing, one 4x4 pixel block per DPP row (see the header comment).
+// Forward of a DENSE tile ("rows"): front-to-back compositing, one 4x4 pixel block per DPP row (see the header
+// comment).  Not a kernel of its own: the forward kernel below runs it for the tiles the launch order marks dense, on
+// its own LDS (256 staged entries: 10.5 KB of the 18.7 KB the lists form holds) -- one launch composites every tile.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void spf_render_fwd_rows_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
-    const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
-    const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
-    float* __restrict__ alpha_out, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int G, int H, int W,
-    int T, int tiles_x, int RT, uint32_t dense_thr) {
-    __shared__ float4 s_p0[kStage];   // x, y, A, B
-    __shared__ float2 s_p1[kStage];   // C, opacity
-    __shared__ float4 s_p2[kStage];   // r, g, b, depth
-    __shared__ uint32_t s_mask[kStage / 32][16];   // [32-entry chunk][4x4 block]
-
-    (void)capacity;
-    if (counters[2] != 0u) { poison_tile(RT, T, tiles_x, H, W, image, depth_out, alpha_out); return; }
+__device__ __forceinline__ void fwd_rows_tile(float4* s_p0, float2* s_p1, float4* s_p2, uint32_t (*s_mask)[16],
+                                              const float* __restrict__ rec_r, const uint64_t* __restrict__ pairs,
+                                              uint32_t beg, uint32_t n, int r, int tx, int ty,
+                                              const float* __restrict__ bg_all, float* __restrict__ image,
+                                              float* __restrict__ depth_out, float* __restrict__ alpha_out,
+                                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, int H, int W) {
     BlockCtx c;
-    if (!block_ctx(c, RT, T, tiles_x, H, W)) return;
-    uint32_t beg, n;
-    tile_range(tl, (size_t)c.r * T + c.tile, beg, n);
-    if (!tile_is_dense(tile_flags[(size_t)c.r * T + c.tile], n, dense_thr)) return;   // sparse tiles: lists kernel
-    const float* __restrict__ rec_r = rec + (size_t)c.r * G * kRec;
+    block_ctx_at(c, r, tx, ty, H, W);
     float fx = (float)c.px, fy = (float)c.py;
     asm volatile("" : "+v"(fx), "+v"(fy));   // keep the converted coordinates live (no per-iteration v_cvt)
 
@@ -360,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     int vid;
     uint32_t beg, n;
     bool dense_tile;
-    if (!lists_tile(tl, tile_flags, dense_thr, RT, vid, beg, n, dense_tile)) return;
+    if (!lists_tile(tl, tile_flags, dense_thr, true, RT, vid, beg, n, dense_tile)) return;
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x;
@@ -372,8 +359,12 @@ __global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
     const int pid = ly * kTile + lx;            // this thread's pixel inside the tile (row-major): its candidate column
     const int px = X0 + lx, py = Y0 + ly;
     const bool inside = px < W && py < H;
-    if (dense_tile) return;                                                          // dense tiles: rows kernel
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
+    if (dense_tile) {                                                                // (block-uniform)
+        fwd_rows_tile(s_p0, s_p1, s_p2, reinterpret_cast<uint32_t (*)[16]>(&s_pm[0][0]), rec_r, pairs, beg, n, r, tx, ty,
+                      bg_all, image, depth_out, alpha_out, final_T, n_contrib, H, W);
+        return;
+    }
     float fx = (float)px, fy = (float)py;
     asm volatile("" : "+v"(fx), "+v"(fy));
     const v2f fxy = {fx, fy};
@@ -523,38 +514,26 @@ __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t s
     store_grec<DEPTH_GRAD>(gpair, slot, acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7], acc[8], acc[9]);
 }
 
-template <bool DEPTH_GRAD>
-__global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
-    const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
-    const uint32_t* __restrict__ tile_flags, const float* __restrict__ bg_all, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dimage, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
-    const uint2* __restrict__ pinfo, float* __restrict__ gpair, int G, int H,
-    int W, int T, int tiles_x, int RT, uint32_t dense_thr, const uint32_t* __restrict__ counters, uint64_t capacity) {
-    (void)capacity;
-    if (counters[2] != 0u) return;           // failed plan: nothing was rendered; the projection backward poisons the gradients
-    __shared__ float4 s_p0[kStage];
-    __shared__ float2 s_p1[kStage];
-    __shared__ float4 s_p2[kStage];
-    __shared__ uint32_t s_slot[kStage];           // Gaussian-major pair index of each staged entry
-    __shared__ float s_acc[kStage][kAcc];         // per-entry gradient accumulators of the whole tile
-    __shared__ uint32_t s_mask[kStage / 32][16];   // [32-entry chunk][4x4 block]
-    __shared__ uint32_t s_wmax[4];
-
-    const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    if (vid >= RT) return;
-    const int r = vid / T, tile = vid - r * T;
-    uint32_t beg, n;
-    tile_range(tl, (size_t)r * T + tile, beg, n);
-    if (!tile_is_dense(tile_flags[(size_t)r * T + tile], n, dense_thr)) return;   // sparse tiles: lists kernel
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+// Backward of a DENSE tile ("rows"); like fwd_rows_tile not a kernel of its own: the backward kernel below runs it for the
+// tiles the launch order marks dense, on its own LDS.  RS = entries staged per round (the kernel's kRoundL <= 256: one per
+// thread, threads >= RS stage nothing); s_slot / s_acc live in the lists form's slot pool.
+template <bool DEPTH_GRAD, int RS>
+__device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4* s_p2, uint32_t* s_slot,
+                                              float (*s_acc)[kAcc], uint32_t (*s_mask)[16], uint32_t* s_wmax,
+                                              const float* __restrict__ rec_r, const uint64_t* __restrict__ pairs,
+                                              uint32_t beg, uint32_t n, int r, int tx, int ty,
+                                              const float* __restrict__ bg_all, const float* __restrict__ final_T,
+                                              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dimage,
+                                              const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha,
+                                              const uint2* __restrict__ pinfo, float* __restrict__ gpair, int G, int H,
+                                              int W) {
+    static_assert(RS % 32 == 0 && RS <= kBlock, "one staged entry per thread, whole mask words");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15;
     const int bx = (wave & 1) * 2 + (row & 1), by = (wave >> 1) * 2 + (row >> 1);
     const int beta = by * 4 + bx;
     const int px = tx * kTile + bx * 4 + (l16 & 3), py = ty * kTile + by * 4 + (l16 >> 2);
     const bool inside = px < W && py < H;
 
-    if (n == 0) return;
-    const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     const float fx = (float)px, fy = (float)py;
     const size_t P = (size_t)H * W, pix = (size_t)py * W + px;
     // Gaussian-major index of list entry idx's (Gaussian, tile) pair: ONE 8-byte gather (rect, first pair)
@@ -598,12 +577,12 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lD = 0.f;
 
     bool staged = false;
-    for (int base = (int)((bmax - 1) / kStage) * kStage; base >= 0; base -= kStage) {
+    for (int base = (int)((bmax - 1) / RS) * RS; base >= 0; base -= RS) {
         // flush the previous round's accumulators: ONE plain 48-byte store per (Gaussian, tile) pair
         if (staged) flush_pair<DEPTH_GRAD>(gpair, s_slot[threadIdx.x], s_acc[threadIdx.x]);
         uint32_t bits = 0;
         const uint32_t idx = (uint32_t)base + threadIdx.x;
-        staged = idx < n && idx < bmax;
+        staged = (int)threadIdx.x < RS && idx < n && idx < bmax;
         if (staged) {
             const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
@@ -620,12 +599,12 @@ __global__ __launch_bounds__(kBlock) void spf_render_bwd_rows_kernel(
         for (int k = 0; k < 16; ++k) {
             const uint64_t m = __ballot((bits >> k) & 1u);
             if (lane == 0) {
-                s_mask[2 * wave][k] = (uint32_t)m;
-                s_mask[2 * wave + 1][k] = (uint32_t)(m >> 32);
+                if (2 * wave < RS / 32) s_mask[2 * wave][k] = (uint32_t)m;
+                if (2 * wave + 1 < RS / 32) s_mask[2 * wave + 1][k] = (uint32_t)(m >> 32);
             }
         }
         __syncthreads();
-        for (int q = kStage / 32 - 1; q >= 0; --q) {
+        for (int q = RS / 32 - 1; q >= 0; --q) {
             const uint32_t qbase = (uint32_t)base + (uint32_t)q * 32u;
             if (qbase >= wmax) continue;
             uint32_t m = s_mask[q][beta];
@@ -754,13 +733,22 @@ __global__ __launch_bounds__(kBlock, BPC) void spf_render_bwd_lists_kernel(
     int vid;
     uint32_t beg, n;
     bool dense_tile;
-    if (!lists_tile(tl, tile_flags, dense_thr, RT, vid, beg, n, dense_tile)) return;
+    if (!lists_tile(tl, tile_flags, dense_thr, false, RT, vid, beg, n, dense_tile)) return;
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = tx * kTile, Y0 = ty * kTile;
     if (n == 0) return;
-    if (dense_tile) return;                                                          // dense tiles: rows kernel
+    if (dense_tile) {                                                                // (block-uniform)
+        static_assert(sizeof(float2) * kPool >= (sizeof(uint32_t) + sizeof(float) * kAcc) * kRoundL, "rows scratch fits the pool");
+        uint32_t* const s_slot = reinterpret_cast<uint32_t*>(s_pool);
+        bwd_rows_tile<DEPTH_GRAD, kRoundL>(s_p0, reinterpret_cast<float2*>(s_p1), s_p2, s_slot,
+                                           reinterpret_cast<float (*)[kAcc]>(s_slot + kRoundL),
+                                           reinterpret_cast<uint32_t (*)[16]>(&s_pm[0][0]), s_wmax,
+                                           rec + (size_t)r * G * kRec, pairs, beg, n, r, tx, ty, bg_all, final_T, n_contrib,
+                                           dL_dimage, dL_ddepth, dL_dalpha, pinfo, gpair, G, H, W);
+        return;
+    }
     const size_t P = (size_t)H * W;
     // ---- per-pixel state: thread <-> pixel in the natural order ----
     // (Rounds 1 - 3 put the pixels on lanes by the number of contributors the forward recorded -- an LDS counting sort,
@@ -1021,121 +1009,72 @@ hipError_t launch_render_fwd_wave(const SpfDims&, const SpfInputs&, const SpfSta
                                   const TileLists&, hipStream_t);                     // render_wave.hip
 hipError_t launch_render_bwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int,
                                   const TileLists&, hipStream_t);
+uint32_t dense_threshold_fwd();
 uint32_t dense_threshold() {
     static const uint32_t v = getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA;
     return v;
+}
+// The forward's own threshold (>= the backward's).  Round-5 sweep (same box, C2 with footprints x 3 / 6 / 10 / 30 and C5 x 1 /
+// 4): the lists FORWARD beats the rows forward up to far denser tiles than the lists backward beats the rows backward
+// (x 6: forward 201 us through rows vs 125 through lists, backward 525 vs 566; x 10: 269 vs 190 and 742 vs 1,468; only at
+// x 30 do the rows win the forward, 508 vs 1,228) -- with one threshold for both, every tile handed to the rows kernels for
+// the backward's sake cost the forward 20 - 40 %.  SPF_DENSE_AREA (experiments) pins both.
+uint32_t dense_threshold_fwd() {
+    static const uint32_t v = getenv("SPF_DENSE_AREA_FWD") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA_FWD"))
+                              : (getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA_FWD);
+    return v > dense_threshold() ? v : dense_threshold();
 }
 
 // When both the sparse and the dense kernel have tiles, they run CONCURRENTLY: the dense one is forked onto an
 // auxiliary stream (event fork / join, capturable in a HIP graph) so that a few long-running dense tiles do not
 // serialise behind -- or in front of -- the sparse kernel's wave of short blocks.  One auxiliary stream per device,
 // created on first use; this is the only state the library keeps besides the stage-timing events.
-struct AuxStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static AuxStream* aux_stream() {
-    // one auxiliary stream + event pair per (device, calling thread): a thread's launches are ordered on ITS streams,
-    // so two host threads (or two devices) never share -- and never race on -- an event pair
-    static thread_local AuxStream aux[32];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    AuxStream& a = aux[dev];
-    if (!a.s) {
-        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) { a.s = nullptr; return nullptr; }
-        if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamDestroy(a.s);
-            a.s = nullptr;
-            return nullptr;
-        }
-    }
-    return &a;
-}
-// Returns the stream the dense kernel should be launched on (the caller's own stream if forking is not possible).
-static hipStream_t fork_dense(hipStream_t stream, AuxStream*& a) {
-    a = getenv("SPF_NO_FORK") ? nullptr : aux_stream();
-    if (!a) return stream;
-    if (hipEventRecord(a->fork, stream) != hipSuccess || hipStreamWaitEvent(a->s, a->fork, 0) != hipSuccess) {
-        a = nullptr;
-        return stream;
-    }
-    return a->s;
-}
-static void join_dense(hipStream_t stream, AuxStream* a) {
-    if (!a) return;
-    (void)hipEventRecord(a->join, a->s);
-    (void)hipStreamWaitEvent(stream, a->join, 0);
-}
-
-// Every tile is rendered by exactly one of the two kernels (decided per tile from tile_flags / list length);
-// `dense_hint` (number of dense tiles, or SPF_UNKNOWN) only lets the host skip a launch that would find no tile.
+// ONE launch composites every tile: the kernel takes the "rows" or the "lists" form per tile (launch-order flag, or
+// tile_flags / list length in image order).  Rounds 2 - 4 ran two kernels on forked streams and skipped one of them from
+// the plan's dense-tile census (`dense_hint`); the empty or near-empty second launch cost 7 - 20 us a direction on every
+// scene with a handful of dense tiles, and the fork's event edges on every exact call.
 hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfOutputs& out,
-                             uint64_t capacity, int T, int tiles_x, uint32_t dense_hint, bool ordered, hipStream_t stream) {
+                             uint64_t capacity, int T, int tiles_x, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
-    const TileLists tl = tile_lists(st, d);
-    TileLists tlo = tl;                           // (the lists kernel only: the rows kernel keeps the image order)
+    TileLists tlo = tile_lists(st, d);
     if (ordered) tlo.order = tile_order_ptr(st, d, RT);
     if (kTile == 8) return launch_render_fwd_wave(d, in, st, out, T, tiles_x, tlo, stream);   // one wave per 8x8 tile
     const int grid = (RT + 7) / 8 * 8;
-    const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
-    AuxStream* a = nullptr;
-    const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
-    if (sparse) {
-        const char* const fe = getenv("SPF_FWD_STAGE");       // ("256" / "512" pins the instantiation: experiments, tests)
-        const int stage = fe ? atoi(fe) : (RT <= kFwdLongRoundsMaxTiles ? 512 : 256);
-        if (stage == 512)
-            spf_render_fwd_lists_kernel<512><<<grid, kBlock, 0, stream>>>(
-                st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-                out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
-        else
-            spf_render_fwd_lists_kernel<256><<<grid, kBlock, 0, stream>>>(
-                st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-                out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
-    }
-    if (dense)
-        spf_render_fwd_rows_kernel<<<grid, kBlock, 0, ds>>>(
-            st.rec, st.pairs, tl, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
-            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold());
-    join_dense(stream, a);
+    const char* const fe = getenv("SPF_FWD_STAGE");           // ("256" / "512" pins the instantiation: experiments, tests)
+    const int stage = fe ? atoi(fe) : (RT <= kFwdLongRoundsMaxTiles ? 512 : 256);
+    if (stage == 512)
+        spf_render_fwd_lists_kernel<512><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold_fwd());
+    else
+        spf_render_fwd_lists_kernel<256><<<grid, kBlock, 0, stream>>>(
+            st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,
+            out.alpha, st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold_fwd());
     return hipGetLastError();
 }
 
 template <bool DG>
 static void launch_render_bwd_t(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                                int tiles_x, int RT, int grid, uint32_t dense_hint, uint64_t capacity, bool ordered,
-                                hipStream_t stream) {
-    const bool sparse = dense_hint != (uint32_t)RT, dense = dense_hint != 0u;
-    const TileLists tl = tile_lists(st, d);
-    TileLists tlo = tl;
+                                int tiles_x, int RT, int grid, uint64_t capacity, bool ordered, hipStream_t stream) {
+    TileLists tlo = tile_lists(st, d);
     if (ordered) tlo.order = tile_order_ptr(st, d, RT);
     const uint2* const pinfo = reinterpret_cast<const uint2*>(st.pair_off);
-    AuxStream* a = nullptr;
-    const hipStream_t ds = (sparse && dense) ? fork_dense(stream, a) : stream;     // fork BEFORE the sparse launch
-    if (sparse) {
-        // round shape by the number of tiles (see the kernel); SPF_BWD_ROUNDS=192 / 224 / 256 pins one (experiments, tests)
-        const char* const fe = getenv("SPF_BWD_ROUNDS");      // (read per call: the tests flip it)
-        const int forced = fe ? atoi(fe) : 0;
-        const int shape = forced ? forced : (RT <= 768 ? 256 : (RT <= 2048 ? 224 : 192));
+    // round shape by the number of tiles (see the kernel); SPF_BWD_ROUNDS=192 / 224 / 256 pins one (experiments, tests)
+    const char* const fe = getenv("SPF_BWD_ROUNDS");          // (read per call: the tests flip it)
+    const int forced = fe ? atoi(fe) : 0;
+    const int shape = forced ? forced : (RT <= 768 ? 256 : (RT <= 2048 ? 224 : 192));
 #define SPF_BWD_LISTS(RL, PL, BPC)                                                                                      \
-        spf_render_bwd_lists_kernel<DG, RL, PL, BPC><<<grid, kBlock, 0, stream>>>(                                        \
-            st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha, \
-            pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters, capacity)
-        if (shape == 256) SPF_BWD_LISTS(256, 2560, 3);
-        else if (shape == 224) SPF_BWD_LISTS(224, 1792, 4);
-        else SPF_BWD_LISTS(192, 1536, 5);
+    spf_render_bwd_lists_kernel<DG, RL, PL, BPC><<<grid, kBlock, 0, stream>>>(                                            \
+        st.rec, st.pairs, tlo, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth, g.dL_dalpha,     \
+        pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters, capacity)
+    if (shape == 256) SPF_BWD_LISTS(256, 2560, 3);
+    else if (shape == 224) SPF_BWD_LISTS(224, 1792, 4);
+    else SPF_BWD_LISTS(192, 1536, 5);
 #undef SPF_BWD_LISTS
-    }
-    if (dense)
-        spf_render_bwd_rows_kernel<DG><<<grid, kBlock, 0, ds>>>(
-            st.rec, st.pairs, tl, st.tile_flags, in.bg, st.final_T, st.n_contrib, g.dL_dimage, g.dL_ddepth,
-            g.dL_dalpha, pinfo, g.gpair, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold(), st.counters,
-            capacity);
-    join_dense(stream, a);
 }
 
 hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g, int T,
-                             int tiles_x, uint32_t dense_hint, uint64_t capacity, bool ordered, hipStream_t stream) {
+                             int tiles_x, uint64_t capacity, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
     if (kTile == 8) {
@@ -1143,8 +1082,8 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
         if (ordered) tlo.order = tile_order_ptr(st, d, RT);
         return launch_render_bwd_wave(d, in, st, g, T, tiles_x, tlo, stream);
     }
-    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
-    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, dense_hint, capacity, ordered, stream);
+    if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, capacity, ordered, stream);
+    else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, capacity, ordered, stream);
     return hipGetLastError();
 }
 

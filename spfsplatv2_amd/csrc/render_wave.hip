@@ -119,7 +119,7 @@ __device__ __forceinline__ bool wave_tile(const TileLists& tl, int RT, int& vid,
     const int slot = xcd_remap(blockIdx.x, gridDim.x);
     if (tl.order) {
         const uint2 o = tl.order[slot];
-        vid = (int)(o.x & 0x7fffffffu);
+        vid = (int)(o.x & kOrderTileMask);
         n = o.y;
         beg = (uint32_t)vid * tl.cap;
         return vid < RT;

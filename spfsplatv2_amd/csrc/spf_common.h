@@ -296,15 +296,18 @@ __device__ __forceinline__ int xcd_remap(int block, int grid) {
     const int per = grid >> 3;
     return (block & 7) * per + (block >> 3);
 }
+// launch-order records: tile id in the low 30 bits, "dense for the backward" / "dense for the forward" above
+constexpr uint32_t kOrderTileMask = 0x3fffffffu, kOrderDenseBwd = 0x80000000u, kOrderDenseFwd = 0x40000000u;
 // The tile this block of a composite lists launch works on (false: none), where its list is and whether the tile
-// belongs to the dense (rows) kernel: in image order, or from the launch order.
+// belongs to the dense (rows) kernel of this direction (`dense_thr`, `forward`): in image order, or from the launch order.
 __device__ __forceinline__ bool lists_tile(const TileLists& tl, const uint32_t* __restrict__ tile_flags,
-                                           uint32_t dense_thr, int RT, int& vid, uint32_t& beg, uint32_t& n, bool& dense) {
+                                           uint32_t dense_thr, bool forward, int RT, int& vid, uint32_t& beg, uint32_t& n,
+                                           bool& dense) {
     const int slot = xcd_remap(blockIdx.x, gridDim.x);
     if (tl.order) {
         const uint2 o = tl.order[slot];
-        vid = (int)(o.x & 0x7fffffffu);
-        dense = (o.x >> 31) != 0u;
+        vid = (int)(o.x & kOrderTileMask);
+        dense = (o.x & (forward ? kOrderDenseFwd : kOrderDenseBwd)) != 0u;
         n = o.y;
         beg = (uint32_t)vid * tl.cap;
         return vid < RT;

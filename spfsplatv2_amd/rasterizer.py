@@ -73,7 +73,6 @@ class PairBudget(NamedTuple):
 
     capacity       pair-buffer entries to allocate
     max_tile_list  assumed upper bound of the longest tile list (0 = unknown: all sort size classes are launched)
-    dense_tiles    None = unknown (both render kernels are launched); 0 = no dense tile; -1 = every tile is dense
     check          "backward": the backward pass reads the flag (one host sync) and raises if the plan failed (a call
                    that will have no backward verifies at once; ``DecoderSplattingCUDA``'s replayed evaluation graphs
                    re-run such a call in exact mode instead of raising);
@@ -81,7 +80,6 @@ class PairBudget(NamedTuple):
     """
     capacity: int
     max_tile_list: int = 0
-    dense_tiles: Optional[int] = None
     check: str = "backward"
 
 
@@ -90,20 +88,20 @@ _SORT_CLASSES = (128, 256, 512, 1024, 2048, 4096, 8192, 16384)
 
 def plan_pair_budget(stats: Optional[dict] = None, slack: float = 1.25, check: str = "backward") -> PairBudget:
     """Budget for the next calls from the statistics of an exact-mode call (default: the most recent one, see
-    ``last_forward_stats``): ``slack`` x the pairs it produced, the list-length class its longest list (x slack) falls
-    in, and its sparse/dense tile census when that was one-sided."""
+    ``last_forward_stats``): ``slack`` x the pairs it produced and the list-length class its longest list (x slack) falls
+    in.  (Rounds 2 - 4 also planned which of two compositing kernels to launch from the call's dense-tile census; one
+    kernel composites every tile now, so there is nothing left to assume -- ``dense_tiles`` stays a statistic.)"""
     st = dict(_last if stats is None else stats)
     if "num_pairs" not in st:
         raise RuntimeError("plan_pair_budget needs the statistics of an exact-mode forward call (max_pairs=None)")
     want = int(st["max_tile_list"] * slack) + 1
     max_tile = next((c for c in _SORT_CLASSES if c >= want), 0)
-    dense = 0 if st.get("dense_tiles", 1) == 0 else (-1 if st.get("dense_tiles") == st.get("tiles") else None)
-    return PairBudget(int(st["num_pairs"] * slack) + 1024, max_tile, dense, check)
+    return PairBudget(int(st["num_pairs"] * slack) + 1024, max_tile, check)
 
 
 def plan_flags(record: Optional[CallRecord] = None) -> int:
     """Device-side verdict on the plan of a planned forward call (synchronises with the device): 0 = the plan held;
-    bit 1 = pair buffer too small, bit 2 = a tile list longer than planned, bit 4 = dense/sparse assumption wrong.
+    bit 1 = pair buffer too small, bit 2 = a tile list longer than planned.
     Non-zero: that call's outputs and its backward's gradients are all NaN (never garbage) -- re-run it in exact mode
     or with a larger budget.  `record`: the CallRecord the call was given (default: the process-wide last call)."""
     c = (_last if record is None else record).get("counters")
@@ -349,12 +347,10 @@ def _record_capacity(capacity: int, S: int, G: int) -> int:
 
 
 def _plan_numbers(max_pairs, RT: int):
-    """(capacity, longest-list hint, dense-tile hint) of a planned call as spf_raster_forward_render takes them."""
+    """(capacity, longest-list hint, dense-tile hint) of a planned call as spf_raster_forward_render takes them (the
+    last is ignored by the library since one kernel composites every tile: always SPF_UNKNOWN)."""
     plan = max_pairs if isinstance(max_pairs, PairBudget) else PairBudget(int(max_pairs))
-    dense = 0xFFFFFFFF if plan.dense_tiles is None else (RT if plan.dense_tiles < 0 else int(plan.dense_tiles))
-    if 0 < dense < RT:
-        dense = 0xFFFFFFFF      # only "none" and "all" are assumptions the device can check
-    return int(plan.capacity), int(plan.max_tile_list), dense
+    return int(plan.capacity), int(plan.max_tile_list), 0xFFFFFFFF
 
 
 class _spf_errors:
@@ -399,8 +395,8 @@ def _raise_if_plan_failed(counters: Tensor, capacity: int, plan=None) -> None:
     if flag:
         longer = f"a tile needs more than its bin of {plan[0]} entries" if direct else \
             f"a tile list longer than planned ({int(host[1])})"
-        raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = {longer}, "
-                            "4 = dense-tile assumption wrong); the outputs are NaN")
+        raise _lib.SpfError(f"the PairBudget of the forward pass did not hold (flags {flag}: 2 = {longer}); "
+                            "the outputs are NaN")
 
 
 def _plan_mode(max_pairs) -> int:

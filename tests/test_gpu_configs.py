@@ -354,8 +354,7 @@ def test_failed_plan_is_nan_everywhere_and_raises_without_backward(hip_lib):
     st = exact["stats"]
     good = spf.plan_pair_budget(st, check="deferred")
     bad_plans = {1: good._replace(capacity=st["num_pairs"] // 2),
-                 2: good._replace(max_tile_list=max(st["max_tile_list"] // 2, 1)),
-                 4: good._replace(dense_tiles=-1 if st["dense_tiles"] < st["tiles"] else 0)}
+                 2: good._replace(max_tile_list=max(st["max_tile_list"] // 2, 1))}
     for bit, plan in bad_plans.items():
         res = util.run_product(batch, max_pairs=plan)
         assert spf.plan_flags(res["decoder"].last_call) & bit

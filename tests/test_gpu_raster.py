@@ -106,7 +106,7 @@ def test_sync_free_capacity_mode_and_overflow(hip_lib):
 
 def test_planned_pair_budget_is_verified_on_the_device(hip_lib):
     """PairBudget: a call planned from an earlier one needs no read-back; the device checks the plan (flag bits
-    1 = capacity, 2 = longest list, 4 = dense/sparse census) and a failed plan is never silent."""
+    1 = capacity, 2 = longest list) and a failed plan is never silent."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd._lib import SpfError
     kw, bg, si = CASES["k4_multiview"]
@@ -127,12 +127,6 @@ def test_planned_pair_budget_is_verified_on_the_device(hip_lib):
     assert spf.last_plan_flags() & 2
     with pytest.raises(SpfError, match="did not hold"):
         util.run_product(batch, background=bg, scale_invariant=si, max_pairs=short._replace(check="backward"))
-
-    # wrong dense/sparse census: flag 4
-    some_dense = 0 < st["dense_tiles"] < st["tiles"]
-    wrong = plan._replace(dense_tiles=-1 if st["dense_tiles"] == 0 or some_dense else 0)
-    util.run_product(batch, background=bg, scale_invariant=si, max_pairs=wrong)
-    assert spf.last_plan_flags() & 4
 
     # too few pairs: flag 1
     util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan._replace(capacity=st["num_pairs"] // 2))
