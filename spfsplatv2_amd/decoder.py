@@ -36,6 +36,7 @@ from torch import Tensor, nn
 
 import os
 
+from ._lib import SpfError as _SpfError
 from .rasterizer import CallRecord, PairBudget, rasterize_batch, render_batch, sh_band4_default
 
 DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
@@ -289,6 +290,20 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # cache stops capturing).  `eval_graphs = False` or SPF_EVAL_GRAPHS=0 switches it off; `clear_eval_graphs()`
         # releases the captured graphs and their buffers.
         self.eval_graphs = True
+        # Opt-in (`decoder.auto_plan = 1.5`, or SPF_AUTO_PLAN=1.5 in the environment): the module plans for itself, so an
+        # UNCHANGED caller gets the no-read-back path.  The first call of a shape (b, v, G, d_sh, h, w) runs in exact mode;
+        # the following ones run under `plan_pair_budget(that call, slack=auto_plan)`.  A call that nothing will be
+        # differentiated through verifies its plan at once and is re-run in exact mode if it failed (evaluation never
+        # sees a NaN image).  A TRAINING call cannot wait for its own verdict without the very synchronisation the plan
+        # is there to avoid: its verdict is copied to pinned memory behind the forward and read at the NEXT call (an
+        # event that is long past by then); if the plan had failed, that step's images and gradients were all NaN --
+        # what the reference's NaN-gradient guard (model_wrapper.py:1117-1151) skips -- and the next call is exact
+        # again and re-plans.  That possible skipped step is why this is opt-in.  `auto_plan` owns `max_pairs`.
+        env_plan = os.environ.get("SPF_AUTO_PLAN", "")
+        self.auto_plan: Optional[float] = float(env_plan) if env_plan else None
+        self._auto_key = None            # shape the current automatic plan was made for
+        self._auto_pending = None        # (pinned verdict, event) of the last planned training call, until it is read
+        self._auto_verdict = None        # the one pinned word + event all of them use
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
         self._graph_seen: dict = {}      # key -> None: keys seen once, not yet captured
         self._graph_unused = 0           # captures since the last replay hit
@@ -339,6 +354,47 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     def _render(self, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
         tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
                    gaussians.rotations, gaussians.scales)
+        if not self.auto_plan or torch.cuda.is_current_stream_capturing():
+            return self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
+        # ---- automatic planning (see __init__) ----
+        from .rasterizer import plan_pair_budget
+        shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(gaussians.harmonics.shape),
+                 tuple(image_shape))
+        if shape != self._auto_key:
+            self._auto_key, self._auto_pending, self.max_pairs = shape, None, None
+        elif self._auto_pending is not None:
+            verdict, event = self._auto_pending
+            self._auto_pending = None
+            event.synchronize()
+            if int(verdict[0]) != 0:
+                self.max_pairs = None                    # the last training step's plan failed: exact again, re-plan
+        trains = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+        planned = self.max_pairs is not None
+        if planned and not trains and self.max_pairs.check == "deferred":
+            self.max_pairs = self.max_pairs._replace(check="backward")      # (evaluation: the graph path verifies at once)
+        elif planned and trains and self.max_pairs.check != "deferred":
+            self.max_pairs = self.max_pairs._replace(check="deferred")
+        try:
+            result = self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
+        except _SpfError:
+            if not planned or trains:
+                raise
+            self.max_pairs = None                        # an evaluation call whose plan failed: exact mode, re-plan below
+            result = self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
+        if self.last_call.get("counters") is None:
+            # this call ran in exact mode (the first of its shape, or a replayed evaluation graph that fell back to it)
+            # and left statistics: plan the next ones from them
+            self.max_pairs = plan_pair_budget(self.last_call, slack=float(self.auto_plan), check="deferred")
+        elif trains:
+            if self._auto_verdict is None:
+                self._auto_verdict = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            verdict, event = self._auto_verdict
+            verdict.copy_(self.last_call["counters"][2:3], non_blocking=True)
+            event.record()
+            self._auto_pending = self._auto_verdict
+        return result
+
+    def _render_planned(self, tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
         key = self._eval_graph_key(tensors, image_shape)
         if key is None:
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
@@ -365,6 +421,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             from .rasterizer import plan_flags
             if plan_flags(entry.record) != 0:
                 # the plan did not hold for THESE inputs (the graph's outputs are NaN): this call in exact mode instead
+                # (on a record of its own: the graph's record must keep the counters its next replay is checked by)
+                self.last_call = CallRecord()
                 with torch.no_grad():
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
                                                                     image_shape, None, self.last_call)

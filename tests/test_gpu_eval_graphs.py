@@ -93,3 +93,72 @@ def test_replayed_call_whose_plan_fails_is_rerun_in_exact_mode(hip_lib):
             d.forward(*args())                                       # first sight, launched as usual: raises as ever
         fixed = d.forward(*args())                                   # second: captured, replayed, verified, re-run exactly
         assert torch.equal(fixed.color, exact.color)
+        again = d.forward(*args())                                   # and every later replay is verified just the same
+        assert torch.equal(again.color, exact.color)
+
+
+def _auto_decoder(slack=1.3):
+    d = util.product_decoder()
+    d.auto_plan = slack
+    return d
+
+
+def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
+    """decoder.auto_plan (opt-in): the module plans for itself.  First call of a shape: exact mode; the next ones planned
+    (and, being evaluation calls, captured); inputs that outgrow the plan are re-run in exact mode at once and re-planned."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    small = syn.make_batch("TEST", 1, 3, seed=21, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    big = syn.make_batch("TEST", 1, 3, seed=21, s_mult=40.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    gs = lambda b: dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
+    call = lambda d, b, g: d.forward(g, b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
+    ref, d = util.product_decoder(), _auto_decoder()
+    g_small, g_big = gs(small), gs(big)
+    with torch.no_grad():
+        want_small, want_big = call(ref, small, g_small), call(ref, big, g_big)
+        first = call(d, small, g_small)
+        assert isinstance(d.max_pairs, spf.PairBudget) and d.last_call.get("counters") is None       # ran exact, planned
+        plan = d.max_pairs
+        outs = [call(d, small, g_small) for _ in range(3)]                                           # planned; captured; replayed
+        assert d.max_pairs.capacity == plan.capacity and len(d._graphs) == 1
+        for o in [first] + outs:
+            assert torch.equal(o.color, want_small.color) and torch.equal(o.depth, want_small.depth)
+        grown = call(d, big, g_big)                                   # same shape, many times the pairs: the plan cannot hold
+        assert torch.equal(grown.color, want_big.color) and d.max_pairs.capacity > plan.capacity
+        after = [call(d, big, g_big) for _ in range(3)]
+        for o in after:
+            assert torch.equal(o.color, want_big.color)
+        assert spf.plan_flags(d.last_call) == 0
+
+
+def test_auto_plan_training_reads_the_verdict_one_call_late(hip_lib):
+    """A training call under an automatic plan waits for nothing: its verdict is read at the next call.  A step whose
+    plan failed is all NaN (the reference's NaN-gradient guard skips it, model_wrapper.py:1117-1151), the next one runs in
+    exact mode and re-plans."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    small = syn.make_batch("TEST", 1, 3, seed=22, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    big = syn.make_batch("TEST", 1, 3, seed=22, s_mult=40.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+
+    def step(d, b):
+        means = b.means.clone().requires_grad_(True)
+        g = dec.Gaussians(means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
+        out = d.forward(g, b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
+        out.color.square().mean().backward()
+        return out.color.detach(), means.grad
+
+    ref, d = util.product_decoder(), _auto_decoder()
+    want_small, want_big = step(ref, small), step(ref, big)
+    c, g = step(d, small)                                             # exact, plans
+    assert torch.equal(c, want_small[0]) and isinstance(d.max_pairs, spf.PairBudget)
+    for _ in range(2):                                                # planned: same images, gradients to rounding
+        c, g = step(d, small)
+        assert torch.equal(c, want_small[0]) and util.rel_linf(g, want_small[1]) < 1e-5
+        assert d._auto_pending is not None and not d._graphs
+    cap = d.max_pairs.capacity
+    c, g = step(d, big)                                               # outgrows the plan: NaN everywhere, nothing raised
+    assert bool(torch.isnan(c).all()) and bool(torch.isnan(g).all())
+    c, g = step(d, big)                                               # verdict read: exact mode again, new plan
+    assert torch.equal(c, want_big[0]) and util.rel_linf(g, want_big[1]) < 1e-5 and d.max_pairs.capacity > cap
+    c, g = step(d, big)                                               # planned under the new plan
+    assert torch.equal(c, want_big[0]) and spf.plan_flags(d.last_call) == 0

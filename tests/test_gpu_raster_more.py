@@ -426,7 +426,7 @@ def test_far_off_centre_anisotropic_splat_gradients(hip_lib, crowd):
     910 px; found by tools/fuzz_campaign.py, seed 2428).  Summing dL/dconic over the pixels and converting once per
     Gaussian -- the classic order -- cancels three ~1e-2 terms to ~1e-5 in float32: 1.3 % error on dL/dmeans.  The pair
     records carry dL/d(cov2D) formed per pixel from v = conic * offset instead (spf_common.h); both render backward
-    kernels are covered: alone the splat's tiles are dense (rows kernel), among `crowd` pixel-aligned small ones they
+    forms are covered: alone the splat's tiles are dense (rows form), among `crowd` pixel-aligned small ones they
     stay sparse (lists kernel, whole-tile slot box)."""
     b = syn.make_batch("TEST", 1, 1, seed=77, s_mult=1.0, G=max(crowd, 1) + 1, K=4, image_hw=(80, 25))
     b.means[0, 0] = torch.tensor([-0.5659291744232178, -0.7119755148887634, 2.077361822128296])
