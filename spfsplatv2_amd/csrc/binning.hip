@@ -174,10 +174,9 @@ __global__ __launch_bounds__(kBlock) void spf_bin_pairs_kernel(const float* __re
     uint32_t* s_base = s_bin + T;
     const int r = blockIdx.y;
     const int g = blockIdx.x * kBlock + threadIdx.x;
-    // The host may launch this chain from a PLAN (capacity, longest list, dense-tile census of an earlier call)
-    // instead of reading the counters back; the plan is checked here, on the device.  Flag bits: 1 = pair buffer too
-    // small (nothing is rendered), 2 = a tile list is longer than planned (it was not sorted), 4 = the planned
-    // sparse/dense kernel choice missed tiles (they were not rendered).
+    // The host may launch this chain from a PLAN (capacity, longest list of an earlier call) instead of reading the
+    // counters back; the plan is checked here, on the device.  Flag bits: 1 = pair buffer too small (nothing is
+    // rendered), 2 = a tile list is longer than planned (it was not sorted).
     if (r == 0 && g == 0) {
         uint32_t flag = counters[0] > capacity ? 1u : 0u;
         if (max_tile_hint != 0u && counters[1] > max_tile_hint) flag |= 2u;

@@ -22,7 +22,7 @@
 
 namespace spf {
 
-constexpr int kStage = 256;  // list entries staged per round (one per thread) of the rows kernels
+constexpr int kStage = 256;  // list entries staged per round (one per thread) of the forward's rows form
 constexpr int kFwdLongRoundsMaxTiles = 768;    // calls of at most this many tiles: 512-entry rounds in the forward lists kernel
 
 struct BlockCtx {
@@ -132,6 +132,31 @@ __device__ __forceinline__ void poison_tile(int RT, int T, int tiles_x, int H, i
     alpha_out[(size_t)r * P + pix] = nan;
 }
 
+// Exponent of ALL compositing forms (lists and rows, forward and backward).  They stage the conic pre-multiplied: A' = -0.5*log2(e)*A, B' = -log2(e)*B,
+// C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
+// spelled out so that the forward and the backward replay evaluate it identically (same hit decisions) -- whichever form
+// composites a tile in either direction: a tile may go forward through lists and backward through rows (the dense
+// thresholds differ), and the forward's images do not depend on the form at all (bit-identical, tested).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
+constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
+// Packed form: the lists kernels stage (x, y | A', C') in one 16-byte LDS record, so the pixel offset is one
+// v_pk_add_f32 and (A' dx, C' dy) one v_pk_mul_f32; then exponent = dx * (A' dx + B' dy) + (C' dy) * dy.
+__device__ __forceinline__ float lists_power2(const float4& p0, float Bs, v2f fxy, v2f& dxy) {
+    dxy = v2f{p0.x, p0.y} - fxy;
+    const v2f u = v2f{p0.z, p0.w} * dxy;                      // (A' dx, C' dy)
+    return fmaf(dxy.x, fmaf(Bs, dxy.y, u.x), u.y * dxy.y);
+}
+// The same expression tree with scalar instructions -- bit-identical results (the backward replay must take the
+// forward's hit decisions), for the backward kernel, where the even-aligned register pairs of the packed form cost more
+// moves than they save (measured: +8 us).
+__device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs, float fx, float fy) {
+    const float dx = p0.x - fx, dy = p0.y - fy;
+    const float ux = p0.z * dx, uy = p0.w * dy;
+    return fmaf(dx, fmaf(Bs, dy, ux), uy * dy);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward of a DENSE tile ("rows"): front-to-back compositing, one 4x4 pixel block per DPP row (see the header
 // comment).  Not a kernel of its own: the forward kernel below runs it for the tiles the launch order marks dense, on
@@ -162,8 +187,8 @@ __device__ __forceinline__ void fwd_rows_tile(float4* s_p0, float2* s_p1, float4
             const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[threadIdx.x] = a;
-            s_p1[threadIdx.x] = make_float2(b.x, b.y);
+            s_p0[threadIdx.x] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);   // x, y | A', C'
+            s_p1[threadIdx.x] = make_float2(kLog2e * a.w, b.y);                               // B', opacity
             s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
             bits = block_bits(a.x, a.y, b.w, c.tx, c.ty);
         }
@@ -188,9 +213,8 @@ __device__ __forceinline__ void fwd_rows_tile(float4* s_p0, float2* s_p1, float4
                     const int j = q * 32 + bit;
                     const float4 p0 = s_p0[j];
                     const float2 p1 = s_p1[j];
-                    const float dx = p0.x - fx, dy = p0.y - fy;
-                    const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
-                    const float alpha = fminf(kAlphaMax, p1.y * __expf(power));
+                    const float power = lists_power2_scalar(p0, p1.x, fx, fy);            // (log2 units)
+                    const float alpha = fminf(kAlphaMax, p1.y * __builtin_amdgcn_exp2f(power));
                     const float4 p2 = s_p2[j];
                     // branch-free body: predicates fold into selects, every lane runs the same ~35 instructions
                     const bool hit = act && !done && power <= 0.f && alpha >= kAlphaMin;
@@ -235,29 +259,6 @@ __device__ __forceinline__ void fwd_rows_tile(float4* s_p0, float2* s_p1, float4
 //            list order, gathering each candidate from LDS and compositing it.
 // A pixel outside the disc has alpha < 1/255 for that Gaussian, so the result equals the plain per-pixel loop.
 // ------------------------------------------------------------------------------------------------
-// Exponent of the lists kernels.  They stage the conic pre-multiplied: A' = -0.5*log2(e)*A, B' = -log2(e)*B,
-// C' = -0.5*log2(e)*C, so that G = exp2(A' dx^2 + B' dx dy + C' dy^2) is one fma chain and one v_exp_f32.  The chain is
-// spelled out so that the forward and the backward replay evaluate it identically (same hit decisions).
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-constexpr float kHalfLog2e = -0.72134752044448170368f;   // -0.5 * log2(e)
-constexpr float kLog2e = -1.44269504088896340736f;       // -log2(e)
-// Packed form: the lists kernels stage (x, y | A', C') in one 16-byte LDS record, so the pixel offset is one
-// v_pk_add_f32 and (A' dx, C' dy) one v_pk_mul_f32; then exponent = dx * (A' dx + B' dy) + (C' dy) * dy.
-__device__ __forceinline__ float lists_power2(const float4& p0, float Bs, v2f fxy, v2f& dxy) {
-    dxy = v2f{p0.x, p0.y} - fxy;
-    const v2f u = v2f{p0.z, p0.w} * dxy;                      // (A' dx, C' dy)
-    return fmaf(dxy.x, fmaf(Bs, dxy.y, u.x), u.y * dxy.y);
-}
-// The same expression tree with scalar instructions -- bit-identical results (the backward replay must take the
-// forward's hit decisions), for the backward kernel, where the even-aligned register pairs of the packed form cost more
-// moves than they save (measured: +8 us).
-__device__ __forceinline__ float lists_power2_scalar(const float4& p0, float Bs, float fx, float fy) {
-    const float dx = p0.x - fx, dy = p0.y - fy;
-    const float ux = p0.z * dx, uy = p0.w * dy;
-    return fmaf(dx, fmaf(Bs, dy, ux), uy * dy);
-}
-
 // Ballot of a lane predicate as the compiler keeps it (an SGPR pair).  HIP's __ballot(int) widens the predicate to
 // 0 / 1 in a VGPR and compares it again (v_cndmask + v_cmp per call); in loops whose body is ~30 instructions that
 // round trip is 5 % of the kernel.
@@ -329,7 +330,7 @@ __device__ __forceinline__ TileBox clipped_box(float gx, float gy, float r2, int
 // but BASELINE config 3 (2,048 tiles) 59.8 -> 71.6, REF2V (4,096) 66.8 -> 78.9, C2 (8,192) 66.4 -> 87.6: four blocks per
 // CU instead of eight costs more than the rounds save as soon as the chip is full -- 512 only up to 768 tiles.
 template <int STAGE>
-__global__ __launch_bounds__(kBlock) void spf_render_fwd_lists_kernel(
+__global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_lists_kernel(   // (8 blocks per CU: <= 64 VGPRs)
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
     const float* __restrict__ bg_all, float* __restrict__ image, float* __restrict__ depth_out,
@@ -587,8 +588,8 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
             const uint32_t gid = (uint32_t)pairs[beg + idx];
             const float4* __restrict__ rp = reinterpret_cast<const float4*>(rec_r + (size_t)gid * kRec);
             const float4 a = rp[0], b = rp[1], cc = rp[2];
-            s_p0[threadIdx.x] = a;
-            s_p1[threadIdx.x] = make_float2(b.x, b.y);
+            s_p0[threadIdx.x] = make_float4(a.x, a.y, kHalfLog2e * a.z, kHalfLog2e * b.x);   // as in the forward
+            s_p1[threadIdx.x] = make_float2(kLog2e * a.w, b.y);
             s_p2[threadIdx.x] = make_float4(cc.x, cc.y, cc.z, b.z);
             s_slot[threadIdx.x] = pair_slot(gid);
 #pragma unroll
@@ -619,8 +620,8 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                 const float4 p0 = s_p0[j];
                 const float2 p1 = s_p1[j];
                 const float dx = p0.x - fx, dy = p0.y - fy;
-                const float power = -0.5f * (p0.z * dx * dx + p1.x * dy * dy) - p0.w * dx * dy;
-                const float Gv = __expf(power);
+                const float power = lists_power2_scalar(p0, p1.x, fx, fy);                // (log2 units)
+                const float Gv = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
                 const bool hit = act && pos < ncon && power <= 0.f && alpha >= kAlphaMin;
                 const uint64_t hb = __ballot(hit);
@@ -653,7 +654,9 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                     r_do = Gv * dL_dalpha_;
                     // v = conic * offset; dL/d(a, b, c) of the 2-D covariance directly (spf_common.h: the classic
                     // sum of dL/dconic cancels in float32 for a far-off-centre anisotropic splat, v does not)
-                    const float vx = p0.z * dx + p0.w * dy, vy = p1.x * dy + p0.w * dx;
+                    // (from the staged A' = -0.5 log2(e) A, C', B' = -log2(e) B: 1 / -0.5 log2(e) = -2 ln 2, 1 / -log2(e) = -ln 2)
+                    constexpr float kInvH = -1.38629436111989061883f, kInvL = -0.69314718055994530942f;
+                    const float vx = fmaf(p0.z * dx, kInvH, (p1.x * dy) * kInvL), vy = fmaf(p0.w * dy, kInvH, (p1.x * dx) * kInvL);
                     r_dx = -sg * vx;
                     r_dy = -sg * vy;
                     r_dA = -0.5f * r_dx * vx;
@@ -792,7 +795,7 @@ __global__ __launch_bounds__(kBlock, BPC) void spf_render_bwd_lists_kernel(
     const uint32_t wmax = wave_max_u32(ncon);
     if (lane == 0) s_wmax[wave] = wmax;
     __syncthreads();
-    const uint32_t bmax = min(n, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));   // (clamp: see the rows kernel)
+    const uint32_t bmax = min(n, max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])));   // (clamp: see bwd_rows_tile)
     {   // entries behind every pixel's last contributor: zero record (each pair slot is written exactly once)
         for (uint32_t idx = bmax + tid; idx < n; idx += kBlock)
             store_grec<DEPTH_GRAD>(gpair, pair_slot((uint32_t)pairs[beg + idx]), 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
@@ -1010,25 +1013,22 @@ hipError_t launch_render_fwd_wave(const SpfDims&, const SpfInputs&, const SpfSta
 hipError_t launch_render_bwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int,
                                   const TileLists&, hipStream_t);
 uint32_t dense_threshold_fwd();
-uint32_t dense_threshold() {
-    static const uint32_t v = getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA;
-    return v;
+uint32_t dense_threshold() {                       // (read per call: the tests flip it)
+    const char* const e = getenv("SPF_DENSE_AREA");
+    return e ? (uint32_t)atoi(e) : SPF_DENSE_AREA;
 }
 // The forward's own threshold (>= the backward's).  Round-5 sweep (same box, C2 with footprints x 3 / 6 / 10 / 30 and C5 x 1 /
 // 4): the lists FORWARD beats the rows forward up to far denser tiles than the lists backward beats the rows backward
 // (x 6: forward 201 us through rows vs 125 through lists, backward 525 vs 566; x 10: 269 vs 190 and 742 vs 1,468; only at
-// x 30 do the rows win the forward, 508 vs 1,228) -- with one threshold for both, every tile handed to the rows kernels for
+// x 30 do the rows win the forward, 508 vs 1,228) -- with one threshold for both, every tile handed to the rows form for
 // the backward's sake cost the forward 20 - 40 %.  SPF_DENSE_AREA (experiments) pins both.
 uint32_t dense_threshold_fwd() {
-    static const uint32_t v = getenv("SPF_DENSE_AREA_FWD") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA_FWD"))
-                              : (getenv("SPF_DENSE_AREA") ? (uint32_t)atoi(getenv("SPF_DENSE_AREA")) : SPF_DENSE_AREA_FWD);
-    return v > dense_threshold() ? v : dense_threshold();
+    const char* const f = getenv("SPF_DENSE_AREA_FWD");
+    const char* const e = getenv("SPF_DENSE_AREA");
+    const uint32_t v = f ? (uint32_t)atoi(f) : (e ? (uint32_t)atoi(e) : SPF_DENSE_AREA_FWD), b = dense_threshold();
+    return v > b ? v : b;
 }
 
-// When both the sparse and the dense kernel have tiles, they run CONCURRENTLY: the dense one is forked onto an
-// auxiliary stream (event fork / join, capturable in a HIP graph) so that a few long-running dense tiles do not
-// serialise behind -- or in front of -- the sparse kernel's wave of short blocks.  One auxiliary stream per device,
-// created on first use; this is the only state the library keeps besides the stage-timing events.
 // ONE launch composites every tile: the kernel takes the "rows" or the "lists" form per tile (launch-order flag, or
 // tile_flags / list length in image order).  Rounds 2 - 4 ran two kernels on forked streams and skipped one of them from
 // the plan's dense-tile census (`dense_hint`); the empty or near-empty second launch cost 7 - 20 us a direction on every

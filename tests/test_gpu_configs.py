@@ -295,6 +295,35 @@ def test_longest_first_launch_order_changes_nothing(hip_lib, monkeypatch):
                 assert torch.equal(ordered["grads"][n], plain["grads"][n]), (cfg, n)
 
 
+def test_forward_does_not_depend_on_the_form_that_composites_a_tile(hip_lib, monkeypatch):
+    """A tile is composited in the "lists" or the "rows" form (render.hip), chosen per direction from its mean footprint
+    (SPF_DENSE_AREA_FWD 120 / SPF_DENSE_AREA 26 px): all forms evaluate alpha with ONE expression tree, so the forward's
+    images, depth, alpha -- and the per-pixel state the backward replays from -- are bit-identical whichever form ran, and
+    the backward takes the forward's hit decisions whichever pair of forms a tile met.  Gradients agree to rounding (the
+    two backward forms sum in different orders)."""
+    import spfsplatv2_amd as spf
+    forms = {"lists/lists": ("1000000000", "1000000000"), "rows/rows": ("1", "1"), "lists/rows": ("1", "1000000000"),
+             "default": (None, None)}
+    for cfg, S, V, kw in (("C2", 2, 4, dict(s_mult=6.0, G=20000)), ("C3", 1, 2, dict(s_mult=3.0, G=60000)),
+                          ("TEST", 2, 2, dict(s_mult=15.0, G=2500, K=4, image_hw=(72, 100)))):
+        batch = syn.make_batch(cfg, S, V, seed=93, **kw)
+        exact = util.run_product(batch)
+        plan = spf.plan_pair_budget(exact["stats"], check="deferred")
+        res = {}
+        for name, (bwd, fwd) in forms.items():
+            for k, v in (("SPF_DENSE_AREA", bwd), ("SPF_DENSE_AREA_FWD", fwd)):
+                monkeypatch.setenv(k, v) if v is not None else monkeypatch.delenv(k, raising=False)
+            res[name] = util.run_product(batch, max_pairs=plan)
+            assert spf.plan_flags(res[name]["decoder"].last_call) == 0
+        monkeypatch.delenv("SPF_DENSE_AREA", raising=False)
+        monkeypatch.delenv("SPF_DENSE_AREA_FWD", raising=False)
+        for name, r in res.items():
+            for k in ("color", "depth", "alpha", "radii"):
+                assert torch.equal(r[k], res["lists/lists"][k]), (cfg, name, k)
+            for n in util.GRAD_NAMES:
+                assert util.rel_linf(r["grads"][n], res["lists/lists"]["grads"][n]) < 2e-5, (cfg, name, n)
+
+
 def test_backward_round_shapes_give_identical_gradients(hip_lib, monkeypatch):
     """The lists backward comes in three round shapes (entries per round / slot pool / blocks per CU: 192 / 1,536 / 5 for
     many tiles, 224 / 1,792 / 4 up to 2,048 tiles, 256 / 2,560 / 3 up to 768: render.hip) picked by the number of tiles of
