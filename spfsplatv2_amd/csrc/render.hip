@@ -47,35 +47,40 @@ __device__ __forceinline__ void block_ctx_at(BlockCtx& c, int r, int tx, int ty,
     c.inside = c.px < W && c.py < H;
 }
 
-// First three steps of the row reduction (lane i <- x[i] + x[i-1] + x[i-2] + x[i-3]); hipcc fuses each
-// into one v_add_f32_dpp.
-__device__ __forceinline__ float row_sum4(float x) {
-    float t = x;
-    t += dpp_f<0x111>(x);             // row_shr:1
-    t += dpp_f<0x112>(x);             // row_shr:2
-    t += dpp_f<0x113>(x);             // row_shr:3
-    return t;
+// Row totals of TEN values at once, 26 instructions (one shift ladder per value: 5 each).  A value-pairing butterfly over
+// the two HIGH lane bits of a row, then plain sums over the two low ones:
+//   step 1 (row_ror:8: lane l meets l ^ 8)        lanes 0-7 keep values 0-7, lanes 8-15 keep values 8, 9;
+//   step 2 (row_half_mirror: l meets 7 - l)       lanes with bit 2 clear keep the lower four of their values, the others
+//                                                 the upper four;
+//   steps 3, 4 (quad_perm xor 2, xor 1)           plain sums: the four lanes of a quad end with the same four totals.
+// "Keep" costs nothing: a DPP add writes only the banks its bank_mask names, so each half of a destination register is
+// written by its own instruction from its own source (no v_cndmask -- the builtin form of the same butterfly, which needs
+// two selects per step, measured 2 - 3 % SLOWER than the ladders; see DESIGN_EXPERIMENTS.md).  On return quad q = l16 >> 2
+// holds z0..z3 = row totals of values 4 q .. 4 q + 3 (q = 2: values 8, 9 in z0, z1; q = 3: nothing).  asm: hipcc lowers
+// a bank-masked update_dpp to three instructions; the leading s_nop covers the VALU-write -> DPP-read hazard (2 wait
+// states) the compiler does not insert around inline asm, inside the block every DPP source is >= 3 instructions old.
+__device__ __forceinline__ void row_sums10(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7,
+                                           float x8, float x9, float& z0, float& z1, float& z2, float& z3) {
+    float y0, y1, y2, y3, y4, y5, y6, y7;
+#define SPF_ROR8(d, a, bank) "v_add_f32_dpp %[" #d "], %[" #a "], %[" #a "] row_ror:8 row_mask:0xf bank_mask:" #bank "\n\t"
+#define SPF_HMIR(d, a, bank) "v_add_f32_dpp %[" #d "], %[" #a "], %[" #a "] row_half_mirror row_mask:0xf bank_mask:" #bank "\n\t"
+#define SPF_QUAD(d, perm) "v_add_f32_dpp %[" #d "], %[" #d "], %[" #d "] quad_perm:" perm " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t"
+                 SPF_ROR8(y0, x0, 0x3) SPF_ROR8(y0, x8, 0xc) SPF_ROR8(y1, x1, 0x3) SPF_ROR8(y1, x9, 0xc)
+                 SPF_ROR8(y2, x2, 0xf) SPF_ROR8(y3, x3, 0xf) SPF_ROR8(y4, x4, 0xf) SPF_ROR8(y5, x5, 0xf)
+                 SPF_ROR8(y6, x6, 0xf) SPF_ROR8(y7, x7, 0xf)
+                 SPF_HMIR(z0, y0, 0x5) SPF_HMIR(z0, y4, 0xa) SPF_HMIR(z1, y1, 0x5) SPF_HMIR(z1, y5, 0xa)
+                 SPF_HMIR(z2, y2, 0x5) SPF_HMIR(z2, y6, 0xa) SPF_HMIR(z3, y3, 0x5) SPF_HMIR(z3, y7, 0xa)
+                 SPF_QUAD(z0, "[2,3,0,1]") SPF_QUAD(z1, "[2,3,0,1]") SPF_QUAD(z2, "[2,3,0,1]") SPF_QUAD(z3, "[2,3,0,1]")
+                 SPF_QUAD(z0, "[1,0,3,2]") SPF_QUAD(z1, "[1,0,3,2]") SPF_QUAD(z2, "[1,0,3,2]") SPF_QUAD(z3, "[1,0,3,2]")
+                 : [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2), [y3] "=&v"(y3), [y4] "=&v"(y4), [y5] "=&v"(y5),
+                   [y6] "=&v"(y6), [y7] "=&v"(y7), [z0] "=&v"(z0), [z1] "=&v"(z1), [z2] "=&v"(z2), [z3] "=&v"(z3)
+                 : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [x4] "v"(x4), [x5] "v"(x5), [x6] "v"(x6),
+                   [x7] "v"(x7), [x8] "v"(x8), [x9] "v"(x9));
+#undef SPF_ROR8
+#undef SPF_HMIR
+#undef SPF_QUAD
 }
-
-// Last two steps (row_shr:4 on banks 1-3, row_shr:8 on banks 2-3) for N values at once: lane 15 of every row
-// ends with the row total.  Written as asm because hipcc lowers a bank-masked update_dpp to
-// v_mov 0 + v_mov_dpp + v_add (3 instructions) instead of one v_add_f32_dpp whose masked-off lanes simply keep
-// their value.  The leading s_nop covers the VALU-write -> DPP-read hazard (2 wait states) that the compiler
-// does not insert around inline asm; inside the block every DPP source was written >= 2 instructions earlier.
-#define SPF_DPP4(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-#define SPF_DPP8(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-__device__ __forceinline__ void row_finish9(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5,
-                                            float& a6, float& a7, float& a8) {
-    asm volatile("s_nop 1\n\t" SPF_DPP4(0) SPF_DPP4(1) SPF_DPP4(2) SPF_DPP4(3) SPF_DPP4(4) SPF_DPP4(5) SPF_DPP4(6)
-                 SPF_DPP4(7) SPF_DPP4(8) SPF_DPP8(0) SPF_DPP8(1) SPF_DPP8(2) SPF_DPP8(3) SPF_DPP8(4) SPF_DPP8(5)
-                 SPF_DPP8(6) SPF_DPP8(7) SPF_DPP8(8)
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
-}
-__device__ __forceinline__ void row_finish1(float& a0) {
-    asm volatile("s_nop 1\n\t" SPF_DPP4(0) "s_nop 1\n\t" SPF_DPP8(0) : "+v"(a0));
-}
-#undef SPF_DPP4
-#undef SPF_DPP8
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t x) {
@@ -663,24 +668,16 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                     r_dB = -r_dx * vy;
                     r_dC = -0.5f * r_dy * vy;
                 }
-                r_dx = row_sum4(r_dx); r_dy = row_sum4(r_dy);
-                r_dA = row_sum4(r_dA); r_dB = row_sum4(r_dB); r_dC = row_sum4(r_dC);
-                r_do = row_sum4(r_do);
-                r_c0 = row_sum4(r_c0); r_c1 = row_sum4(r_c1); r_c2 = row_sum4(r_c2);
-                row_finish9(r_dx, r_dy, r_dA, r_dB, r_dC, r_do, r_c0, r_c1, r_c2);
-                if (DEPTH_GRAD) {
-                    r_dd = row_sum4(r_dd);
-                    row_finish1(r_dd);
-                }
+                float z0, z1, z2, z3;                     // quad q of the row: totals of values 4 q .. 4 q + 3
+                row_sums10(r_dx, r_dy, r_dA, r_dB, r_dC, r_do, r_c0, r_c1, r_c2, r_dd, z0, z1, z2, z3);
                 const bool rowhit = ((hb >> (lane & 48)) & 0xffffull) != 0;
-                if (l16 == 15 && rowhit) {
-                    // the tile's 16 blocks meet in LDS (ds_add_f32); HBM sees one record per pair
-                    float* gp = s_acc[j];
-                    atomicAdd(gp + 0, r_dx); atomicAdd(gp + 1, r_dy);
-                    atomicAdd(gp + 2, r_dA); atomicAdd(gp + 3, r_dB); atomicAdd(gp + 4, r_dC);
-                    atomicAdd(gp + 5, r_do);
-                    atomicAdd(gp + 6, r_c0); atomicAdd(gp + 7, r_c1); atomicAdd(gp + 8, r_c2);
-                    if (DEPTH_GRAD) atomicAdd(gp + 9, r_dd);
+                const int quad = l16 >> 2;
+                if ((l16 & 3) == 0 && quad < 3 && rowhit) {
+                    // the tile's 16 blocks meet in LDS (ds_add_f32; three lanes of a row add four, four and two values);
+                    // HBM sees one record per pair.  (Without a depth gradient value 9 is zero: its accumulator is not read.)
+                    float* gp = s_acc[j] + 4 * quad;
+                    atomicAdd(gp + 0, z0); atomicAdd(gp + 1, z1);
+                    if (quad < 2) { atomicAdd(gp + 2, z2); atomicAdd(gp + 3, z3); }
                 }
             }
         }
