@@ -631,13 +631,14 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                 const bool hit = act && pos < ncon && power <= 0.f && alpha >= kAlphaMin;
                 const uint64_t hb = __ballot(hit);
                 if (hb == 0) continue;
-                float r_dx = 0.f, r_dy = 0.f, r_dA = 0.f, r_dB = 0.f, r_dC = 0.f, r_do = 0.f;
-                float r_c0 = 0.f, r_c1 = 0.f, r_c2 = 0.f, r_dd = 0.f;
+                // (the ten partial gradients are products of two per-lane scalars, w = alpha T and u = G dL/dalpha: only those
+                //  are zeroed for the lanes without a hit, the products are formed for the whole wave after the branch)
+                float w = 0.f, u = 0.f;
                 if (hit) {
                     const float4 p2 = s_p2[j];
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                     Tr = fmaf(Tr, alpha * inv1ma, Tr);       // (not Tr * inv1ma: see the lists kernel)
-                    const float w = alpha * Tr;
+                    w = alpha * Tr;
                     // colour accumulated behind this entry (recurrence, back to front)
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
                     acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
@@ -651,23 +652,18 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                     // image = C + T_final * bg and alpha_out = 1 - T_final both see alpha only through
                     // T_final: dT_final/dalpha = -T_final / (1 - alpha)
                     dL_dalpha_ += (T_final * inv1ma) * tail;
-                    r_c0 = w * gI0; r_c1 = w * gI1; r_c2 = w * gI2;
-                    if (DEPTH_GRAD) r_dd = w * gD;
-                    // [3DGS-grad] the min(0.99, .) clamp is straight-through
-                    const float dL_dG = p1.y * dL_dalpha_;
-                    const float sg = dL_dG * Gv;
-                    r_do = Gv * dL_dalpha_;
-                    // v = conic * offset; dL/d(a, b, c) of the 2-D covariance directly (spf_common.h: the classic
-                    // sum of dL/dconic cancels in float32 for a far-off-centre anisotropic splat, v does not)
-                    // (from the staged A' = -0.5 log2(e) A, C', B' = -log2(e) B: 1 / -0.5 log2(e) = -2 ln 2, 1 / -log2(e) = -ln 2)
-                    constexpr float kInvH = -1.38629436111989061883f, kInvL = -0.69314718055994530942f;
-                    const float vx = fmaf(p0.z * dx, kInvH, (p1.x * dy) * kInvL), vy = fmaf(p0.w * dy, kInvH, (p1.x * dx) * kInvL);
-                    r_dx = -sg * vx;
-                    r_dy = -sg * vy;
-                    r_dA = -0.5f * r_dx * vx;
-                    r_dB = -r_dx * vy;
-                    r_dC = -0.5f * r_dy * vy;
+                    u = Gv * dL_dalpha_;
                 }
+                const float r_c0 = w * gI0, r_c1 = w * gI1, r_c2 = w * gI2, r_dd = DEPTH_GRAD ? w * gD : 0.f;
+                // [3DGS-grad] the min(0.99, .) clamp is straight-through: dL/dG = opacity * dL/dalpha
+                const float sg = p1.y * u, r_do = u;
+                // v = conic * offset; dL/d(a, b, c) of the 2-D covariance directly (spf_common.h: the classic
+                // sum of dL/dconic cancels in float32 for a far-off-centre anisotropic splat, v does not)
+                // (from the staged A' = -0.5 log2(e) A, C', B' = -log2(e) B: 1 / -0.5 log2(e) = -2 ln 2, 1 / -log2(e) = -ln 2)
+                constexpr float kInvH = -1.38629436111989061883f, kInvL = -0.69314718055994530942f;
+                const float vx = fmaf(p0.z * dx, kInvH, (p1.x * dy) * kInvL), vy = fmaf(p0.w * dy, kInvH, (p1.x * dx) * kInvL);
+                const float r_dx = -sg * vx, r_dy = -sg * vy;
+                const float r_dA = -0.5f * r_dx * vx, r_dB = -r_dx * vy, r_dC = -0.5f * r_dy * vy;
                 float z0, z1, z2, z3;                     // quad q of the row: totals of values 4 q .. 4 q + 3
                 row_sums10(r_dx, r_dy, r_dA, r_dB, r_dC, r_do, r_c0, r_c1, r_c2, r_dd, z0, z1, z2, z3);
                 const bool rowhit = ((hb >> (lane & 48)) & 0xffffull) != 0;
