@@ -753,19 +753,33 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
 // classes touch disjoint tiles, and each alone is a one-round kernel that leaves most of the chip idle (REF2V: 4,096
 // tiles -- 30 % short lists, 70 % of 513 .. 1024, a handful longer: 15 + 23 + 12 us back to back); the long lists are
 // dispatched first.  Same networks, same lists bit for bit.
+// BIG: a fourth class in front of them -- lists of 2,049 .. 4,096 entries, sixteen keys per thread (32 KB of LDS, 72 VGPRs:
+// five blocks per CU) -- for calls whose plan reaches that class: the reference's 10-view shape is 768 tiles of ~2,800
+// entries with a few shorter ones at the image border, and as two launches the classes ran one after the other, each on
+// a third of the chip (39 + 18 us).
+template <bool BIG>
 __global__ __launch_bounds__(kBlock) void spf_sort_tiles_mixed_kernel(TileLists tl, const uint32_t* __restrict__ flags,
                                                                       uint32_t* __restrict__ counters,
                                                                       uint64_t* __restrict__ pairs, uint64_t capacity,
                                                                       int RT, uint32_t dense_thr,
                                                                       uint2* __restrict__ order, int T, uint32_t dense_thr_fwd) {
-    __shared__ uint64_t s_x[8 * kBlock];
+    __shared__ uint64_t s_x[(BIG ? 16 : 8) * kBlock];
     if (counters[0] > capacity) return;
     const int ob = order ? 8 * order_windows(RT) : 0;
     if ((int)blockIdx.x < ob) {
         tile_order_block((int)blockIdx.x, tl.count, flags, order, RT, T, tl.cap, dense_thr, dense_thr_fwd);
         return;
     }
-    const int blk = (int)blockIdx.x - ob;
+    int blk = (int)blockIdx.x - ob;
+    if (BIG) {
+        if (blk < RT) {
+            uint32_t b, n;
+            tile_range(tl, blk, b, n);
+            if (n > 2048u && n <= 4096u) sort_tile_in_block<16>(pairs + b, n, s_x);
+            return;
+        }
+        blk -= RT;
+    }
     if (blk < RT) {
         uint32_t b, n;
         tile_range(tl, blk, b, n);
@@ -940,9 +954,15 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
         spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr, thr_f);
-    if (mixed)
-        spf_sort_tiles_mixed_kernel<<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity,
-                                                                            RT, thr, order, T, thr_f);
+    // (SPF_SORT_BIG_MIXED=0: the 2,049 .. 4,096 class as a launch of its own, as before)
+    const char* const bm = getenv("SPF_SORT_BIG_MIXED");
+    const bool big_mixed = mixed && mx > 2048 && !getenv("SPF_SORT_LDS_2K") && !(bm && bm[0] == '0');
+    if (big_mixed)
+        spf_sort_tiles_mixed_kernel<true><<<ob + 2 * RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                                      capacity, RT, thr, order, T, thr_f);
+    else if (mixed)
+        spf_sort_tiles_mixed_kernel<false><<<ob + RT + wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
+                                                                                   capacity, RT, thr, order, T, thr_f);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     // (8 px grid: lists are a quarter as long -- up to 512 entries one wave per tile, four tiles per block, is the better fit)
     const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE") && (kTile == 16 || mx > 512);
@@ -966,7 +986,7 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     // with lane exchanges, the last two merges start with three exchanges through LDS) -- round 5: the reference's
     // 10-view shape is 768 tiles of ~2,800 entries, ALL in this class, and the all-LDS network below took 74 us for them
     // (78 barrier-separated passes of 1,024 threads); 4097 .. 8192 stay with it
-    if (mx > 2048 && !getenv("SPF_SORT_LDS_2K"))
+    if (mx > 2048 && !getenv("SPF_SORT_LDS_2K") && !big_mixed)
         spf_sort_tiles_block_kernel<16><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 2048);
     if (mx > 2048 && getenv("SPF_SORT_LDS_2K"))
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 2048, 8192);

@@ -374,6 +374,35 @@ def test_both_sort_families_give_the_same_lists(hip_lib, monkeypatch):
             assert torch.equal(a["grads"][n], b["grads"][n]), n
 
 
+def test_long_list_class_inside_the_mixed_sort_launch_gives_the_same_lists(hip_lib, monkeypatch):
+    """Calls of few tiles sort lists of 2,049..4,096 entries (sixteen keys per thread) in the same launch as the shorter
+    classes (`spf_sort_tiles_mixed_kernel<true>`); `SPF_SORT_BIG_MIXED=0` gives that class a launch of its own, as before.
+    Same networks on the same lists: bit-equal images and gradients, exact and planned."""
+    import spfsplatv2_amd as spf
+    batch, G = None, 9000
+    for _ in range(8):                                   # (the longest list grows ~linearly with G: aim at 2,600)
+        cand = syn.make_batch("TESTBIG", 1, 1, seed=23, s_mult=1.0, G=G)
+        cand.opacities = cand.opacities * 0.03
+        longest = util.run_product(cand, with_grads=False)["stats"]["max_tile_list"]
+        if 2048 < longest <= 3400:
+            batch = cand
+            break
+        G = max(int(G * 2600 / max(longest, 1)), 64)
+    assert batch is not None, ("no batch with a longest list of 2,049..3,400 entries", G, longest)
+    outs = []
+    for big in ("0", "1"):
+        monkeypatch.setenv("SPF_SORT_BIG_MIXED", big)
+        exact = util.run_product(batch)
+        planned = util.run_product(batch, max_pairs=spf.plan_pair_budget(exact["stats"], check="deferred"))
+        assert spf.plan_flags(planned["decoder"].last_call) == 0
+        outs.append((exact, planned))
+    monkeypatch.delenv("SPF_SORT_BIG_MIXED")
+    for a, b in zip(*outs):
+        assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"])
+        for n in util.GRAD_NAMES:
+            assert torch.equal(a["grads"][n], b["grads"][n]), n
+
+
 def test_two_views_per_binning_block_give_the_same_lists(hip_lib, monkeypatch):
     """Renders of many blocks bin two views of a scene per block (`spf_bin_pairs_views_kernel`, picked from G >= 262,144;
     `SPF_BIN_VIEWS` pins it): bins fill in another order, the sorted lists are the same -- bit-equal images and gradients,
