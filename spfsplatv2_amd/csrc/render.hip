@@ -1,8 +1,14 @@
 // 16x16-tile alpha compositing, forward and backward, for gfx950 (wave64).
 //
-// Block = one tile = 256 threads = 4 waves; wave w owns the 8x8 sub-tile (w&1, w>>1) and every DPP row
-// (16 lanes) of a wave owns one 4x4 pixel block.  A pixel-aligned Gaussian covers ~5x5 pixels, so most
-// (block, Gaussian) combinations of a tile are empty:
+// ONE kernel per direction; a block = one tile = 256 threads = 4 waves composites its tile in one of two forms, chosen per
+// tile and per direction from the tile's mean footprint (SPF_DENSE_AREA_FWD / SPF_DENSE_AREA, include/spfsplat_hip.h):
+//
+// "lists" (sparse tiles: footprints of a few pixels) -- see spf_render_fwd_lists_kernel / spf_render_bwd_lists_kernel:
+//   thread i scatters staged entry i's footprint into per-pixel candidate bit words, thread p then walks ITS pixel's
+//   candidates; work is proportional to the (pixel, Gaussian) pairs that really interact.
+//
+// "rows" (dense tiles) -- fwd_rows_tile / bwd_rows_tile, device functions the lists kernels branch into (block-uniform)
+// on their own LDS: wave w owns the 8x8 sub-tile (w&1, w>>1) and every DPP row (16 lanes) of a wave owns one 4x4 pixel block.
 //   * the tile's depth-sorted list is staged 256 entries at a time into LDS (one coalesced 8-byte key load +
 //     one 48-byte record gather per thread),
 //   * while staging, each thread tests its entry against the tile's sixteen 4x4 blocks with a conservative
@@ -12,8 +18,9 @@
 //     different Gaussians at the same time; entries are read back from LDS (four addresses per wave),
 //   * per-lane early termination (T < 1e-4) is folded into row / wave ballots and a block-wide
 //     __syncthreads_and, so a saturated tile stops streaming its list.
-// A culled (block, entry) is one whose alpha is < 1/255 at every pixel of the block, i.e. one the per-pixel loop
-// would have skipped anyway, so results are identical to the un-culled loop.
+// A culled (block, entry) -- or, in the lists form, (pixel, entry) -- is one whose alpha is < 1/255 there, i.e. one the
+// per-pixel loop would have skipped anyway, so results are identical to the un-culled loop; and every form evaluates
+// alpha with the same expression tree (lists_power2_scalar), so the forward's output does not depend on the form.
 //
 // Semantics: SURVEY.md Appendix B #10/#11 (restated in oracle/splat_ref.py::composite).
 #include <stdlib.h>
