@@ -48,6 +48,22 @@ def test_parity_vs_oracle_full_size_c3_c5(hip_lib, config, min_pairs, min_list):
         assert float(prod["grads"]["harmonics"][..., 9:].abs().max()) > 0        # degree-3 coefficients take part
 
 
+def test_parity_vs_oracle_full_size_stress_regime(hip_lib):
+    """SURVEY.md 8(d)'s stress regime at full size (the bench's `C2_stress` line): BASELINE config 2 with footprints x 10
+    -- most tiles take the dense "rows" form backward and the sparse "lists" form forward (mean cull box between the two
+    thresholds), the rest lists both ways: forward and every gradient of one (scene, view) against the float64 oracle."""
+    batch = syn.make_batch("C2", 1, 1, seed=5, s_mult=10.0)
+    ref = util.run_oracle(batch, torch.float64, mask_fragile=True, unmasked_too=True)
+    prod = util.run_product(batch, pixel_mask=ref["pixel_mask"], unmasked_too=True)
+    rep = util.compare(prod, ref, max_fragile_frac=0.003)       # (measured: 0.15 % of the pixels flagged; 224 of 256 tiles dense)
+    st = prod["stats"]
+    rep.update(num_pairs=st["num_pairs"], max_tile_list=st["max_tile_list"], dense_tiles=st["dense_tiles"])
+    from tests.test_gpu_raster import _report
+    _report("c2_stress_full_size", rep)
+    assert not rep["fails"], rep
+    assert st["dense_tiles"] > st["tiles"] // 2 and st["num_pairs"] >= 80000, st
+
+
 # ---- properties on the bench's batches -------------------------------------------------------------------------
 def _render(b, harm=None, bg=(0.0, 0.0, 0.0), max_pairs=None, scenes=None, leaves=False):
     import spfsplatv2_amd as spf
