@@ -166,7 +166,7 @@ def parse_args(argv=None):
                          "graph and replayed on its own stream, so that the latency-bound stages of one micro-batch "
                          "(projection, binning, sort) run under the VALU-bound compositing of another (implies --graph; "
                          "same renders, same loss -- each micro-batch weighs 1/N --, same backward)")
-    ap.add_argument("--api", default="batched", choices=["batched", "per-view"],
+    ap.add_argument("--api", default="batched", choices=["batched", "per-view", "module"],
                     help="per-view: the step is the REFERENCE's own glue, unchanged -- `repeat` of every Gaussian tensor "
                          "per view (decoder_splatting_cuda.py:59-64), torch camera preamble, then b*v sequential "
                          "`GaussianRasterizer(settings)(...)` calls with `.item()` host syncs (cuda_splatting.py:96-143) "
@@ -324,11 +324,23 @@ def eval_latency(args, dev) -> dict:
         return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
 
     n = max(args.steps * 10, 100)
+    unchanged_caller = decoder.auto_plan              # (the module's default: it plans for itself)
+    decoder.auto_plan = None                          # exact mode, every call
     for _ in range(max(args.warmup, 3)):
         call()
     exact_med, exact_min = latency(call, n)
     reference_image = call().color.clone()
-    decoder.max_pairs = spf.plan_pair_budget(decoder.last_call, slack=1.25, check="deferred")
+    plan = spf.plan_pair_budget(decoder.last_call, slack=1.25, check="deferred")
+    # what an UNCHANGED caller gets: no max_pairs, the module's own planning + graph cache (first call exact, then planned)
+    decoder.auto_plan = unchanged_caller
+    for _ in range(max(args.warmup, 3) + 2):
+        call()
+    default_med, default_min = latency(call, n)
+    if not torch.equal(call().color, reference_image):
+        raise RuntimeError("the unchanged-caller path does not reproduce the exact-mode image")
+    decoder.auto_plan = None
+    decoder.clear_eval_graphs()
+    decoder.max_pairs = plan
     decoder.eval_graphs = False
     for _ in range(max(args.warmup, 3)):
         call()
@@ -372,6 +384,7 @@ def eval_latency(args, dev) -> dict:
                        "launch": "one decoder.forward call, then torch.cuda.synchronize: wall time per call; planned "
                                  "calls are replayed from the module's own HIP-graph cache"},
             "latency_ms": {"exact_mode_median": round(exact_med, 4), "exact_mode_min": round(exact_min, 4),
+                           "unchanged_caller_median": round(default_med, 4), "unchanged_caller_min": round(default_min, 4),
                            "planned_median": round(plan_med, 4), "planned_min": round(plan_min, 4),
                            "planned_no_graph_cache_median": round(nograph_med, 4),
                            "planned_no_graph_cache_min": round(nograph_min, 4),
@@ -564,6 +577,12 @@ def main():
         if args.streams > 1 or args.allreduce:
             sys.exit("bench.py: --api per-view is a single-stream, single-rank-style step")
         args.eager, args.exact, args.graph = True, True, False      # host syncs inside the step: nothing to capture
+    if args.api == "module":
+        # the step of an UNCHANGED caller of the batched decoder module: DecoderSplattingCUDA.forward with nothing
+        # configured -- the module plans for itself and verifies every call (one host sync per forward, at its end)
+        if args.streams > 1 or args.allreduce:
+            sys.exit("bench.py: --api module is a single-stream, single-rank-style step")
+        args.eager, args.graph = True, False
     if not args.graph:          # launch mode: HIP-graph replay unless something in the step cannot be captured
         args.graph = not (args.eager or args.exact or args.allreduce)
 
@@ -581,6 +600,7 @@ def main():
             # its own stream under the next micro-batch's kernels
             self.bucket = shard.GradBucket(*(self.leaves[n] for n in names[:5])) if args.allreduce else None
             self.work = None
+            self.decoder = None
 
         def render_per_view(self):
             """The reference's decoder + render_cuda, statement for statement, on the drop-in rasterizer surface."""
@@ -632,10 +652,25 @@ def main():
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
                 loss.backward(gradient=spf.unit_grad(dev))
                 return loss
-            color, depth, _alpha = spf.render_views(
-                L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
-                L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
-                enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record)
+            if args.api == "module":
+                from spfsplatv2_amd import decoder as dec
+                if self.decoder is None:
+                    self.decoder = dec.get_decoder(dec.DecoderSplattingCUDACfg(
+                        name="splatting_cuda", background_color=[0.0, 0.0, 0.0], make_scale_invariant=True,
+                        enable_cov_grad=True, enable_sh_grad=True)).to(dev)
+                    if args.exact:
+                        self.decoder.auto_plan = None
+                out = self.decoder.forward(dec.Gaussians(L["means"], None, L["rotations"], L["scales"], L["harmonics"],
+                                                         L["opacities"]),
+                                           L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w))
+                color = out.color
+                if "num_pairs" not in self.record:                  # (the first call of a shape is exact: statistics)
+                    self.record.update({k: v for k, v in self.decoder.last_call.items() if k != "counters"})
+            else:
+                color, depth, _alpha = spf.render_views(
+                    L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
+                    L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
+                    enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record)
             if args.torch_loss:
                 loss = torch.nn.functional.mse_loss(color, b.target[sl]) * self.weight
             else:
@@ -819,7 +854,9 @@ def main():
                        "loss": "torch.nn.functional.mse_loss" if args.torch_loss else "spfsplatv2_amd.mse_loss (fused HIP)",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
-                       "s_mult": args.s_mult, "pair_buffer": "exact (read-back per step)" if max_pairs is None else
+                       "s_mult": args.s_mult, "pair_buffer": ("module default: planned by DecoderSplattingCUDA itself, verified per call (one host sync at the "
+                                       "end of each forward)" if args.api == "module" and not args.exact else
+                                       "exact (read-back per step)") if max_pairs is None else
                                       f"planned from step 0 (x1.25 = {max_pairs.capacity} pairs), verified on device",
                        "launch": (f"{len(micro)} micro-batches of {S // len(micro)} scenes, one HIP graph and one stream "
                                   "each (kernels of the streams overlap; roofline durations are exclusive, from an "
@@ -830,7 +867,9 @@ def main():
                        "process_group": (dist.get_backend() if launched else None),
                        "api": ("per-view: the reference's own glue (repeat + torch camera preamble + b*v sequential "
                                "GaussianRasterizer calls with .item() syncs) on the drop-in surface"
-                               if args.api == "per-view" else "batched: one decoder call for all renders"),
+                               if args.api == "per-view" else
+                               ("module: DecoderSplattingCUDA.forward with nothing configured by the caller"
+                                if args.api == "module" else "batched: one decoder call for all renders")),
                        "sharding": ("views of the same scenes per rank + RCCL all-reduce of the Gaussian gradients: one flat "
                                     "bucket per scene micro-batch, written in place by the backward kernels, reduced "
                                     "asynchronously under the next micro-batch"

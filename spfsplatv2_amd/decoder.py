@@ -268,10 +268,11 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self.enable_sh_grad = cfg.enable_sh_grad
         self.register_buffer("background_color", torch.tensor(cfg.background_color, dtype=torch.float32),
                              persistent=False)
-        # None: every call sizes its pair buffer from a 16-byte read-back.  A training loop may set a
-        # ``spfsplatv2_amd.plan_pair_budget(...)`` here after one exact call: no call waits for the device any more
-        # (the plan is verified on the device, see rasterizer.PairBudget).
-        self.max_pairs = None
+        # `max_pairs` (property): None, or a ``spfsplatv2_amd.plan_pair_budget(...)`` the CALLER sets after one exact call --
+        # then no call waits for the device any more (the plan is verified on the device, see rasterizer.PairBudget) and
+        # the module's own planning (`auto_plan`, below) stands back.
+        self._max_pairs = None
+        self._auto_owned = False         # True while `_max_pairs` holds a plan the module made for itself
         # None: SH band 4 of a d_sh = 25 model follows the SPF_SH_BAND4 environment variable (default: not evaluated,
         # as in the published 3DGS kernels); True / False pins it for this decoder.
         self.sh_band4 = None
@@ -290,17 +291,25 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # cache stops capturing).  `eval_graphs = False` or SPF_EVAL_GRAPHS=0 switches it off; `clear_eval_graphs()`
         # releases the captured graphs and their buffers.
         self.eval_graphs = True
-        # Opt-in (`decoder.auto_plan = 1.5`, or SPF_AUTO_PLAN=1.5 in the environment): the module plans for itself, so an
-        # UNCHANGED caller gets the no-read-back path.  The first call of a shape (b, v, G, d_sh, h, w) runs in exact mode;
-        # the following ones run under `plan_pair_budget(that call, slack=auto_plan)`.  A call that nothing will be
-        # differentiated through verifies its plan at once and is re-run in exact mode if it failed (evaluation never
-        # sees a NaN image).  A TRAINING call cannot wait for its own verdict without the very synchronisation the plan
-        # is there to avoid: its verdict is copied to pinned memory behind the forward and read at the NEXT call (an
-        # event that is long past by then); if the plan had failed, that step's images and gradients were all NaN --
-        # what the reference's NaN-gradient guard (model_wrapper.py:1117-1151) skips -- and the next call is exact
-        # again and re-plans.  That possible skipped step is why this is opt-in.  `auto_plan` owns `max_pairs`.
-        env_plan = os.environ.get("SPF_AUTO_PLAN", "")
-        self.auto_plan: Optional[float] = float(env_plan) if env_plan else None
+        # `auto_plan` (slack factor, default 1.5; SPF_AUTO_PLAN=<slack>, SPF_AUTO_PLAN=0 / `auto_plan = None`: off): while the
+        # caller has set no `max_pairs`, the module plans for itself -- an UNCHANGED caller does not pay exact mode's
+        # read-back in the MIDDLE of every forward (project -> scan -> 16 bytes to the host -> allocate -> bin -> sort ->
+        # composite: the GPU idles while the host turns around, and the lists take the classic scan + binning chain).
+        # The first call of a shape (b, v, G, d_sh, h, w) runs in exact mode; the following ones run under
+        # `plan_pair_budget(that call, slack=auto_plan)` with direct bins, verified by the forward itself (check="early":
+        # the verdict is final behind the projection kernel and is copied out there; the host waits for it only after the
+        # sort and the compositing have been issued -- ONE wait per call as before, but the GPU works through it).  A call
+        # whose plan failed is re-run in exact mode on the spot and re-planned: results are ALWAYS those of exact mode
+        # (bit-identical in the forward: the sorted lists are unique), never NaN, nothing is raised.  Evaluation calls go
+        # through the graph cache above.  (Verifying at the END of the forward instead was measured: 0.540 ms per C2 step
+        # against exact mode's 0.470 -- the host then starts issuing the loss and the backward only when the GPU is idle.)
+        # `auto_plan_defer = True` (SPF_AUTO_PLAN_DEFER=1), opt-in, drops even that synchronisation for TRAINING calls: the
+        # verdict is copied to pinned memory behind the forward and read at the NEXT call (an event long past by then);
+        # if the plan had failed, that one step's images and gradients were all NaN -- what the reference's NaN-gradient
+        # guard (model_wrapper.py:1117-1151) skips -- and the next call is exact again and re-plans.
+        env_plan = os.environ.get("SPF_AUTO_PLAN", "1.5")
+        self.auto_plan: Optional[float] = (float(env_plan) or None) if env_plan else None
+        self.auto_plan_defer = os.environ.get("SPF_AUTO_PLAN_DEFER", "0") == "1"
         self._auto_key = None            # shape the current automatic plan was made for
         self._auto_pending = None        # (pinned verdict, event) of the last planned training call, until it is read
         self._auto_verdict = None        # the one pinned word + event all of them use
@@ -310,6 +319,17 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
 
     _EVAL_GRAPH_SLOTS = 4
     _EVAL_GRAPH_MISSES = 8
+
+    @property
+    def max_pairs(self):
+        return self._max_pairs
+
+    @max_pairs.setter
+    def max_pairs(self, plan) -> None:           # (the caller's word: the module's own planning stands back until it is None again)
+        self._max_pairs, self._auto_owned, self._auto_key, self._auto_pending = plan, False, None, None
+
+    def _set_auto(self, plan) -> None:
+        self._max_pairs, self._auto_owned = plan, True
 
     def clear_eval_graphs(self) -> None:
         self._graphs.clear()
@@ -354,38 +374,42 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     def _render(self, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
         tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
                    gaussians.rotations, gaussians.scales)
-        if not self.auto_plan or torch.cuda.is_current_stream_capturing():
+        auto = (self.auto_plan and (self._max_pairs is None or self._auto_owned) and extrinsics.is_cuda
+                and not torch.cuda.is_current_stream_capturing())
+        if not auto:
             return self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
-        # ---- automatic planning (see __init__) ----
+        # ---- the module's own planning (see __init__) ----
         from .rasterizer import plan_pair_budget
+        run = lambda: self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
         shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(gaussians.harmonics.shape),
                  tuple(image_shape))
         if shape != self._auto_key:
-            self._auto_key, self._auto_pending, self.max_pairs = shape, None, None
+            self._auto_key, self._auto_pending = shape, None
+            self._set_auto(None)
         elif self._auto_pending is not None:
             verdict, event = self._auto_pending
             self._auto_pending = None
             event.synchronize()
             if int(verdict[0]) != 0:
-                self.max_pairs = None                    # the last training step's plan failed: exact again, re-plan
+                self._set_auto(None)                     # (deferred mode) the last training step's plan failed: exact again
         trains = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
-        planned = self.max_pairs is not None
-        if planned and not trains and self.max_pairs.check == "deferred":
-            self.max_pairs = self.max_pairs._replace(check="backward")      # (evaluation: the graph path verifies at once)
-        elif planned and trains and self.max_pairs.check != "deferred":
-            self.max_pairs = self.max_pairs._replace(check="deferred")
+        planned = self._max_pairs is not None
+        if planned:      # evaluation: "backward" (the forward / the graph path verifies at once); training: "early" (the
+            #              forward verifies behind the projection kernel and raises), or nothing at all when deferred
+            check = ("deferred" if self.auto_plan_defer else "early") if trains else "backward"
+            self._set_auto(self._max_pairs._replace(check=check))
         try:
-            result = self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
+            result = run()
         except _SpfError:
-            if not planned or trains:
+            if not planned or (trains and self.auto_plan_defer):
                 raise
-            self.max_pairs = None                        # an evaluation call whose plan failed: exact mode, re-plan below
-            result = self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
+            self._set_auto(None)                         # this call's plan failed: the same call in exact mode, re-plan below
+            result = run()
         if self.last_call.get("counters") is None:
-            # this call ran in exact mode (the first of its shape, or a replayed evaluation graph that fell back to it)
-            # and left statistics: plan the next ones from them
-            self.max_pairs = plan_pair_budget(self.last_call, slack=float(self.auto_plan), check="deferred")
-        elif trains:
+            # this call ran in exact mode (the first of its shape, or one that fell back to it) and left statistics:
+            # plan the next ones from them
+            self._set_auto(plan_pair_budget(self.last_call, slack=float(self.auto_plan), check="deferred"))
+        elif trains and self.auto_plan_defer:
             if self._auto_verdict is None:
                 self._auto_verdict = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
             verdict, event = self._auto_verdict

@@ -76,7 +76,12 @@ class PairBudget(NamedTuple):
     check          "backward": the backward pass reads the flag (one host sync) and raises if the plan failed (a call
                    that will have no backward verifies at once; ``DecoderSplattingCUDA``'s replayed evaluation graphs
                    re-run such a call in exact mode instead of raising);
-                   "deferred": the library never reads it -- call ``last_plan_flags()`` when convenient
+                   "deferred": the library never reads it -- call ``last_plan_flags()`` when convenient;
+                   "early": the FORWARD verifies and raises, at the cost of one short wait -- with direct bins the verdict
+                   is final when the projection kernel has run, so it is copied to pinned memory right behind that kernel,
+                   the rest of the chain (sort, compositing) is issued, and only then does the host wait for the copy:
+                   the GPU keeps working through the wait (exact mode's read-back sits at the same point of the chain but
+                   with nothing issued behind it).  What ``DecoderSplattingCUDA`` uses for its own planning.
     """
     capacity: int
     max_tile_list: int = 0
@@ -196,6 +201,20 @@ def _on_device_of_first_arg(fn):
     return wrapped
 
 
+_early_cache: dict = {}
+
+
+def _early_verdict(dev: torch.device):
+    """(pinned int32[1], event) of a device, for check="early" plans: one pair per device and host thread is enough --
+    a forward call has read its verdict before it returns."""
+    import threading
+    key = (dev.index, threading.get_ident())
+    got = _early_cache.get(key)
+    if got is None:
+        got = _early_cache[key] = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+    return got
+
+
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                   view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None, sh_band4=False,
@@ -230,7 +249,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         else:
             rec_out["counters"] = counters
             _last["counters"] = counters
-            if _plan_mode(max_pairs) == 1 and nothing_needs_grad and not torch.cuda.is_current_stream_capturing():
+            early = isinstance(max_pairs, PairBudget) and max_pairs.check == "early"
+            if ((_plan_mode(max_pairs) == 1 and nothing_needs_grad) or early) and not torch.cuda.is_current_stream_capturing():
                 _raise_if_plan_failed(counters, pairs.numel())
         return ((image, depth, alpha, radii_v),
                 (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, 0, pairs.numel()))
@@ -300,6 +320,12 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         rec_out["counters"] = counters
         _last["counters"] = counters
         rec_out["plan"] = _last["plan"] = (int(bin_cap), int(capacity), lib.spf_raster_pair_shards(S, G) if bin_cap else 1)
+    early = None
+    if isinstance(max_pairs, PairBudget) and max_pairs.check == "early" and not torch.cuda.is_current_stream_capturing():
+        early = _early_verdict(dev)
+        if bin_cap:      # direct bins: the projection kernel has binned -- the verdict is final behind it
+            early[0].copy_(counters[2:3], non_blocking=True)
+            early[1].record()
     if not bin_cap:
         pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
         st.pairs = _ptr(pairs)
@@ -307,6 +333,14 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     _lib.check(lib.spf_raster_forward_render(C.byref(dims), C.byref(inp), C.byref(st), C.byref(out),
                                              capacity, max_tile, dense, stream),
                "spf_raster_forward_render")
+    if early is not None:
+        if bin_cap:
+            early[1].synchronize()                   # (waits for the projection kernel and 4 bytes, not for the chain)
+            failed = int(early[0][0]) != 0
+        else:
+            failed = True                            # classic chain: the binning kernel decides -- read it the slow way
+        if failed:
+            _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity, rec_out.get("plan"))
     if max_pairs is not None and _plan_mode(max_pairs) == 1 and nothing_needs_grad \
             and not torch.cuda.is_current_stream_capturing():
         # check="backward" promises that a failed plan raises -- but no backward will come (evaluation under
@@ -403,7 +437,7 @@ def _plan_mode(max_pairs) -> int:
     """0 = exact mode, 1 = planned and verified in backward, 2 = planned, verification left to the caller."""
     if max_pairs is None:
         return 0
-    return 2 if isinstance(max_pairs, PairBudget) and max_pairs.check == "deferred" else 1
+    return 2 if isinstance(max_pairs, PairBudget) and max_pairs.check in ("deferred", "early") else 1
 
 
 @_on_device_of_first_arg

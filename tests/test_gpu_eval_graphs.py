@@ -97,15 +97,16 @@ def test_replayed_call_whose_plan_fails_is_rerun_in_exact_mode(hip_lib):
         assert torch.equal(again.color, exact.color)
 
 
-def _auto_decoder(slack=1.3):
-    d = util.product_decoder()
-    d.auto_plan = slack
+def _auto_decoder(slack=1.3, defer=False):
+    d = util.product_decoder(auto_plan=slack)
+    d.auto_plan_defer = defer
     return d
 
 
 def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
-    """decoder.auto_plan (opt-in): the module plans for itself.  First call of a shape: exact mode; the next ones planned
-    (and, being evaluation calls, captured); inputs that outgrow the plan are re-run in exact mode at once and re-planned."""
+    """decoder.auto_plan (on by default): the module plans for itself.  First call of a shape: exact mode; the next ones
+    planned (and, being evaluation calls, captured); inputs that outgrow the plan are re-run in exact mode at once and
+    re-planned."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec
     small = syn.make_batch("TEST", 1, 3, seed=21, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
@@ -131,10 +132,52 @@ def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
         assert spf.plan_flags(d.last_call) == 0
 
 
-def test_auto_plan_training_reads_the_verdict_one_call_late(hip_lib):
-    """A training call under an automatic plan waits for nothing: its verdict is read at the next call.  A step whose
-    plan failed is all NaN (the reference's NaN-gradient guard skips it, model_wrapper.py:1117-1151), the next one runs in
-    exact mode and re-plans."""
+def test_default_decoder_plans_for_itself_and_always_returns_exact_results(hip_lib):
+    """A decoder nobody configured (what an unchanged caller of the reference gets): the first call of a shape is exact,
+    later TRAINING calls are planned and verified when their forward has been issued; one that outgrew its plan is re-run
+    exactly on the spot -- images bit-equal to exact mode, gradients to rounding, never NaN, nothing raised.  A `max_pairs`
+    set by the caller switches the module's own planning off."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    small = syn.make_batch("TEST", 1, 3, seed=24, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    big = syn.make_batch("TEST", 1, 3, seed=24, s_mult=300.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+
+    def step(d, b):
+        means = b.means.clone().requires_grad_(True)
+        g = dec.Gaussians(means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
+        out = d.forward(g, b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
+        out.color.square().mean().backward()
+        return out.color.detach(), means.grad
+
+    ref = util.product_decoder()                                       # exact mode, every call
+    d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
+                                                    make_scale_invariant=True, enable_cov_grad=True,
+                                                    enable_sh_grad=True)).cuda()
+    assert d.auto_plan == 1.5 and not d.auto_plan_defer and d.max_pairs is None
+    want_small, want_big = step(ref, small), step(ref, big)
+    for i in range(3):
+        c, g = step(d, small)
+        assert torch.equal(c, want_small[0]) and util.rel_linf(g, want_small[1]) < 1e-5
+        assert isinstance(d.max_pairs, spf.PairBudget) and (d.last_call.get("counters") is None) == (i == 0)
+    cap = d.max_pairs.capacity
+    for i in range(2):
+        c, g = step(d, big)                                           # i = 0: plan fails, re-run exactly, re-planned
+        assert torch.equal(c, want_big[0]) and util.rel_linf(g, want_big[1]) < 1e-5
+    assert d.max_pairs.capacity > cap and d.last_call.get("counters") is not None
+    # the caller's own plan switches the module's planning off
+    mine = d.max_pairs._replace(check="deferred")
+    d.max_pairs = mine
+    step(d, small)
+    assert d.max_pairs is mine and spf.plan_flags(d.last_call) == 0
+    d.max_pairs = None
+    c, g = step(d, small)                                             # back to the module: exact first
+    assert d.last_call.get("counters") is None and torch.equal(c, want_small[0])
+
+
+def test_auto_plan_deferred_training_reads_the_verdict_one_call_late(hip_lib):
+    """`auto_plan_defer` (opt-in): a training call under an automatic plan waits for nothing, its verdict is read at the next
+    call.  A step whose plan failed is all NaN (the reference's NaN-gradient guard skips it, model_wrapper.py:1117-1151),
+    the next one runs in exact mode and re-plans."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec
     small = syn.make_batch("TEST", 1, 3, seed=22, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
@@ -147,7 +190,7 @@ def test_auto_plan_training_reads_the_verdict_one_call_late(hip_lib):
         out.color.square().mean().backward()
         return out.color.detach(), means.grad
 
-    ref, d = util.product_decoder(), _auto_decoder()
+    ref, d = util.product_decoder(), _auto_decoder(defer=True)
     want_small, want_big = step(ref, small), step(ref, big)
     c, g = step(d, small)                                             # exact, plans
     assert torch.equal(c, want_small[0]) and isinstance(d.max_pairs, spf.PairBudget)

@@ -116,13 +116,16 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
     return res
 
 
-def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cuda", max_pairs=None, band4=None):
+def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cuda", max_pairs=None, band4=None,
+                    auto_plan=None):
     """The product's decoder MODULE under the reference's registry name and config
-    (decoder/__init__.py:4-12, decoder_splatting_cuda.py:15-21)."""
+    (decoder/__init__.py:4-12, decoder_splatting_cuda.py:15-21).  `auto_plan`: the module's own planning is OFF here
+    unless asked for (the tests pin exact / planned calls themselves; tests/test_gpu_eval_graphs.py covers the default)."""
     from spfsplatv2_amd import decoder as dec
     d = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=list(background),
                                                     make_scale_invariant=scale_invariant, enable_cov_grad=True,
                                                     enable_sh_grad=True)).to(device)
+    d.auto_plan = auto_plan
     d.max_pairs = max_pairs
     d.sh_band4 = band4
     return d
