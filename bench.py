@@ -242,6 +242,7 @@ SECONDARY = (
     ("REF2V_band4", ["--config", "REF2V"], {"SPF_SH_BAND4": "1"}),
     ("REF10V", ["--config", "REF10V"], {"SPF_SH_BAND4": "0"}),
     ("C2_stress", ["--config", "C2", "--s-mult", "10"], {}),     # SURVEY.md 8(d)'s stress regime: footprints x 10, dense tiles
+    ("C2_module", ["--config", "C2", "--api", "module"], {}),    # an UNCHANGED caller: DecoderSplattingCUDA.forward, nothing configured
     ("C2_streams2", ["--config", "C2", "--streams", "2"], {}),
     ("eval_1x3", ["--eval-latency"], {"SPF_SH_BAND4": "0"}),
     ("rope2d", ["--rope"], {}),

@@ -175,6 +175,28 @@ def test_product_decoder_registry_and_types():
     assert isinstance(d, dec.DecoderSplattingCUDA) and isinstance(d, dec.Decoder)
     assert list(dec.DECODERS) == ["splatting_cuda"] and len(list(d.parameters())) == 0
     assert "background_color" not in d.state_dict()          # non-persistent buffer, like the reference
+    # planning: the module plans for itself (slack 1.5) until the caller sets a plan; the caller's plan is the caller's
+    from spfsplatv2_amd import PairBudget
+    assert d.auto_plan == 1.5 and not d.auto_plan_defer and d.max_pairs is None and not d._auto_owned
+    d._set_auto(PairBudget(1000, 512, "early"))
+    assert d.max_pairs.capacity == 1000 and d._auto_owned
+    mine = PairBudget(2000, 1024, "deferred")
+    d.max_pairs = mine
+    assert d.max_pairs is mine and not d._auto_owned and d._auto_key is None
+    d.max_pairs = None
+    assert d.max_pairs is None and not d._auto_owned
+
+
+def test_auto_plan_environment_switches(monkeypatch):
+    from spfsplatv2_amd import decoder as dec
+    cfg = dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
+                                      make_scale_invariant=True, enable_cov_grad=True, enable_sh_grad=True)
+    for env, want in (("0", None), ("", None), ("2", 2.0), ("1.25", 1.25)):
+        monkeypatch.setenv("SPF_AUTO_PLAN", env)
+        assert dec.get_decoder(cfg).auto_plan == want, env
+    monkeypatch.delenv("SPF_AUTO_PLAN")
+    monkeypatch.setenv("SPF_AUTO_PLAN_DEFER", "1")
+    assert dec.get_decoder(cfg).auto_plan_defer and dec.get_decoder(cfg).auto_plan == 1.5
 
 
 @pytest.mark.parametrize("tag", ["decoder_k4_si", "decoder_k25_nosi"])
