@@ -273,6 +273,9 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # the module's own planning (`auto_plan`, below) stands back.
         self._max_pairs = None
         self._auto_owned = False         # True while `_max_pairs` holds a plan the module made for itself
+        self._auto_key = None            # shape the current automatic plan was made for
+        self._auto_plans: dict = {}      # shape -> the plan it ran under last (a few shapes alternate in a real loop)
+        self._auto_pending = None        # (deferred mode) (pinned verdict, event) of the last planned training call, until read
         # None: SH band 4 of a d_sh = 25 model follows the SPF_SH_BAND4 environment variable (default: not evaluated,
         # as in the published 3DGS kernels); True / False pins it for this decoder.
         self.sh_band4 = None
@@ -310,8 +313,6 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         env_plan = os.environ.get("SPF_AUTO_PLAN", "1.5")
         self.auto_plan: Optional[float] = (float(env_plan) or None) if env_plan else None
         self.auto_plan_defer = os.environ.get("SPF_AUTO_PLAN_DEFER", "0") == "1"
-        self._auto_key = None            # shape the current automatic plan was made for
-        self._auto_pending = None        # (pinned verdict, event) of the last planned training call, until it is read
         self._auto_verdict = None        # the one pinned word + event all of them use
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
         self._graph_seen: dict = {}      # key -> None: keys seen once, not yet captured
@@ -326,7 +327,16 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
 
     @max_pairs.setter
     def max_pairs(self, plan) -> None:           # (the caller's word: the module's own planning stands back until it is None again)
+        self._stash_auto()
         self._max_pairs, self._auto_owned, self._auto_key, self._auto_pending = plan, False, None, None
+
+    def _stash_auto(self) -> None:
+        """Remember the module's own plan of the current shape (a plan is verified by every call that uses it, so a stale
+        one costs one re-run)."""
+        if self._auto_owned and self._auto_key is not None and self._max_pairs is not None:
+            if len(self._auto_plans) >= 8 and self._auto_key not in self._auto_plans:
+                self._auto_plans.pop(next(iter(self._auto_plans)))
+            self._auto_plans[self._auto_key] = self._max_pairs
 
     def _set_auto(self, plan) -> None:
         self._max_pairs, self._auto_owned = plan, True
@@ -384,8 +394,11 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(gaussians.harmonics.shape),
                  tuple(image_shape))
         if shape != self._auto_key:
+            # (a loop may alternate between a few shapes -- training and validation views, test_step's one-view calls:
+            #  every shape keeps its plan)
+            self._stash_auto()
             self._auto_key, self._auto_pending = shape, None
-            self._set_auto(None)
+            self._set_auto(self._auto_plans.get(shape))
         elif self._auto_pending is not None:
             verdict, event = self._auto_pending
             self._auto_pending = None

@@ -170,8 +170,18 @@ def test_default_decoder_plans_for_itself_and_always_returns_exact_results(hip_l
     step(d, small)
     assert d.max_pairs is mine and spf.plan_flags(d.last_call) == 0
     d.max_pairs = None
-    c, g = step(d, small)                                             # back to the module: exact first
-    assert d.last_call.get("counters") is None and torch.equal(c, want_small[0])
+    c, g = step(d, small)                                             # back to the module: the shape's plan is remembered
+    assert d.last_call.get("counters") is not None and torch.equal(c, want_small[0])
+    # two shapes alternating (training views / one validation view): each keeps its plan, only the first call of each is exact
+    one = syn.make_batch("TEST", 1, 1, seed=25, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    want_one = step(ref, one)
+    exact_calls = 0
+    for i in range(3):
+        for b, want in ((one, want_one), (small, want_small)):
+            c, g = step(d, b)
+            exact_calls += d.last_call.get("counters") is None
+            assert torch.equal(c, want[0]) and util.rel_linf(g, want[1]) < 1e-5
+    assert exact_calls == 1, exact_calls
 
 
 def test_auto_plan_deferred_training_reads_the_verdict_one_call_late(hip_lib):
