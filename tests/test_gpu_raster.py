@@ -131,6 +131,13 @@ def test_planned_pair_budget_is_verified_on_the_device(hip_lib):
     # too few pairs: flag 1
     util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan._replace(capacity=st["num_pairs"] // 2))
     assert spf.last_plan_flags() & 1
+    # check="early": the forward itself verifies (behind the projection kernel, the rest of the chain already issued) and
+    # raises; a plan that holds gives the planned result with nothing left to check
+    early = util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan._replace(check="early"))
+    assert torch.equal(early["color"], exact["color"]) and spf.last_plan_flags() == 0
+    for bad in (short, plan._replace(capacity=st["num_pairs"] // 2)):
+        with pytest.raises(SpfError):
+            util.run_product(batch, background=bg, scale_invariant=si, max_pairs=bad._replace(check="early"), with_grads=False)
     # and a good plan afterwards is clean again
     util.run_product(batch, background=bg, scale_invariant=si, max_pairs=plan)
     assert spf.last_plan_flags() == 0
