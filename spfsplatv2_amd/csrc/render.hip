@@ -586,8 +586,7 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
     if (bmax == 0) return;
 
     float Tr = T_final;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accD = 0.f;   // colour/depth behind the current entry
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lD = 0.f;
+    float sB = -tail * T_final;          // running "behind" scalar of the replay (as in the lists form, see its phase B)
 
     bool staged = false;
     for (int base = (int)((bmax - 1) / RS) * RS; base >= 0; base -= RS) {
@@ -646,19 +645,15 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                     const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
                     Tr = fmaf(Tr, alpha * inv1ma, Tr);       // (not Tr * inv1ma: see the lists kernel)
                     w = alpha * Tr;
-                    // colour accumulated behind this entry (recurrence, back to front)
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    accD = last_alpha * lD + (1.f - last_alpha) * accD;
-                    lc0 = p2.x; lc1 = p2.y; lc2 = p2.z; lD = p2.w;
-                    float dL_dalpha_ = (p2.x - acc0) * gI0 + (p2.y - acc1) * gI1 + (p2.z - acc2) * gI2 +
-                                       (p2.w - accD) * gD;
-                    dL_dalpha_ *= Tr;
-                    last_alpha = alpha;
-                    // image = C + T_final * bg and alpha_out = 1 - T_final both see alpha only through
-                    // T_final: dT_final/dalpha = -T_final / (1 - alpha)
-                    dL_dalpha_ += (T_final * inv1ma) * tail;
+                    // With w_j = alpha_j*T_j and cg_j = c_j . dL/dC (+ depth_j * dL/ddepth):
+                    //   dL/dalpha_i = cg_i*T_i - (sum_{j behind i} cg_j*w_j - tail*T_final) / (1 - alpha_i)
+                    // (image = C + T_final*bg and alpha_out = 1 - T_final see alpha_i only through T_final); the bracket
+                    // is ONE running scalar -- the classic form carries the normalised colour behind the entry instead,
+                    // four accumulators and a dot product per hit: 19 instructions where this takes 7
+                    float cg = fmaf(p2.x, gI0, fmaf(p2.y, gI1, p2.z * gI2));
+                    if (DEPTH_GRAD) cg = fmaf(p2.w, gD, cg);
+                    const float dL_dalpha_ = fmaf(cg, Tr, -(sB * inv1ma));
+                    sB = fmaf(cg, w, sB);
                     u = Gv * dL_dalpha_;
                 }
                 const float r_c0 = w * gI0, r_c1 = w * gI1, r_c2 = w * gI2, r_dd = DEPTH_GRAD ? w * gD : 0.f;
