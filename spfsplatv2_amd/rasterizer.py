@@ -81,7 +81,9 @@ class PairBudget(NamedTuple):
                    is final when the projection kernel has run, so it is copied to pinned memory right behind that kernel,
                    the rest of the chain (sort, compositing) is issued, and only then does the host wait for the copy:
                    the GPU keeps working through the wait (exact mode's read-back sits at the same point of the chain but
-                   with nothing issued behind it).  What ``DecoderSplattingCUDA`` uses for its own planning.
+                   with nothing issued behind it).  What ``DecoderSplattingCUDA`` uses for its own planning.  (Calls that
+                   cannot run with direct bins, and calls through the compiled per-view binding, verify when the whole
+                   forward has been issued; under stream capture nothing is read: the flag stays for the caller.)
     """
     capacity: int
     max_tile_list: int = 0
