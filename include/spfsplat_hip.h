@@ -47,11 +47,7 @@ extern "C" {
 #define SPF_E_CAPACITY (-3)  /* pair buffer smaller than the number of (Gaussian, tile) pairs */
 
 #define SPF_UNKNOWN 0xffffffffu
-#ifndef SPF_TILE
-#define SPF_TILE 16          /* square tile edge in pixels: 16 (four waves per tile, render.hip) or 8 (one wave per tile,
-                                render_wave.hip; -DSPF_TILE=8 builds the whole library -- projection, bins, sort, compositing
-                                -- on the 8 px grid).  spf_raster_num_tiles() tells a host which grid the library was built for */
-#endif
+#define SPF_TILE 16          /* square tile edge in pixels (four waves per tile); spf_raster_num_tiles() counts them */
 #define SPF_DENSE_AREA 26    /* mean cull-box area (px) above which a tile's BACKWARD takes the dense "rows" form inside the
                                 compositing kernel (and what the dense-tile census, counters[3], counts) */
 #define SPF_DENSE_AREA_FWD 120 /* the same for the FORWARD: the sparse "lists" form stays ahead of the rows form up to much

@@ -17,8 +17,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OUT_DIR = PKG / os.environ.get("SPF_LIB_DIR", "_C")      # SPF_LIB_DIR=_C_xyz: a variant build next to the regular one
 LIB = OUT_DIR / "libspfsplat_hip.so"
-SOURCES = ["api.hip", "adapter.hip", "camera.hip", "project.hip", "binning.hip", "render.hip", "render_wave.hip", "rope2d.hip",
-           "loss.hip"]
+SOURCES = ["api.hip", "adapter.hip", "camera.hip", "project.hip", "binning.hip", "render.hip", "rope2d.hip", "loss.hip"]
 HEADERS = [CSRC / "spf_common.h", PKG.parent / "include" / "spfsplat_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

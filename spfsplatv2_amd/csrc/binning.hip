@@ -965,7 +965,7 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
                                                                                    capacity, RT, thr, order, T, thr_f);
     // many tiles, lists of 2 .. 1024: a pair of waves per tile (C2 29.3 -> 27.7 us, C5 57.3 -> 50.1; SPF_SORT_SINGLE=1: one wave)
     // (8 px grid: lists are a quarter as long -- up to 512 entries one wave per tile, four tiles per block, is the better fit)
-    const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE") && (kTile == 16 || mx > 512);
+    const bool pairsk = !blocks && mx > 1 && mx <= 1024 && !getenv("SPF_SORT_SINGLE");
     if (pairsk)
         spf_sort_tiles_pair_kernel<<<ob + RT, 2 * kWave, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs, capacity, RT,
                                                                       thr, order, T, thr_f);

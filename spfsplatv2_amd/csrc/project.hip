@@ -450,8 +450,7 @@ constexpr uint32_t kHistCountShift = 20u, kHistAreaMask = (1u << 20) - 1u;
 // views whose histograms fit the LDS budget at once (the loop flushes between groups)
 // (direct bins: a group also holds the bins' base offsets [VG][T] and every thread's (rect, depth) per view)
 __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false) {
-    // (8 px grid: four times the tiles per render -- a budget that still holds the four views of the headline batch)
-    const int fit = direct ? ((kTile == 8 ? 44 : 36) * 1024) / (8 * T + 2048) : (32 * 1024) / (4 * T);
+    const int fit = direct ? (36 * 1024) / (8 * T + 2048) : (32 * 1024) / (4 * T);
     return fit < 1 ? 1 : (fit < V ? fit : V);
 }
 
@@ -535,21 +534,14 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
             if (ok) {
                 // The 3-sigma rect is part of the SEMANTICS: a Gaussian reaches exactly the pixels
                 // of the 16 px tiles its radius box touches -- also pixels beyond the radius inside those tiles -- and is
-                // culled (radii = 0) when it touches none.  So the rect is always taken on the 16 px grid; a build on the
-                // 8 px grid (kTile == 8) then covers the same pixels with twice the tiles per side (the cull-disc shrink
-                // below is exact at any granularity).
-                constexpr int kSemTile = 16;
+                // culled (radii = 0) when it touches none (the cull-disc shrink below never drops a contributing pixel).
+                constexpr int kSemTile = kTile;
                 const float fgx = (float)((d.W + kSemTile - 1) / kSemTile), fgy = (float)((d.H + kSemTile - 1) / kSemTile);
                 x0 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px - radius) * (1.0f / kSemTile))));
                 y0 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py - radius) * (1.0f / kSemTile))));
                 x1 = (int)fminf(fgx, fmaxf(0.f, truncf((pr.px + radius + (kSemTile - 1)) * (1.0f / kSemTile))));
                 y1 = (int)fminf(fgy, fmaxf(0.f, truncf((pr.py + radius + (kSemTile - 1)) * (1.0f / kSemTile))));
                 ok = (x1 - x0) * (y1 - y0) > 0;
-                if (kTile != kSemTile) {
-                    constexpr int f = kSemTile / kTile;
-                    x0 = min(tiles_x, f * x0); x1 = min(tiles_x, f * x1);
-                    y0 = min(tiles_y, f * y0); y1 = min(tiles_y, f * y1);
-                }
             }
         }
         float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = make_float4(0.f, 0.f, 0.f, -1.f), rec2 = rec0;

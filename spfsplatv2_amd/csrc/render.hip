@@ -1003,10 +1003,6 @@ __global__ __launch_bounds__(kBlock, BPC) void spf_render_bwd_lists_kernel(
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
-hipError_t launch_render_fwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfOutputs&, int, int,
-                                  const TileLists&, hipStream_t);                     // render_wave.hip
-hipError_t launch_render_bwd_wave(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int,
-                                  const TileLists&, hipStream_t);
 uint32_t dense_threshold_fwd();
 uint32_t dense_threshold() {                       // (read per call: the tests flip it)
     const char* const e = getenv("SPF_DENSE_AREA");
@@ -1033,7 +1029,6 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     const int RT = d.S * d.V * T;
     TileLists tlo = tile_lists(st, d);
     if (ordered) tlo.order = tile_order_ptr(st, d, RT);
-    if (kTile == 8) return launch_render_fwd_wave(d, in, st, out, T, tiles_x, tlo, stream);   // one wave per 8x8 tile
     const int grid = (RT + 7) / 8 * 8;
     const char* const fe = getenv("SPF_FWD_STAGE");           // ("256" / "512" pins the instantiation: experiments, tests)
     const int stage = fe ? atoi(fe) : (RT <= kFwdLongRoundsMaxTiles ? 512 : 256);
@@ -1072,11 +1067,6 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
                              int tiles_x, uint64_t capacity, bool ordered, hipStream_t stream) {
     const int RT = d.S * d.V * T;
     const int grid = (RT + 7) / 8 * 8;
-    if (kTile == 8) {
-        TileLists tlo = tile_lists(st, d);
-        if (ordered) tlo.order = tile_order_ptr(st, d, RT);
-        return launch_render_bwd_wave(d, in, st, g, T, tiles_x, tlo, stream);
-    }
     if (g.dL_ddepth) launch_render_bwd_t<true>(d, in, st, g, T, tiles_x, RT, grid, capacity, ordered, stream);
     else launch_render_bwd_t<false>(d, in, st, g, T, tiles_x, RT, grid, capacity, ordered, stream);
     return hipGetLastError();

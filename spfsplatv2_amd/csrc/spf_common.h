@@ -217,9 +217,8 @@ __device__ __forceinline__ uint32_t disc_area_capped_fast(float gx, float gy, fl
     const float w = fminf(fmaxf(b.xhi - b.xlo + 1.f, 0.f), (float)kTile), h = fminf(fmaxf(b.yhi - b.ylo + 1.f, 0.f), (float)kTile);
     return (uint32_t)(w * h);
 }
-// (the 8 px grid has no dense kernels: its one-wave-per-tile kernels take every tile, render_wave.hip)
 __host__ __device__ __forceinline__ bool tile_is_dense(uint32_t area_sum, uint32_t n, uint32_t thr = SPF_DENSE_AREA) {
-    return kTile == 16 && area_sum > thr * n;
+    return area_sum > thr * n;
 }
 
 // Where tile `vid` (= render * T + tile) keeps its list: packed lists (start = exclusive scan of the counts) or, with
