@@ -279,8 +279,8 @@ def run_secondary(args) -> dict:
         keep["launch"] = line.get("config", {}).get("launch")
         if "roofline" in line:
             rf = line["roofline"]
-            keep["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "launch_ms", "achieved", "frac", "traffic",
-                                                               "algorithmic_bytes_per_launch")}
+            keep["dominant_kernel"] = {k: rf.get(k) for k in ("kernel", "launch_ms", "achieved", "frac", "frac_by_counters",
+                                                               "traffic", "algorithmic_bytes_per_launch")}
         for k in ("latency_ms", "timing", "cases", "cpu_baseline", "roofline"):
             if k in line and not (k == "roofline" and name != "rope2d"):
                 keep[k] = line[k]
@@ -398,60 +398,100 @@ def eval_latency(args, dev) -> dict:
 ROPE_SHAPES = ((48, 256, 16, 64), (32, 258, 12, 64))     # encoder self-attention, decoder
 
 
+ROPE_COLD_BYTES = 512 << 20     # bytes of q rows a rotation must touch before it comes back to a buffer (2 x the 256 MiB MALL)
+
+
 def rope_bench(args, dev) -> dict:
     """RoPE-2D (`curope.rope_2d`, curope.cpp:49-65 / kernels.cu:84-108) under the driver's clock: the HIP kernel in place
-    on strided q views (and q + k in one launch) of a [B,N,3,H,D] qkv buffer, as blocks.py:97-104 calls it.
+    on strided q views (and q + k in one launch) of [B,N,3,H,D] qkv buffers, as blocks.py:97-104 calls it.
 
-    `us` = device time per call in a stream of DEPENDENT calls: 50 calls captured in one HIP graph, replayed, HIP events
-    around the replays, / 50 (a Python thread cannot issue a 10 us kernel every 10 us, and an event pair around ONE launch
-    adds the launch latency to it: `us_single_event` reports that too).  Algorithmic bytes:
-    2*B*N*H*D*sizeof + 16*B*N per tensor.  CPU baselines, fp32, same shapes: oracle/rope_ref.c (the restated C++ loop
-    curope.cpp:11-47, one core, as the reference runs it) and oracle/rope_torch_ref.py (the restated PyTorch fallback
-    pos_embed.py:112-159, on up to 16 host cores)."""
+    The reference rotates a DIFFERENT q / k of a different layer every time (24 encoder + 12 decoder blocks per forward):
+    every call reads its rows from HBM.  So `us` = device time per call in a ROTATION over n distinct qkv buffers whose q
+    rows add up to > 512 MiB (twice the 256 MiB Infinity Cache: a buffer's lines are cold again when its turn comes):
+    one HIP graph of one call per buffer, replayed, HIP events around the replays.  `us_cache_resident` (round 5's method,
+    50 dependent calls on ONE buffer: the working set stays in the Infinity Cache) is kept next to it, labelled as what it
+    is -- the kernel's issue-side ceiling, not an HBM figure.  Algorithmic bytes: 2*B*N*H*D*sizeof +
+    16*B*N per tensor; `roofline.traffic` = the PMC bytes per launch of the headline case (profiles/pmc_summary_rope.json,
+    tools/pmc_rope.sh: `--rope --eager` runs only that case, launched one by one).  CPU baselines, fp32, same shapes:
+    oracle/rope_ref.c (the restated C++ loop curope.cpp:11-47, one core, as the reference runs it) and
+    oracle/rope_torch_ref.py (the restated PyTorch fallback pos_embed.py:112-159, on up to 16 host cores)."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib
     cases = []
     calls = 50
-    for (B, N, H, D) in ROPE_SHAPES:
-        for dt in (torch.float32, torch.float16):
+    pmc_only = args.eager            # counter passes: the headline case only, eager launches over the rotation
+    for (B, N, H, D) in ROPE_SHAPES[:1] if pmc_only else ROPE_SHAPES:
+        for dt in (torch.float32,) if pmc_only else (torch.float32, torch.float16):
             gen = torch.Generator().manual_seed(B + N)
-            qkv = torch.randn(B, N, 3, H, D, generator=gen).to(dev, dt)
+            esz = 4 if dt == torch.float32 else 2
+            q_bytes = B * N * H * D * esz
+            n_buf = max(8, -(-ROPE_COLD_BYTES // q_bytes))
+            base = torch.randn(B, N, 3, H, D, generator=gen).to(dev, dt)
+            bufs = [base] + [base.clone() for _ in range(n_buf - 1)]
             pos = torch.randint(0, 18, (B, N, 2), generator=gen).to(dev)
-            q, k = qkv[:, :, 0], qkv[:, :, 1]                    # strided [B,N,H,D] views, stride(2) = D
-            for pair in (False, True):
-                fn = (lambda: spf.rope_2d_pair(q, k, pos, 100.0, 1.0)) if pair else (lambda: spf.rope_2d(q, pos, 100.0, 1.0))
-                for _ in range(5):
-                    fn()
+            qs = [t[:, :, 0] for t in bufs]                      # strided [B,N,H,D] views, stride(2) = D
+            ks = [t[:, :, 1] for t in bufs]
+            for pair in (False,) if pmc_only else (False, True):
+                def one(i):
+                    if pair:
+                        spf.rope_2d_pair(qs[i], ks[i], pos, 100.0, 1.0)
+                    else:
+                        spf.rope_2d(qs[i], pos, 100.0, 1.0)
+                for i in range(n_buf):
+                    one(i)
+                if pmc_only:
+                    for _ in range(3):
+                        for i in range(n_buf):
+                            one(i)
+                    torch.cuda.synchronize(dev)
+                    byts = 2 * q_bytes + 16 * B * N
+                    return {"metric": "RoPE-2D counter pass (headline case only, eager rotation)", "value": None,
+                            "config": {"workload": f"rope2d fp32 q ({B},{N},{H},{D}) over {n_buf} buffers"},
+                            "algorithmic_bytes": byts}
                 _lib.stage_timing_enable(["rope2d"])
-                for _ in range(20):
-                    fn()
+                for i in range(min(20, n_buf)):
+                    one(i)
                 torch.cuda.synchronize(dev)
                 ms, cnt = _lib.stage_times()["rope2d"]
                 _lib.stage_timing_enable(False)
                 single = 1e3 * ms / max(cnt, 1)
-                g_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_):
-                    for _ in range(calls):
-                        fn()
-                g_.replay()
-                torch.cuda.synchronize(dev)
                 reps = max(args.steps // 2, 10)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ts = []
-                for _ in range(5):
-                    e0.record()
-                    for _ in range(reps):
-                        g_.replay()
-                    e1.record()
+
+                def timed(graph, per_replay):
+                    graph.replay()
                     torch.cuda.synchronize(dev)
-                    ts.append(e0.elapsed_time(e1) * 1e3 / (reps * calls))
-                us = sorted(ts)[len(ts) // 2]
-                byts = (2 if pair else 1) * 2 * B * N * H * D * qkv.element_size() + 16 * B * N
+                    ts = []
+                    for _ in range(5):
+                        e0.record()
+                        for _ in range(reps):
+                            graph.replay()
+                        e1.record()
+                        torch.cuda.synchronize(dev)
+                        ts.append(e0.elapsed_time(e1) * 1e3 / (reps * per_replay))
+                    return sorted(ts)[len(ts) // 2]
+                g_rot = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_rot):
+                    for i in range(n_buf):
+                        one(i)
+                us = timed(g_rot, n_buf)
+                g_hot = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_hot):
+                    for _ in range(calls):
+                        one(0)
+                us_hot = timed(g_hot, calls)
+                del g_rot, g_hot
+                byts = (2 if pair else 1) * 2 * q_bytes + 16 * B * N
                 cases.append({"shape": [B, N, H, D], "dtype": str(dt).split(".")[-1],
                               "tensors": "q+k, one launch" if pair else "q", "us": round(us, 3),
-                              "us_single_event": round(single, 3), "algorithmic_bytes": byts,
-                              "GBs": round(byts / us / 1e3, 1), "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)})
+                              "buffers_in_rotation": n_buf, "q_bytes_in_rotation": n_buf * q_bytes * (2 if pair else 1),
+                              "us_cache_resident": round(us_hot, 3), "us_single_event": round(single, 3),
+                              "algorithmic_bytes": byts, "GBs": round(byts / us / 1e3, 1),
+                              "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4),
+                              "GBs_cache_resident": round(byts / us_hot / 1e3, 1)})
                 log(f"rope2d {cases[-1]}")
+            del bufs, qs, ks, base
+            torch.cuda.empty_cache()
     # CPU baselines (fp32, q only): the reference's two CPU implementations, restated under oracle/
     from oracle import rope_torch_ref
     from tests import util
@@ -489,16 +529,29 @@ def rope_bench(args, dev) -> dict:
         log(f"rope2d cpu {cpu[-1]}")
     head = cases[0]
     worst = min(cases, key=lambda c: c["frac"])
+    traffic = None
+    prof = ROOT / "profiles" / "pmc_summary_rope.json"
+    if prof.exists():
+        try:
+            traffic = json.loads(prof.read_text())["spf_rope2d_vec_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
     return {"metric": "RoPE-2D in place, GB/s of algorithmic bytes (fp32 q at (48,256,16,64))", "value": head["GBs"],
             "unit": "GB/s", "higher_is_better": True, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(head["us"] / 1e3, 6), "scaling": "weak", "vs_baseline": None, "dtype": "f32 / f16",
             "data": "synthetic",
             "config": {"workload": "rope2d: curope.rope_2d on strided q (and q + k) views of a [B,N,3,H,D] qkv buffer, "
                                    "(B,N,H,D) = (48,256,16,64) and (32,258,12,64), float32 and float16, positions 0..17",
-                       "launch": f"{calls} dependent calls per HIP graph, replayed; HIP events around the replays"},
+                       "launch": f"one call per buffer of a rotation over {head['buffers_in_rotation']}+ distinct qkv buffers "
+                                 "(> 512 MiB of q rows between two visits of a buffer: cold lines, as the reference's 36 "
+                                 "attention blocks see them) in one HIP graph, replayed; HIP events around the replays"},
             "roofline": {"bound": "hbm", "kernel": "spf_rope2d_vec_kernel", "achieved": head["GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": head["frac"], "traffic": None, "launch_ms": round(head["us"] / 1e3, 6),
+                         "unit": "GB/s", "frac": head["frac"], "traffic": traffic, "launch_ms": round(head["us"] / 1e3, 6),
                          "algorithmic_bytes_per_launch": head["algorithmic_bytes"],
+                         "frac_of_copy_ceiling": round(head["GBs"] / HBM_COPY_GBS, 4),
+                         "cache_resident": {"GBs": head["GBs_cache_resident"], "us": head["us_cache_resident"],
+                                            "note": f"{calls} dependent calls on ONE buffer (round 5's method): the working "
+                                                    "set sits in the 256 MiB Infinity Cache -- not an HBM figure"},
                          "worst_case": {k: worst[k] for k in ("shape", "dtype", "tensors", "us", "frac")}},
             "cases": cases,
             "cpu_baseline": {"value": cpu[0]["c_loop"]["GBs"], "unit": "GB/s", "cores": 1, "host_cores": host_cores,
@@ -882,6 +935,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": None if traffic is None else traffic / chunks, "launch_ms": round(dom_ms, 5),
+                         # the same fraction from the COUNTER bytes (FETCH_SIZE doubled + WRITE_SIZE per launch): where the
+                         # kernel moves fewer bytes than SURVEY.md 8(d)'s model charges (REF2V / REF10V: the projection
+                         # backward), this is the smaller, honest figure of what crosses HBM
+                         "frac_by_counters": None if traffic is None else
+                         round(traffic / chunks / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "launches_per_step": chunks,
                          "algorithmic_bytes_per_launch": dom_bytes,
                          "valu": valu_roofline(kernel, dom_ms, default_workload, chunks),

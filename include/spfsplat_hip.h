@@ -207,8 +207,8 @@ int spf_raster_launch_slot_tile(int32_t R, int32_t T, int32_t xcd, int32_t slot)
  * cursors (block b -> shard b % 8; one cursor would be a hot word) and shard i owns the gradient records
  * [i * pair_capacity / 8, (i + 1) * pair_capacity / 8): plan flag 1 is raised when ONE shard outgrows its eighth, so a
  * caller that wants "D <= capacity never fails" sizes pair_capacity (and g->gpair) with headroom for the imbalance of a
- * round-robin deal of blocks -- the Python host passes twice the planned capacity (address space, never touched unless
- * used). */
+ * round-robin deal of blocks -- the Python host passes 1.25 x the planned capacity (the shards are interleaved samples of
+ * the same scenes: they differ by per cents). */
 int spf_raster_pair_shards(int32_t S, int32_t G);
 int spf_raster_max_lds_tiles(void);
 /* Into how many chunks of renders spf_raster_forward_render (backward = 0) / spf_raster_backward (backward = 1) split a

@@ -42,6 +42,21 @@ from .rasterizer import CallRecord, PairBudget, rasterize_batch, render_batch, s
 DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
 
 
+def _auto_plan_from_env() -> Optional[float]:
+    """SPF_AUTO_PLAN: slack factor of the module's own planning (default 1.5; 0 / empty: off).  A typo is an error that
+    names the variable, not a bare float() failure inside a constructor."""
+    raw = os.environ.get("SPF_AUTO_PLAN", "1.5").strip()
+    if not raw:
+        return None
+    try:
+        v = float(raw)
+    except ValueError:
+        raise ValueError(f"SPF_AUTO_PLAN={raw!r} is not a number (slack factor >= 1, or 0 for off)") from None
+    if v != 0 and not v >= 1.0:
+        raise ValueError(f"SPF_AUTO_PLAN={raw!r}: the slack factor must be >= 1 (or 0 for off)")
+    return v or None
+
+
 @dataclass
 class Gaussians:
     means: Tensor        # [b, g, 3]
@@ -249,7 +264,7 @@ class _EvalGraph:
     """One captured evaluation call of a decoder: the graph, the tensors it writes (colour and depth packed into one
     flat buffer, alpha, radii -- owned by the graph's memory pool) and the call record whose `counters` it
     refreshes."""
-    __slots__ = ("graph", "outputs", "record", "sizes", "color_shape", "depth_shape")
+    __slots__ = ("graph", "outputs", "record", "sizes", "color_shape", "depth_shape", "nbytes")
 
     def __init__(self, graph, outputs, record):
         self.graph, self.outputs, self.record = graph, outputs, record
@@ -310,8 +325,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # verdict is copied to pinned memory behind the forward and read at the NEXT call (an event long past by then);
         # if the plan had failed, that one step's images and gradients were all NaN -- what the reference's NaN-gradient
         # guard (model_wrapper.py:1117-1151) skips -- and the next call is exact again and re-plans.
-        env_plan = os.environ.get("SPF_AUTO_PLAN", "1.5")
-        self.auto_plan: Optional[float] = (float(env_plan) or None) if env_plan else None
+        self._auto_plan: Optional[float] = None
+        self.auto_plan = _auto_plan_from_env()
         self.auto_plan_defer = os.environ.get("SPF_AUTO_PLAN_DEFER", "0") == "1"
         self._auto_verdict = None        # the one pinned word + event all of them use
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
@@ -320,6 +335,34 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
 
     _EVAL_GRAPH_SLOTS = 4
     _EVAL_GRAPH_MISSES = 8
+    _EVAL_GRAPH_BYTES = 2 << 30      # captured evaluation graphs may pin this much device memory in total
+
+    @property
+    def auto_plan(self) -> Optional[float]:
+        return self._auto_plan
+
+    @auto_plan.setter
+    def auto_plan(self, slack) -> None:
+        """None / 0: the module stops planning for itself -- and drops the plan it made (the next call is exact mode's,
+        not a stale `check="deferred"` plan nobody verifies any more); a slack factor >= 1 otherwise."""
+        if slack is not None and slack != 0 and not (float(slack) >= 1.0):
+            raise ValueError(f"auto_plan is a slack factor >= 1 (or None / 0 for off), got {slack!r}")
+        self._auto_plan = float(slack) if slack else None
+        if not self._auto_plan and getattr(self, "_auto_owned", False):
+            self._max_pairs, self._auto_owned, self._auto_key, self._auto_pending = None, False, None, None
+            self._auto_plans.clear()
+
+    # a decoder is copied (EMA: copy.deepcopy(model)) and pickled (torch.save(model)) like any module -- both go through
+    # __getstate__: captured graphs, events and pinned words stay with the original
+    _TRANSIENT = ("_graphs", "_graph_seen", "_auto_verdict", "_auto_pending", "_train_graphs")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._TRANSIENT:
+            if k in state:
+                state[k] = {} if isinstance(state[k], dict) else None
+        state["last_call"] = CallRecord()
+        return state
 
     @property
     def max_pairs(self):
@@ -393,18 +436,21 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         run = lambda: self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
         shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(gaussians.harmonics.shape),
                  tuple(image_shape))
-        if shape != self._auto_key:
-            # (a loop may alternate between a few shapes -- training and validation views, test_step's one-view calls:
-            #  every shape keeps its plan)
-            self._stash_auto()
-            self._auto_key, self._auto_pending = shape, None
-            self._set_auto(self._auto_plans.get(shape))
-        elif self._auto_pending is not None:
+        if self._auto_pending is not None:
+            # (deferred mode) the last training step's verdict, an event long past: a failed plan is neither used again
+            # nor remembered for its shape
             verdict, event = self._auto_pending
             self._auto_pending = None
             event.synchronize()
             if int(verdict[0]) != 0:
-                self._set_auto(None)                     # (deferred mode) the last training step's plan failed: exact again
+                self._set_auto(None)
+                self._auto_plans.pop(self._auto_key, None)
+        if shape != self._auto_key:
+            # (a loop may alternate between a few shapes -- training and validation views, test_step's one-view calls:
+            #  every shape keeps its plan)
+            self._stash_auto()
+            self._auto_key = shape
+            self._set_auto(self._auto_plans.get(shape))
         trains = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
         planned = self._max_pairs is not None
         if planned:      # evaluation: "backward" (the forward / the graph path verifies at once); training: "early" (the
@@ -450,6 +496,11 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                                                                     image_shape, self.max_pairs, self.last_call)
                 return DecoderOutput(color, depth), alpha, radii
             entry = self._capture(key, gaussians, extrinsics, intrinsics, near, far, image_shape)
+            if entry is None:        # the capture failed (another thread's HIP call, out of memory ...): this call eagerly
+                with torch.no_grad():
+                    color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
+                                                                    image_shape, self.max_pairs, self.last_call)
+                return DecoderOutput(color, depth), alpha, radii
         else:
             self._graph_unused = 0
         entry.graph.replay()
@@ -473,12 +524,33 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             return out, None, None
         return out, alpha.clone(), radii.clone()
 
-    def _capture(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "_EvalGraph":
-        while len(self._graphs) >= self._EVAL_GRAPH_SLOTS:
+    def _capture(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "Optional[_EvalGraph]":
+        """Capture this evaluation call.  None when the capture failed: the key is forgotten, the cache is switched off
+        for this decoder (`eval_graphs = False`: a val / test loop that worked before keeps working, kernel by kernel)
+        and the caller renders eagerly."""
+        while len(self._graphs) >= self._EVAL_GRAPH_SLOTS or \
+                (self._graphs and sum(e.nbytes for e in self._graphs.values()) > self._EVAL_GRAPH_BYTES):
             self._graphs.pop(next(iter(self._graphs)))
+        try:
+            entry = self._capture_unguarded(key, gaussians, extrinsics, intrinsics, near, far, image_shape)
+        except Exception as e:                      # noqa: BLE001
+            import warnings
+            self._graph_seen.pop(key, None)
+            self._graphs.pop(key, None)
+            self.eval_graphs = False
+            warnings.warn(f"spfsplatv2_amd: capturing the evaluation call in a HIP graph failed ({type(e).__name__}: {e}); "
+                          "this decoder launches its evaluation calls kernel by kernel from now on")
+            return None
+        return entry
+
+    def _capture_unguarded(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "_EvalGraph":
         record = CallRecord()
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        dev = extrinsics.device
+        before = torch.cuda.memory_allocated(dev)
+        # (thread_local: a capture-unsafe HIP call of ANOTHER host thread -- a DataLoader's pin_memory thread, another
+        #  rank's thread -- does not invalidate this capture)
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             color, depth4, alpha, radii = render_views(
                 extrinsics, intrinsics, near, far, image_shape, self.background_color,
                 gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
@@ -497,6 +569,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             else:
                 flat = torch.cat((color.reshape(-1), depth.reshape(-1)))
         entry = _EvalGraph(graph, (flat, alpha, radii), record)
+        entry.nbytes = max(torch.cuda.memory_allocated(dev) - before, 0)     # what the graph's private pool pins
         entry.sizes = [color.numel(), depth.numel()]
         entry.color_shape, entry.depth_shape = tuple(color.shape), tuple(depth.shape)
         self._graphs[key] = entry

@@ -375,11 +375,14 @@ def _record_capacity(capacity: int, S: int, G: int) -> int:
     """Gradient records (`gpair`) of a direct-bins call.  The projection kernel numbers the (Gaussian, tile) pairs from
     up to eight sharded cursors (block b -> shard b % 8; one cursor would be a hot word), each shard owning an eighth of
     the records, and raises plan flag 1 when ONE shard outgrows its share -- so with the plan's bare capacity a call
-    whose pairs fit in total could fail on the imbalance of the deal.  Twice the planned capacity: every
-    shard may hold double its fair share before anything is flagged, i.e. `D <= capacity` keeps meaning "fits" for any
-    deal that is not adversarial.  The extra records are address space only (never written unless used)."""
+    whose pairs fit in total could fail on the imbalance of the deal.  Shard b % 8 takes every eighth block of
+    256 consecutive Gaussians of EVERY scene, i.e. eight interleaved samples of the same scenes: their pair counts differ
+    by a few per cent, not by factors, so each shard gets a quarter more than its fair share on top of the plan's own slack
+    (round 5 gave 2x: with the module's default slack of 1.5 that was 3x exact mode's records, 40 bytes each, committed
+    by the allocator in every backward -- ADVICE r5).  A deal that is more lopsided raises flag 1 like any plan that does
+    not hold: exact re-run and a new plan (module), or the caller's larger capacity."""
     shards = _lib.load().spf_raster_pair_shards(S, G)
-    return int(capacity) * (2 if shards > 1 else 1)
+    return int(capacity) + (int(capacity) // 4 if shards > 1 else 0)
 
 
 def _plan_numbers(max_pairs, RT: int):

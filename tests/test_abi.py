@@ -143,14 +143,14 @@ def test_compiled_host_binding_loads_and_can_be_switched_off(hip_lib, monkeypatc
 
 def test_direct_bins_planning_helpers(hip_lib):
     """Host-side planning of a direct-bins call (no GPU): the pair numbering is sharded from 512 blocks on, the host
-    then doubles the gradient-record capacity (each shard owns an eighth: ADVICE r4), and the bins stay in proportion to
+    then adds a quarter to the gradient-record capacity (each shard owns an eighth: ADVICE r4, r5), and the bins stay in proportion to
     the plan -- BASELINE config 3 (2,048 tiles, lists of ~1,700 -> 4,096-entry bins) keeps them, a 16,384-entry class on
     8,192 tiles (1 GiB of keys) falls back to the classic chain."""
     from spfsplatv2_amd import rasterizer as rz
     assert hip_lib.spf_raster_pair_shards(1, 256 * 511) == 1 and hip_lib.spf_raster_pair_shards(1, 256 * 512) == 8
     assert hip_lib.spf_raster_pair_shards(8, 65536) == 8 and hip_lib.spf_raster_pair_shards(2, 3000) == 1
     assert hip_lib.spf_raster_max_lds_tiles() == 4096
-    assert rz._record_capacity(1000, 2, 3000) == 1000 and rz._record_capacity(1000, 8, 65536) == 2000
+    assert rz._record_capacity(1000, 2, 3000) == 1000 and rz._record_capacity(1000, 8, 65536) == 1250
     c3 = rz.plan_pair_budget(dict(num_pairs=2_170_000, max_tile_list=1700, dense_tiles=0, tiles=2048))
     assert c3.max_tile_list == 4096 and rz._direct_bin_cap(c3, 2048, 256) == 4096
     c2 = rz.plan_pair_budget(dict(num_pairs=2_250_000, max_tile_list=505, dense_tiles=0, tiles=8192))

@@ -194,9 +194,43 @@ def test_auto_plan_environment_switches(monkeypatch):
     for env, want in (("0", None), ("", None), ("2", 2.0), ("1.25", 1.25)):
         monkeypatch.setenv("SPF_AUTO_PLAN", env)
         assert dec.get_decoder(cfg).auto_plan == want, env
+    for bad in ("fast", "0.5", "-1"):                       # a typo names the variable; a slack below 1 is refused
+        monkeypatch.setenv("SPF_AUTO_PLAN", bad)
+        with pytest.raises(ValueError, match="SPF_AUTO_PLAN"):
+            dec.get_decoder(cfg)
     monkeypatch.delenv("SPF_AUTO_PLAN")
     monkeypatch.setenv("SPF_AUTO_PLAN_DEFER", "1")
     assert dec.get_decoder(cfg).auto_plan_defer and dec.get_decoder(cfg).auto_plan == 1.5
+
+
+def test_switching_auto_plan_off_drops_the_modules_own_plan():
+    """`auto_plan = None` on a live decoder returns to EXACT mode -- the plan the module made for itself (and
+    the per-shape stash) goes with the switch, a plan the CALLER set stays; copies and pickles of a decoder carry no
+    graphs, events or pinned words."""
+    import copy
+    import pickle
+    from spfsplatv2_amd import PairBudget, decoder as dec
+    cfg = dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
+                                      make_scale_invariant=True, enable_cov_grad=True, enable_sh_grad=True)
+    d = dec.get_decoder(cfg)
+    d._auto_key = ("shape",)
+    d._set_auto(PairBudget(1000, 512, "deferred"))
+    d._stash_auto()
+    d.auto_plan = None
+    assert d.max_pairs is None and not d._auto_owned and not d._auto_plans and d._auto_key is None
+    mine = PairBudget(2000, 1024, "deferred")
+    d.max_pairs = mine
+    d.auto_plan = 0
+    assert d.max_pairs is mine and d.auto_plan is None
+    with pytest.raises(ValueError):
+        d.auto_plan = 0.9
+    d.auto_plan = 1.5
+    d._graphs["k"] = object()                                # (stand-ins for a captured graph / a pinned word + event)
+    d._auto_verdict = (object(), object())
+    for clone in (copy.deepcopy(d), pickle.loads(pickle.dumps(d))):
+        assert clone._graphs == {} and clone._auto_verdict is None and clone.auto_plan == 1.5
+        assert clone.max_pairs == mine and torch.equal(clone.background_color, d.background_color)
+    assert "k" in d._graphs
 
 
 @pytest.mark.parametrize("tag", ["decoder_k4_si", "decoder_k25_nosi"])
