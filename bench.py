@@ -184,6 +184,14 @@ def parse_args(argv=None):
                     help="measure the RoPE-2D kernel (curope's rope_2d, SURVEY.md 8a row A9) instead of the decoder step: "
                          "fp32 and fp16 at the reference's encoder / decoder attention shapes (48,256,16,64) and "
                          "(32,258,12,64) on strided q views of a qkv buffer, next to the reference's two CPU paths")
+    ap.add_argument("--sh-split", action="store_true",
+                    help="d_sh = 25 workloads (REF2V / REF10V): the harmonics are resident BAND-SPLIT -- planes [.,3,16] and "
+                         "[.,3,9] (Gaussians.harmonics_band4, SpfDims.sh_layout 2), what the fused adapter writes with "
+                         "split_harmonics=True -- so that the default degree-3 evaluation never moves band 4's bytes")
+    ap.add_argument("--with-adapter", action="store_true",
+                    help="the step starts at the network's RAW channels: UnifiedGaussianAdapter.forward (fused HIP pre-pass, "
+                         "gaussian_adapter.py:122-150) -> decoder -> MSE -> backward through the adapter to dL/draw: the "
+                         "producer of the harmonics layout is inside the timed step (with --sh-split it writes the split)")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -241,6 +249,13 @@ SECONDARY = (
     ("REF2V", ["--config", "REF2V"], {"SPF_SH_BAND4": "0"}),
     ("REF2V_band4", ["--config", "REF2V"], {"SPF_SH_BAND4": "1"}),
     ("REF10V", ["--config", "REF10V"], {"SPF_SH_BAND4": "0"}),
+    # the same two shapes with the harmonics BAND-SPLIT (what the fused adapter writes on request): decoder-only steps,
+    # comparable with REF2V / REF10V; and with the adapter INSIDE the step, both layouts (the producer's cost in the open)
+    ("REF2V_split", ["--config", "REF2V", "--sh-split"], {"SPF_SH_BAND4": "0"}),
+    ("REF10V_split", ["--config", "REF10V", "--sh-split"], {"SPF_SH_BAND4": "0"}),
+    ("REF2V_adapter", ["--config", "REF2V", "--with-adapter"], {"SPF_SH_BAND4": "0"}),
+    ("REF2V_adapter_split", ["--config", "REF2V", "--with-adapter", "--sh-split"], {"SPF_SH_BAND4": "0"}),
+    ("REF10V_adapter_split", ["--config", "REF10V", "--with-adapter", "--sh-split"], {"SPF_SH_BAND4": "0"}),
     ("C2_stress", ["--config", "C2", "--s-mult", "10"], {}),     # SURVEY.md 8(d)'s stress regime: footprints x 10, dense tiles
     ("C2_module", ["--config", "C2", "--api", "module"], {}),    # an UNCHANGED caller: DecoderSplattingCUDA.forward, nothing configured
     ("C2_streams2", ["--config", "C2", "--streams", "2"], {}),
@@ -623,6 +638,19 @@ def main():
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
     bg = torch.zeros(3, device=dev)
+    if (args.sh_split or args.with_adapter) and (K != 25 or args.allreduce or args.api == "per-view"):
+        sys.exit("bench.py: --sh-split / --with-adapter are for the d_sh = 25 workloads (REF2V, REF10V), batched or module api")
+    adapter_mod = raw_all = None
+    if args.with_adapter:
+        # raw network channels that the adapter maps back onto the resident batch (same scales -> same pairs -> the same
+        # decoder workload as the plain config): softplus^-1 of the scales, the unit quaternions, harmonics / sh_mask
+        from spfsplatv2_amd import adapter as _ad
+        adapter_mod = _ad.UnifiedGaussianAdapter(_ad.GaussianAdapterCfg(0.5, 15.0, 4), split_harmonics=args.sh_split).to(dev)
+        y = (b.scales.double() / 0.001).clamp_min(1e-12)
+        raw_scales = torch.where(y > 20.0, y, torch.log(torch.expm1(y.clamp_max(20.0)))).float()
+        raw_all = torch.cat((raw_scales, b.rotations,
+                             (b.harmonics / adapter_mod.sh_mask.to(dev)).reshape(*b.harmonics.shape[:2], 75)), dim=-1)
+        names = ("means", "opacities", "extrinsics", "raw")
     if args.streams > 1:
         if S % args.streams or args.allreduce:
             sys.exit("bench.py: --streams N needs a scene count divisible by N (and is not combined with --allreduce)")
@@ -645,7 +673,11 @@ def main():
 
         def __init__(self, s0, s1):
             self.sl = slice(s0, s1)
-            self.leaves = {n: getattr(b, n)[self.sl].clone().requires_grad_(True) for n in names}
+            self.leaves = {n: (raw_all if n == "raw" else getattr(b, n))[self.sl].clone().requires_grad_(True) for n in names}
+            if args.sh_split and not args.with_adapter:
+                full = self.leaves["harmonics"].detach()
+                self.leaves["harmonics"] = full[..., :16].contiguous().requires_grad_(True)
+                self.leaves["harmonics_band4"] = full[..., 16:].contiguous().requires_grad_(True)
             self.weight = (s1 - s0) / S
             self.record = spf.CallRecord()
             self.max_pairs = None
@@ -706,6 +738,10 @@ def main():
                 loss = spf.mse_loss(color, b.target[sl], self.weight)
                 loss.backward(gradient=spf.unit_grad(dev))
                 return loss
+            if args.with_adapter:
+                ga = adapter_mod(L["means"], L["opacities"], L["raw"], with_covariances=False)
+                L = dict(L, scales=ga.scales, rotations=ga.rotations, harmonics=ga.harmonics,
+                         harmonics_band4=ga.harmonics_band4)
             if args.api == "module":
                 from spfsplatv2_amd import decoder as dec
                 if self.decoder is None:
@@ -715,7 +751,7 @@ def main():
                     if args.exact:
                         self.decoder.auto_plan = None
                 out = self.decoder.forward(dec.Gaussians(L["means"], None, L["rotations"], L["scales"], L["harmonics"],
-                                                         L["opacities"]),
+                                                         L["opacities"], harmonics_band4=L.get("harmonics_band4")),
                                            L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w))
                 color = out.color
                 if "num_pairs" not in self.record:                  # (the first call of a shape is exact: statistics)
@@ -724,7 +760,8 @@ def main():
                 color, depth, _alpha = spf.render_views(
                     L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
                     L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
-                    enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record)
+                    enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record,
+                    gaussian_sh_band4=L.get("harmonics_band4"))
             if args.torch_loss:
                 loss = torch.nn.functional.mse_loss(color, b.target[sl]) * self.weight
             else:
@@ -879,14 +916,17 @@ def main():
         chunks = lib_.spf_raster_chunks(S // len(micro), V, h, w, chunk_stages[dom]) if dom in chunk_stages else 1
         dom_ms = (stages[dom][0] / stages[dom][1]) if stages[dom][1] else survey[dom][0] / survey[dom][1] / chunks
         # (with --streams the surveyed launch is one micro-batch's: its share of the scenes and pairs)
-        dom_bytes = stage_bytes(dom, S // len(micro), V, G, K, P, D_total // len(micro)) / chunks
+        # band-split harmonics evaluated to degree 3: the algorithm needs (and the kernels move) 16 of the 25 coefficients
+        K_model = 16 if (args.sh_split and os.environ.get("SPF_SH_BAND4", "0") != "1") else K
+        dom_bytes = stage_bytes(dom, S // len(micro), V, G, K_model, P, D_total // len(micro)) / chunks
         if args.api == "per-view":          # one launch per render
-            dom_bytes = stage_bytes(dom, 1, 1, G, K, P, D_total // (S * V))
+            dom_bytes = stage_bytes(dom, 1, 1, G, K_model, P, D_total // (S * V))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         # the counter passes under profiles/ (tools/refresh_profiles.sh) were collected per config on its default batch
         default_workload = args.config if ((S, V) == WORKLOADS[args.config] and args.s_mult == 1.0 and
-                                           not args.allreduce and len(micro) == 1 and args.api == "batched") else None
+                                           not args.allreduce and len(micro) == 1 and args.api == "batched" and
+                                           not args.sh_split and not args.with_adapter) else None
         prof = ROOT / "profiles" / f"pmc_summary_{args.config}.json"
         kernel = _lib.stage_kernel_name(dom)
         if prof.exists() and default_workload:      # the PMC passes were collected on exactly this workload
@@ -894,7 +934,9 @@ def main():
                 traffic = json.loads(prof.read_text()).get(kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        A = total_bytes(S, V, G, K, P, D_total)
+        A = total_bytes(S, V, G, K_model, P, D_total)
+        if args.with_adapter:       # + the adapter, both directions: raw in / parameters out, gradients in / dL/draw out
+            A += 2.0 * S * G * (2 * (7 + 3 * K) * 4 - (0 if K_model == K else 4 * 3 * (K - K_model)))
         deg = int(K ** 0.5) - 1
         out = {
             "metric": "Mpixels/s fwd+bwd, 256x256 @ ~65k Gaussians" if args.config == "C2" else
@@ -904,7 +946,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, {K} SH coefficient(s) per "
                                    f"channel (sh_degree {deg}), {h}x{w}, {S} scenes x {V} views per GPU per step, "
-                                   "decoder fwd + MSE + bwd to all Gaussian parameters and poses",
+                                   + ("fused Gaussian adapter (raw network channels in) + " if args.with_adapter else "")
+                                   + "decoder fwd + MSE + bwd to all Gaussian parameters and poses"
+                                   + (" and through the adapter to the raw channels" if args.with_adapter else "")
+                                   + ("; harmonics band-split [.,3,16] | [.,3,9] (sh_layout 2)" if args.sh_split else ""),
                        "loss": "torch.nn.functional.mse_loss" if args.torch_loss else "spfsplatv2_amd.mse_loss (fused HIP)",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),

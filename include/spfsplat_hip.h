@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SPF_ABI_VERSION 5
+#define SPF_ABI_VERSION 6
 
 #define SPF_OK 0
 #define SPF_E_INVALID (-1)   /* bad argument (null pointer, size, unsupported degree ...) */
@@ -62,7 +62,13 @@ typedef struct SpfDims {
     int32_t S, V, G, K, sh_degree, H, W;
     float scale_modifier;
     int32_t sh_layout;   /* 0: shs / dL_dshs are [S,G,K,3] (what the reference hands its rasterizer,
-                            cuda_splatting.py:79); 1: [S,G,3,K] (the encoder's native layout: no transposed copy) */
+                            cuda_splatting.py:79); 1: [S,G,3,K] (the encoder's native layout: no transposed copy);
+                            2 ("band split", K = 25 only): TWO planes, shs / dL_dshs = [S,G,3,16] (bands 0 - 3) and
+                            shs_high / dL_dshs_high = [S,G,3,9] (band 4) -- what spf_adapter_forward writes when it is given
+                            a second plane.  The reference ships d_sh = 25 (config/model/encoder/spfsplatv2.yaml:20) and
+                            a degree-3 evaluation (sh_band4 = 0) then touches plane 0 only: the band-4 third of every
+                            coefficient block neither crosses HBM in the forward nor is zero-written in the backward
+                            (in one [3,25] block it shares cache lines with the bands that are read) */
     int32_t sh_band4;    /* 0 (default): the reference's d_sh = 25 / sh_degree 4 (config/model/encoder/spfsplatv2.yaml:20,
                             cuda_splatting.py:77-78,114) is accepted as a stride and evaluated to degree 3 like the
                             published 3DGS kernels; 1: band 4 (coefficients 16..24) is evaluated too, forward and
@@ -86,7 +92,7 @@ typedef struct SpfInputs {
     const float* scales;     /* [S,G,3] */
     const float* rotations;  /* [S,G,4] quaternion (r,x,y,z), used as given (not normalised) */
     const float* opacities;  /* [S,G]   */
-    const float* shs;        /* [S,G,K,3] ([S,G,3,K] with sh_layout 1) or NULL when colors is set */
+    const float* shs;        /* [S,G,K,3] ([S,G,3,K] with sh_layout 1; [S,G,3,16] with sh_layout 2) or NULL when colors is set */
     const float* colors;     /* [S,G,3]  or NULL when shs is set (colors_precomp) */
     const float* viewmatrix; /* [S,V,4,4] world->view, row-vector convention (p_view = [p,1] @ M) */
     const float* projmatrix; /* [S,V,4,4] perspective only, row-vector convention */
@@ -102,6 +108,7 @@ typedef struct SpfInputs {
                                 camera (after the 1/near rescale |t| is tens of units while z may be 0.2): the
                                 projection kernels form it in float64 -- from this matrix when given, else from the
                                 float32 one promoted -- and round once.  Everything else stays float32. */
+    const float* shs_high;   /* sh_layout 2 only: [S,G,3,9], band 4; read only when sh_band4 is set (may be NULL otherwise) */
 } SpfInputs;
 
 /* State written by the forward pass and read by the backward pass (owned by the caller, e.g. the
@@ -172,6 +179,8 @@ typedef struct SpfGrads {
     float* dL_dcolors;        /* [S,G,3]   */
     float* dL_dviewmatrix;    /* [S,V,4,4] */
     float* dL_dmeans2D;       /* [R,G,3]   NDC-scaled screen-space gradient (xy, 0) */
+    float* dL_dshs_high;      /* sh_layout 2 with sh_band4 only: [S,G,3,9] (otherwise never touched, may be NULL: the
+                                 gradient of band 4 is zero and its consumer, spf_adapter_backward, takes NULL for that) */
 } SpfGrads;
 
 /* Camera set-up for R = S*V renders (all float32, contiguous). */
@@ -269,13 +278,18 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
                         const SpfGrads* g, uint64_t capacity, uint32_t dense_tiles_hint, void* stream);
 
 /* Fused Gaussian adapter (UnifiedGaussianAdapter.forward, src/model/encoder/common/gaussian_adapter.py:122-150):
- * raw[N, 7+3K] network channels -> scales[N,3] = min(0.001*softplus, 0.3), rotations[N,4] = q/(|q|+eps),
- * harmonics[N,3,K] = raw[7:] * sh_mask[K]; and its backward (any upstream gradient may be NULL = zero). */
-int spf_adapter_forward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps, float* scales,
-                        float* rotations, float* harmonics, void* stream);
-int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps,
+ * raw[N, 7+3K] network channels (row stride `raw_stride` floats >= 7+3K: the encoder hands over `gaussians[..., 1:]`, a view
+ * of its 83-channel head output, encoder_spfsplatv2.py:261-268 -- read in place, no contiguous copy) ->
+ * scales[N,3] = min(0.001*softplus, 0.3), rotations[N,4] = q/(|q|+eps), harmonics[N,3,K] = raw[7:] * sh_mask[K];
+ * with harmonics_high != NULL (K = 25): the band-split layout, harmonics = [N,3,16] and harmonics_high = [N,3,9]
+ * (SpfDims.sh_layout 2).  One pass: every raw row is read once, through LDS, and every output is written coalesced.
+ * Backward: dL_draw[N, 7+3K] (contiguous); any upstream gradient may be NULL = zero; `split` says dL_dharmonics is
+ * [N,3,16] with band 4's gradient in dL_dharmonics_high [N,3,9] -- or NULL, which is never read and costs nothing. */
+int spf_adapter_forward(const float* raw, int64_t raw_stride, int64_t N, int32_t K, const float* sh_mask, float eps,
+                        float* scales, float* rotations, float* harmonics, float* harmonics_high, void* stream);
+int spf_adapter_backward(const float* raw, int64_t raw_stride, int64_t N, int32_t K, const float* sh_mask, float eps,
                          const float* dL_dscales, const float* dL_drotations, const float* dL_dharmonics,
-                         float* dL_draw, void* stream);
+                         const float* dL_dharmonics_high, int32_t split, float* dL_draw, void* stream);
 
 /* Photometric MSE on the decoder output (LossMse.forward, src/loss/loss_mse.py:36-51):
  * loss[0] = weight * mean((prediction - image)^2) over n floats, and its backward

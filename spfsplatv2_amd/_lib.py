@@ -12,7 +12,7 @@ from pathlib import Path
 
 # SPF_LIB_DIR: development only -- a profiling/experimental build kept next to the regular one (see build.py)
 LIB_PATH = Path(__file__).resolve().parent / os.environ.get("SPF_LIB_DIR", "_C") / "libspfsplat_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 STAGE_NAMES = ("project_fwd", "tile_scan", "bin_pairs", "tile_sort", "render_fwd", "render_bwd",
                "project_bwd", "rope2d")
@@ -31,14 +31,15 @@ def _ptr_struct(name, fields):
 
 
 SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
-                                      "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64"])
+                                      "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64",
+                                      "shs_high"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
                                     "n_contrib", "pair_cursor", "sh_clamp"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
 SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",
-                                    "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D"])
+                                    "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D", "dL_dshs_high"])
 
 
 
@@ -76,10 +77,10 @@ SYMBOLS = {
     "spf_mse_forward_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "spf_mse_scale_grad": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
-    "spf_adapter_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p]),
-    "spf_adapter_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spf_adapter_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spf_adapter_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "spf_rope2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                              C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float,
                              C.c_void_p]),

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
+from typing import Optional
 
 import torch
 from torch import Tensor, nn
@@ -22,6 +23,7 @@ class Gaussians:                       # field order of the adapter's own datacl
     rotations: Tensor
     harmonics: Tensor
     opacities: Tensor
+    harmonics_band4: Optional[Tensor] = None    # band-split harmonics: see decoder.Gaussians.harmonics_band4
 
 
 @dataclass
@@ -35,47 +37,83 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _rows(raw: Tensor, d_in: int) -> Tensor:
+    """`raw` as [N, d_in] rows the kernel can read IN PLACE: unit stride along the channels, ONE row stride over all the
+    leading dimensions.  The encoder hands over `gaussians[..., 1:]`, a view into its 83-channel head output
+    (encoder_spfsplatv2.py:261-268): that qualifies -- no contiguous copy, 328 bytes per Gaussian read and written less.
+    Anything else (a permuted tensor, another dtype) is copied once, as before."""
+    if raw.dtype == torch.float32 and raw.stride(-1) == 1:
+        rs, span, ok = None, None, True
+        for size, stride in zip(reversed(raw.shape[:-1]), reversed(raw.stride()[:-1])):
+            if size == 1:
+                continue                       # (unit dimensions -- "b v r srf () c" -- carry no stride of their own)
+            if rs is None:
+                rs = span = stride
+                ok = rs >= d_in
+            elif stride != span:
+                ok = False
+            if not ok:
+                break
+            span *= size
+        if ok:
+            n = raw.numel() // d_in
+            return raw.as_strided((n, d_in), (d_in if rs is None else rs, 1), raw.storage_offset())
+    return raw.reshape(-1, d_in).contiguous().float()
+
+
 class _AdapterFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, mask, eps):
+    def forward(ctx, raw, mask, eps, split):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         N, Cn = raw.shape
         K = (Cn - 7) // 3
-        scales = torch.empty((N, 3), dtype=torch.float32, device=raw.device)
-        rot = torch.empty((N, 4), dtype=torch.float32, device=raw.device)
-        sh = torch.empty((N, 3, K), dtype=torch.float32, device=raw.device)
+        f32 = dict(dtype=torch.float32, device=raw.device)
+        scales = torch.empty((N, 3), **f32)
+        rot = torch.empty((N, 4), **f32)
+        sh = torch.empty((N, 3, 16 if split else K), **f32)
+        sh_hi = torch.empty((N, 3, 9), **f32) if split else None
         with torch.cuda.device(raw.device):
-            _lib.check(lib.spf_adapter_forward(_p(raw), N, K, _p(mask), float(eps), _p(scales), _p(rot), _p(sh),
+            _lib.check(lib.spf_adapter_forward(_p(raw), raw.stride(0), N, K, _p(mask), float(eps), _p(scales), _p(rot),
+                                               _p(sh), _p(sh_hi),
                                                C.c_void_p(torch.cuda.current_stream(raw.device).cuda_stream)),
                        "spf_adapter_forward")
         ctx.save_for_backward(raw, mask)
-        ctx.eps = float(eps)
-        return scales, rot, sh
+        ctx.eps, ctx.split = float(eps), bool(split)
+        return (scales, rot, sh, sh_hi) if split else (scales, rot, sh)
 
     @staticmethod
-    def backward(ctx, g_scales, g_rot, g_sh):
+    def backward(ctx, g_scales, g_rot, g_sh, g_sh_hi=None):
         lib = _lib.load()
         raw, mask = ctx.saved_tensors
         N, Cn = raw.shape
         K = (Cn - 7) // 3
         c = lambda g: None if g is None else g.contiguous().float()
-        g_scales, g_rot, g_sh = c(g_scales), c(g_rot), c(g_sh)
-        g_raw = torch.empty_like(raw)
+        # (band split: a decoder that evaluates to degree 3 hands back NO gradient for the band-4 plane -- None here --
+        #  and the kernel then writes zeros for those channels without reading anything)
+        g_scales, g_rot, g_sh, g_sh_hi = c(g_scales), c(g_rot), c(g_sh), c(g_sh_hi)
+        g_raw = torch.empty((N, Cn), dtype=torch.float32, device=raw.device)
         with torch.cuda.device(raw.device):
-            _lib.check(lib.spf_adapter_backward(_p(raw), N, K, _p(mask), ctx.eps, _p(g_scales), _p(g_rot), _p(g_sh),
-                                                _p(g_raw),
+            _lib.check(lib.spf_adapter_backward(_p(raw), raw.stride(0), N, K, _p(mask), ctx.eps, _p(g_scales), _p(g_rot),
+                                                _p(g_sh), _p(g_sh_hi), 1 if ctx.split else 0, _p(g_raw),
                                                 C.c_void_p(torch.cuda.current_stream(raw.device).cuda_stream)),
                        "spf_adapter_backward")
-        return g_raw, None, None
+        return g_raw, None, None, None
 
 
 class UnifiedGaussianAdapter(nn.Module):
     """``forward(means, opacities, raw_gaussians, eps=1e-8) -> Gaussians`` with the reference's semantics."""
 
-    def __init__(self, cfg: GaussianAdapterCfg):
+    def __init__(self, cfg: GaussianAdapterCfg, split_harmonics: bool = False):
+        """``split_harmonics`` (d_sh = 25 only; not an argument of the reference's class): write the harmonics BAND-SPLIT,
+        ``Gaussians.harmonics`` = bands 0 - 3 [.., 3, 16] and ``Gaussians.harmonics_band4`` = band 4 [.., 3, 9] -- the
+        layout in which the decoder's default evaluation depth (degree 3) leaves band 4's third of every
+        coefficient block in HBM, forward and backward (SpfDims.sh_layout 2)."""
         super().__init__()
         self.cfg = cfg
+        if split_harmonics and cfg.sh_degree != 4:
+            raise ValueError("split_harmonics is the 16 + 9 split of sh_degree 4 (d_sh = 25)")
+        self.split_harmonics = bool(split_harmonics)
         mask = torch.ones((self.d_sh,), dtype=torch.float32)
         for degree in range(1, cfg.sh_degree + 1):
             mask[degree ** 2:(degree + 1) ** 2] = 0.1 * 0.25 ** degree
@@ -100,14 +138,20 @@ class UnifiedGaussianAdapter(nn.Module):
         if not raw_gaussians.is_cuda:
             raise RuntimeError("UnifiedGaussianAdapter: tensors are on the CPU; this build only runs on a HIP device")
         batch = raw_gaussians.shape[:-1]
-        raw = raw_gaussians.reshape(-1, self.d_in).contiguous().float()
-        scales, rot, sh = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps)
+        raw = _rows(raw_gaussians, self.d_in)
+        sh_hi = None
+        if self.split_harmonics:
+            scales, rot, sh, sh_hi = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, True)
+            sh_hi = sh_hi.reshape(*batch, 3, 9).broadcast_to((*opacities.shape, 3, 9))
+        else:
+            scales, rot, sh = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, False)
         scales, rot = scales.reshape(*batch, 3), rot.reshape(*batch, 4)
-        sh = sh.reshape(*batch, 3, self.d_sh).broadcast_to((*opacities.shape, 3, self.d_sh))
+        sh = sh.reshape(*batch, 3, sh.shape[-1]).broadcast_to((*opacities.shape, 3, sh.shape[-1]))
         if with_covariances:
             from .adapter_cov import build_covariance
             cov = build_covariance(scales, rot)
         else:
             cov = torch.full((), float("nan"), dtype=torch.float32, device=raw.device).expand(*batch, 3, 3)
         return Gaussians(means=means, covariances=cov, scales=scales,
-                         rotations=rot.broadcast_to((*scales.shape[:-1], 4)), harmonics=sh, opacities=opacities)
+                         rotations=rot.broadcast_to((*scales.shape[:-1], 4)), harmonics=sh, opacities=opacities,
+                         harmonics_band4=sh_hi)

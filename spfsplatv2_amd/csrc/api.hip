@@ -18,9 +18,10 @@ hipError_t launch_render_fwd(const SpfDims&, const SpfInputs&, const SpfState&, 
                              bool, hipStream_t);
 hipError_t launch_render_bwd(const SpfDims&, const SpfInputs&, const SpfState&, const SpfGrads&, int, int, uint64_t, bool,
                              hipStream_t);
-hipError_t launch_adapter_fwd(const float*, int64_t, int, const float*, float, float*, float*, float*, hipStream_t);
-hipError_t launch_adapter_bwd(const float*, int64_t, int, const float*, float, const float*, const float*, const float*,
-                              float*, hipStream_t);
+hipError_t launch_adapter_fwd(const float*, int64_t, int64_t, int, const float*, float, float*, float*, float*, float*,
+                              hipStream_t);
+hipError_t launch_adapter_bwd(const float*, int64_t, int64_t, int, const float*, float, const float*, const float*,
+                              const float*, const float*, int, float*, hipStream_t);
 int mse_partial_blocks();
 hipError_t launch_mse_fwd(const float*, const float*, int64_t, float, float*, float*, float, float*, hipStream_t);
 hipError_t launch_mse_scale(float*, int64_t, const float*, hipStream_t);
@@ -165,7 +166,8 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
         const size_t sg = (size_t)scene0 * G;
         c.in.means3D = off(in.means3D, 3 * sg); c.in.scales = off(in.scales, 3 * sg);
         c.in.rotations = off(in.rotations, 4 * sg); c.in.opacities = off(in.opacities, sg);
-        c.in.shs = off(in.shs, 3 * sg * (size_t)d.K); c.in.colors = off(in.colors, 3 * sg);
+        c.in.shs = off(in.shs, 3 * sg * (size_t)(d.sh_layout == 2 ? 16 : d.K)); c.in.colors = off(in.colors, 3 * sg);
+        c.in.shs_high = off(in.shs_high, 3 * sg * 9);
     }
     c.st = st;
     c.st.rec = off(st.rec, r * G * spf::kRec); c.st.radii = off(st.radii, r * G); c.st.rect = off(st.rect, r * G);
@@ -191,7 +193,8 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
             const size_t sg = (size_t)scene0 * G;
             c.g.dL_dmeans3D = off(g->dL_dmeans3D, 3 * sg); c.g.dL_dscales = off(g->dL_dscales, 3 * sg);
             c.g.dL_drotations = off(g->dL_drotations, 4 * sg); c.g.dL_dopacities = off(g->dL_dopacities, sg);
-            c.g.dL_dshs = off(g->dL_dshs, 3 * sg * (size_t)d.K); c.g.dL_dcolors = off(g->dL_dcolors, 3 * sg);
+            c.g.dL_dshs = off(g->dL_dshs, 3 * sg * (size_t)(d.sh_layout == 2 ? 16 : d.K)); c.g.dL_dcolors = off(g->dL_dcolors, 3 * sg);
+            c.g.dL_dshs_high = off(g->dL_dshs_high, 3 * sg * 9);
         }
     } else {
         memset(&c.g, 0, sizeof c.g);
@@ -211,7 +214,9 @@ int check_dims(const SpfDims* d) {
     if (d->sh_degree < 0 || d->sh_degree > 4) return fail(SPF_E_INVALID, "sh_degree %d outside 0..4", d->sh_degree);
     if (d->K < 0) return fail(SPF_E_INVALID, "K must be >= 0");
     if (d->sh_band4 != 0 && d->sh_band4 != 1) return fail(SPF_E_INVALID, "sh_band4 must be 0 or 1");
-    if (d->sh_layout != 0 && d->sh_layout != 1) return fail(SPF_E_INVALID, "sh_layout must be 0 or 1");
+    if (d->sh_layout < 0 || d->sh_layout > 2) return fail(SPF_E_INVALID, "sh_layout must be 0, 1 or 2");
+    if (d->sh_layout == 2 && d->K != 25 && d->K != 0)
+        return fail(SPF_E_INVALID, "sh_layout 2 (band split) is the 16 + 9 split of K = 25 coefficients (got K = %d)", d->K);
     if (d->bin_cap < 0) return fail(SPF_E_INVALID, "bin_cap must be >= 0");
     if (d->bin_cap > 0) {
         const int64_t rt = (int64_t)d->S * d->V * spf_raster_num_tiles(d->H, d->W);
@@ -236,6 +241,8 @@ int check_inputs(const SpfDims* d, const SpfInputs* in) {
         const int deg = d->sh_degree > cap ? cap : d->sh_degree;
         if (d->K < (deg + 1) * (deg + 1))
             return fail(SPF_E_INVALID, "K = %d is too small for sh_degree %d", d->K, d->sh_degree);
+        if (d->sh_layout == 2 && deg == 4 && !in->shs_high)
+            return fail(SPF_E_INVALID, "sh_layout 2 with sh_band4: shs_high (band 4) is null");
     }
     return SPF_OK;
 }
@@ -481,6 +488,8 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     if (g->dL_dviewmatrix && !g->vpartial) return fail(SPF_E_INVALID, "vpartial is required with dL_dviewmatrix");
     if ((g->dL_dscales == nullptr) != (g->dL_drotations == nullptr))
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");
+    if (in->shs && d->sh_layout == 2 && d->sh_band4 && d->sh_degree == 4 && g->dL_dshs && !g->dL_dshs_high)
+        return fail(SPF_E_INVALID, "sh_layout 2 with sh_band4: dL_dshs_high is needed next to dL_dshs");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int T = tiles_x * tiles_y;
@@ -518,24 +527,31 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
     return rc;
 }
 
-int spf_adapter_forward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps, float* scales,
-                        float* rotations, float* harmonics, void* stream_) {
+int spf_adapter_forward(const float* raw, int64_t raw_stride, int64_t N, int32_t K, const float* sh_mask, float eps,
+                        float* scales, float* rotations, float* harmonics, float* harmonics_high, void* stream_) {
     if (!raw || !sh_mask || !scales || !rotations || !harmonics) return fail(SPF_E_INVALID, "adapter: null pointer");
-    if (N < 0 || K < 1) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K >= 1");
+    if (N < 0 || K < 1 || K > 64) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K in 1..64");
+    if (raw_stride < 7 + 3 * (int64_t)K) return fail(SPF_E_INVALID, "adapter: raw_stride %lld is below the %d channels of a row", (long long)raw_stride, 7 + 3 * K);
+    if (harmonics_high && K != 25) return fail(SPF_E_INVALID, "adapter: the band-split layout is the 16 + 9 split of K = 25 (got K = %d)", K);
     if (N == 0) return SPF_OK;
-    SPF_HIP(spf::launch_adapter_fwd(raw, N, K, sh_mask, eps, scales, rotations, harmonics,
+    SPF_HIP(spf::launch_adapter_fwd(raw, raw_stride, N, K, sh_mask, eps, scales, rotations, harmonics, harmonics_high,
                                     static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 
-int spf_adapter_backward(const float* raw, int64_t N, int32_t K, const float* sh_mask, float eps,
+int spf_adapter_backward(const float* raw, int64_t raw_stride, int64_t N, int32_t K, const float* sh_mask, float eps,
                          const float* dL_dscales, const float* dL_drotations, const float* dL_dharmonics,
-                         float* dL_draw, void* stream_) {
+                         const float* dL_dharmonics_high, int32_t split, float* dL_draw, void* stream_) {
     if (!raw || !sh_mask || !dL_draw) return fail(SPF_E_INVALID, "adapter: null pointer");
-    if (N < 0 || K < 1) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K >= 1");
+    if (N < 0 || K < 1 || K > 64) return fail(SPF_E_INVALID, "adapter: N must be >= 0 and K in 1..64");
+    if (raw_stride < 7 + 3 * (int64_t)K) return fail(SPF_E_INVALID, "adapter: raw_stride %lld is below the %d channels of a row", (long long)raw_stride, 7 + 3 * K);
+    if (split && K != 25) return fail(SPF_E_INVALID, "adapter: the band-split layout is the 16 + 9 split of K = 25 (got K = %d)", K);
+    if (!split && dL_dharmonics_high) return fail(SPF_E_INVALID, "adapter: dL_dharmonics_high without split");
+    if (dL_drotations && (reinterpret_cast<uintptr_t>(dL_drotations) & 15))
+        return fail(SPF_E_INVALID, "adapter: dL_drotations must be 16-byte aligned");
     if (N == 0) return SPF_OK;
-    SPF_HIP(spf::launch_adapter_bwd(raw, N, K, sh_mask, eps, dL_dscales, dL_drotations, dL_dharmonics, dL_draw,
-                                    static_cast<hipStream_t>(stream_)));
+    SPF_HIP(spf::launch_adapter_bwd(raw, raw_stride, N, K, sh_mask, eps, dL_dscales, dL_drotations, dL_dharmonics,
+                                    dL_dharmonics_high, split ? 1 : 0, dL_draw, static_cast<hipStream_t>(stream_)));
     return SPF_OK;
 }
 

@@ -244,9 +244,19 @@ __device__ __forceinline__ void st4(float* __restrict__ p, float a, float b, flo
     if (ALIGNED) *reinterpret_cast<f4a*>(p) = v;
     else *reinterpret_cast<f4u*>(p) = v;
 }
-template <bool NATIVE, bool ALIGNED>
-__device__ __forceinline__ void sh_load4(const float* __restrict__ sh, int K, int k4, float v[4][3]) {
-    if (NATIVE) {
+// NATIVE == 2 (band split, SpfDims.sh_layout 2): coefficients 0..15 of channel c at sh[16 c + k] (16-byte aligned rows),
+// 16..24 at hi[9 c + k - 16] (dword aligned).  Only the degree-4 kernels are instantiated with it: up to degree 3 the
+// launchers hand plane 0 to the NATIVE == 1 kernels as a K = 16 block (launch_project_fwd / _bwd).
+template <int NATIVE, bool ALIGNED>
+__device__ __forceinline__ void sh_load4(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k4,
+                                         float v[4][3]) {
+    if (NATIVE == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f4a t = k4 < 4 ? ld4<true>(sh + c * 16 + 4 * k4) : ld4<false>(hi + c * 9 + 4 * (k4 - 4));
+            v[0][c] = t.x; v[1][c] = t.y; v[2][c] = t.z; v[3][c] = t.w;
+        }
+    } else if (NATIVE) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const f4a t = ld4<ALIGNED>(sh + c * K + 4 * k4);
@@ -259,9 +269,15 @@ __device__ __forceinline__ void sh_load4(const float* __restrict__ sh, int K, in
         v[2][2] = c.x; v[3][0] = c.y; v[3][1] = c.z; v[3][2] = c.w;
     }
 }
-template <bool NATIVE, bool ALIGNED>
-__device__ __forceinline__ void sh_store4(float* __restrict__ sh, int K, int k4, const float v[4][3]) {
-    if (NATIVE) {
+template <int NATIVE, bool ALIGNED>
+__device__ __forceinline__ void sh_store4(float* __restrict__ sh, float* __restrict__ hi, int K, int k4, const float v[4][3]) {
+    if (NATIVE == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (k4 < 4) st4<true>(sh + c * 16 + 4 * k4, v[0][c], v[1][c], v[2][c], v[3][c]);
+            else st4<false>(hi + c * 9 + 4 * (k4 - 4), v[0][c], v[1][c], v[2][c], v[3][c]);
+        }
+    } else if (NATIVE) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) st4<ALIGNED>(sh + c * K + 4 * k4, v[0][c], v[1][c], v[2][c], v[3][c]);
     } else {
@@ -276,9 +292,16 @@ __device__ __forceinline__ void zero_floats(float* __restrict__ p, int n) {
     for (; i + 4 <= n; i += 4) st4<false>(p + i, 0.f, 0.f, 0.f, 0.f);
     for (; i < n; ++i) p[i] = 0.f;
 }
-template <bool NATIVE>
-__device__ __forceinline__ float sh_at(const float* __restrict__ sh, int K, int k, int c) {
+template <int NATIVE>
+__device__ __forceinline__ float sh_at(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k, int c) {
+    if (NATIVE == 2) return k < 16 ? sh[c * 16 + k] : hi[c * 9 + k - 16];
     return NATIVE ? sh[c * K + k] : sh[3 * k + c];
+}
+// where coefficient k of channel c of a gradient block goes
+template <int NATIVE>
+__device__ __forceinline__ float* sh_slot(float* __restrict__ o, float* __restrict__ o_hi, int K, int k, int c) {
+    if (NATIVE == 2) return k < 16 ? o + c * 16 + k : o_hi + c * 9 + k - 16;
+    return NATIVE ? o + c * K + k : o + 3 * k + c;
 }
 
 // colour = sum_k basis_k sh_k (forward), optionally with D{x,y,z}[c] = sum_k dbasis_k/d{x,y,z} sh_k[c] (backward).
@@ -298,15 +321,15 @@ __device__ __forceinline__ void sh_accumulate(int k, const ShDir& dir, const flo
         }
     }
 }
-template <int NB, bool NATIVE, bool ALIGNED, bool WITH_GRAD>
-__device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K, const ShDir& dir, float col[3],
-                                            float Dx[3], float Dy[3], float Dz[3]) {
+template <int NB, int NATIVE, bool ALIGNED, bool WITH_GRAD>
+__device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const float* __restrict__ hi, int K,
+                                            const ShDir& dir, float col[3], float Dx[3], float Dy[3], float Dz[3]) {
     constexpr int NV = NB / 4;
     if (NV <= 1) {
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
             float v[4][3];
-            sh_load4<NATIVE, ALIGNED>(sh, K, k4, v);
+            sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4, v);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[i], col, Dx, Dy, Dz);
         }
@@ -315,10 +338,10 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K,
         // a compiler barrier after every group keeps the scheduler from hoisting ALL the loads to the top (which costs
         // 3*NB live registers -- with 16 / 25 coefficients that alone pushed the backward to one wave per SIMD).
         float v[2][4][3];
-        sh_load4<NATIVE, ALIGNED>(sh, K, 0, v[0]);
+        sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0]);
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
-            if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, K, k4 + 1, v[(k4 + 1) & 1]);
+            if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[k4 & 1][i], col, Dx, Dy, Dz);
             asm volatile("" ::: "memory");
@@ -326,7 +349,7 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K,
     }
 #pragma unroll
     for (int k = 4 * NV; k < NB; ++k) {
-        const float v[3] = {sh_at<NATIVE>(sh, K, k, 0), sh_at<NATIVE>(sh, K, k, 1), sh_at<NATIVE>(sh, K, k, 2)};
+        const float v[3] = {sh_at<NATIVE>(sh, hi, K, k, 0), sh_at<NATIVE>(sh, hi, K, k, 1), sh_at<NATIVE>(sh, hi, K, k, 2)};
         sh_accumulate<WITH_GRAD>(k, dir, v, col, Dx, Dy, Dz);
     }
 }
@@ -335,9 +358,9 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, int K,
 // itself, because it learns which channels the forward clamped only at the end of the pass; here `g` already has those
 // channels zeroed, from SpfState.sh_clamp).  Round 5: 255 -> 227 VGPRs at degree 3, 348 -> 256 at degree 4 (two waves
 // per SIMD instead of one).
-template <int NB, bool NATIVE, bool ALIGNED>
-__device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ sh, int K, const ShDir& dir,
-                                                      const float g[3], float dd[3]) {
+template <int NB, int NATIVE, bool ALIGNED>
+__device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ sh, const float* __restrict__ hi, int K,
+                                                      const ShDir& dir, const float g[3], float dd[3]) {
     constexpr int NV = NB / 4;
     auto acc = [&](int k, const float v[3]) {
         float gx, gy, gz;
@@ -349,17 +372,17 @@ __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ 
     };
     // groups of four coefficients, double-buffered by hand behind a compiler barrier (see sh_contract)
     float v[2][4][3];
-    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, K, 0, v[0]);
+    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0]);
 #pragma unroll
     for (int k4 = 0; k4 < NV; ++k4) {
-        if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, K, k4 + 1, v[(k4 + 1) & 1]);
+        if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc(4 * k4 + i, v[k4 & 1][i]);
         asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int k = 4 * NV; k < NB; ++k) {
-        const float t[3] = {sh_at<NATIVE>(sh, K, k, 0), sh_at<NATIVE>(sh, K, k, 1), sh_at<NATIVE>(sh, K, k, 2)};
+        const float t[3] = {sh_at<NATIVE>(sh, hi, K, k, 0), sh_at<NATIVE>(sh, hi, K, k, 1), sh_at<NATIVE>(sh, hi, K, k, 2)};
         acc(k, t);
     }
 }
@@ -368,9 +391,10 @@ __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ 
 // with clamped channels already zeroed) -- instead of 3*NB accumulator registers carried through the whole loop.
 // park[(6 * v + j) * kBlock + tid]; `first`: store, otherwise add to what an earlier chunk of views stored.
 // TO_LDS: `o` is the thread's own 3*K-float row of an LDS staging buffer (element-wise stores; `first` is true).
-template <int NB, bool NATIVE, bool ALIGNED, bool TO_LDS = false>
-__device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K, const float* __restrict__ park,
-                                                    int nviews, bool first) {
+template <int NB, int NATIVE, bool ALIGNED, bool TO_LDS = false>
+__device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, float* __restrict__ o_hi, int K,
+                                                    const float* __restrict__ park, int nviews, bool first) {
+    static_assert(!(TO_LDS && NATIVE == 2), "the split layout writes its planes directly");
     constexpr int NV = NB / 4;
     const int sk = NATIVE ? 1 : 3, sc = NATIVE ? K : 1;
     auto group = [&](int k0, int n, float (&acc)[4][3]) {
@@ -403,11 +427,11 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
         }
         if (!first) {
             float old[4][3];
-            sh_load4<NATIVE, ALIGNED>(o, K, k4, old);
+            sh_load4<NATIVE, ALIGNED>(o, o_hi, K, k4, old);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[i][0] += old[i][0]; acc[i][1] += old[i][1]; acc[i][2] += old[i][2]; }
         }
-        sh_store4<NATIVE, ALIGNED>(o, K, k4, acc);
+        sh_store4<NATIVE, ALIGNED>(o, o_hi, K, k4, acc);
     }
     if (NB % 4 != 0) {
         float acc[4][3];
@@ -415,8 +439,11 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, int K
 #pragma unroll
         for (int i = 0; i < NB % 4; ++i) {
             const int k = 4 * NV + i;
-            if (!first) { acc[i][0] += o[sk * k]; acc[i][1] += o[sk * k + sc]; acc[i][2] += o[sk * k + 2 * sc]; }
-            o[sk * k] = acc[i][0]; o[sk * k + sc] = acc[i][1]; o[sk * k + 2 * sc] = acc[i][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float* __restrict__ q = sh_slot<NATIVE>(o, o_hi, K, k, c);
+                *q = first ? acc[i][c] : acc[i][c] + *q;
+            }
         }
     }
     if (TO_LDS) {
@@ -459,7 +486,7 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // numbers its (Gaussian, tile) pairs from a sharded global cursor, and every thread writes its keys
 // (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
-template <int DEG, bool NATIVE>
+template <int DEG, int NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
@@ -562,10 +589,11 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                     dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
                 const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
                 const ShDir sd = sh_dir(dir[0] * inv, dir[1] * inv, dir[2] * inv);
-                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                const float* __restrict__ sh = in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
+                const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 col[0] = col[1] = col[2] = 0.f;
-                if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
-                else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                if (NATIVE == 2 || d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -814,7 +842,7 @@ __host__ __device__ inline bool sh_stage_out(int V, int K) {
 
 // (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
 // the SH section -- 300+ VGPRs, one wave per SIMD; asking for two blocks per CU caps it at 256 VGPRs)
-template <int DEG, bool NATIVE>
+template <int DEG, int NATIVE>
 __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? SPF_PBWD_DEG4_BPC : SPF_PBWD_BPC))) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
     (void)capacity;
@@ -838,7 +866,11 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * sg + k] = nan;
         gr.dL_dopacities[sg] = nan;
         if (gr.dL_dcolors) for (int k = 0; k < 3; ++k) gr.dL_dcolors[3 * sg + k] = nan;
-        if (gr.dL_dshs) for (int k = 0; k < 3 * d.K; ++k) gr.dL_dshs[sg * (size_t)d.K * 3 + k] = nan;
+        if (gr.dL_dshs) {
+            const int kk = NATIVE == 2 ? 16 : d.K;
+            for (int k = 0; k < 3 * kk; ++k) gr.dL_dshs[sg * (size_t)kk * 3 + k] = nan;
+            if (NATIVE == 2) for (int k = 0; k < 27; ++k) gr.dL_dshs_high[sg * 27 + k] = nan;
+        }
         if (gr.dL_dscales) for (int k = 0; k < 3; ++k) gr.dL_dscales[3 * sg + k] = nan;
         if (gr.dL_drotations) for (int k = 0; k < 4; ++k) gr.dL_drotations[4 * sg + k] = nan;
         return;
@@ -877,12 +909,13 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     float* __restrict__ s_park = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + threadIdx.x;
     constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
     const bool want_dsh = DEG >= 0 && gr.dL_dshs != nullptr;
-    float* __restrict__ dsh_out = want_dsh ? gr.dL_dshs + sg * (size_t)d.K * 3 : nullptr;
+    float* __restrict__ dsh_out = want_dsh ? gr.dL_dshs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3 : nullptr;
+    float* __restrict__ dsh_out_hi = (want_dsh && NATIVE == 2) ? gr.dL_dshs_high + sg * 27 : nullptr;
     // When every view fits the parked chunk, dL/dsh leaves through an LDS staging buffer (half a block at a time) and
     // is written with full-wave contiguous stores.  Per-thread stores of a 3*K-float block are 16-byte pieces at a
     // 12*K-byte stride: lines fill up piece by piece over the whole flush and the set of open lines outgrows the L2
     // -- at K = 25 the stores alone were 250 of the kernel's 439 us.
-    const bool stage_out = kPark && want_dsh && sh_stage_out(d.V, d.K);
+    const bool stage_out = NATIVE != 2 && kPark && want_dsh && sh_stage_out(d.V, d.K);    // (split planes: direct stores)
     float dsh[kPark ? 1 : NB][3];
 #pragma unroll
     for (int k = 0; k < (kPark ? 1 : NB); ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
@@ -975,14 +1008,15 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                 const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
                 const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
                 const ShDir sd = sh_dir(x, y, z);
-                const float* __restrict__ sh = in.shs + sg * (size_t)d.K * 3;
+                const float* __restrict__ sh = in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
+                const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 float dd[3] = {0.f, 0.f, 0.f};
                 if (DEG == 0) {
                     // one term: re-evaluate the colour exactly as the forward kernel does (a colour clamped at 0 passes
                     // no gradient)
                     float col[3] = {0.f, 0.f, 0.f};
-                    if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
-                    else sh_contract<NB, NATIVE, false, false>(sh, d.K, sd, col, nullptr, nullptr, nullptr);
+                    if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
+                    else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)
                         if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
@@ -993,8 +1027,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                     if (cm & 1u) gcol[0] = 0.f;
                     if (cm & 2u) gcol[1] = 0.f;
                     if (cm & 4u) gcol[2] = 0.f;
-                    if (d.K % 4 == 0) sh_direction_gradient<NB, NATIVE, true>(sh, d.K, sd, gcol, dd);
-                    else sh_direction_gradient<NB, NATIVE, false>(sh, d.K, sd, gcol, dd);
+                    if (NATIVE == 2 || d.K % 4 == 0) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd);
+                    else sh_direction_gradient<NB, NATIVE, false>(sh, sh_hi, d.K, sd, gcol, dd);
                 }
                 sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
                 if (!kPark) {
@@ -1086,8 +1120,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             if (live && !stage_out && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
                 const int nv = v % kShChunk + 1;
                 const bool first = v < kShChunk;
-                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, d.K, s_park, nv, first);
-                else sh_grad_from_parked<NB, NATIVE, false>(dsh_out, d.K, s_park, nv, first);
+                if (NATIVE == 2 || d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, dsh_out_hi, d.K, s_park, nv, first);
+                else sh_grad_from_parked<NB, NATIVE, false>(dsh_out, dsh_out_hi, d.K, s_park, nv, first);
             }
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
@@ -1112,15 +1146,15 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             }
         }
     }
-    if (stage_out) {
+    if constexpr (NATIVE != 2) if (stage_out) {
         const int row = 3 * d.K;
         float* __restrict__ s_out = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + d.V * 6 * kBlock;
         for (int half = 0; half < 2; ++half) {
             __syncthreads();                                  // (buffer free; the parked views are complete)
             if ((int)(threadIdx.x >> 7) == half && live) {
                 float* __restrict__ mine = s_out + (threadIdx.x & 127) * row;
-                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true, true>(mine, d.K, s_park, d.V, true);
-                else sh_grad_from_parked<NB, NATIVE, false, true>(mine, d.K, s_park, d.V, true);
+                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true, true>(mine, nullptr, d.K, s_park, d.V, true);
+                else sh_grad_from_parked<NB, NATIVE, false, true>(mine, nullptr, d.K, s_park, d.V, true);
             }
             __syncthreads();
             const int g0 = blockIdx.x * kBlock + half * 128;
@@ -1226,12 +1260,12 @@ static inline int sh_eval_degree(const SpfDims& d) {
     const int cap = d.sh_band4 ? 4 : 3;
     return d.sh_degree > cap ? cap : d.sh_degree;
 }
-template <int DEG, bool NATIVE>
+template <int DEG, int NATIVE>
 static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDims& d, const SpfInputs& in,
                           const SpfState& st, int tiles_x, int tiles_y, int lds) {
     spf_project_fwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds);
 }
-template <int DEG, bool NATIVE>
+template <int DEG, int NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
                           const SpfGrads& g, int nblk, uint64_t capacity) {
     size_t lds = (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float);
@@ -1251,7 +1285,15 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
     }
     spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), lds, stream>>>(d, in, st, g, nblk, capacity);
 }
+// The band-split layout (sh_layout 2: planes [S,G,3,16] | [S,G,3,9]) below degree 4 IS the native layout with K = 16 on
+// plane 0 -- 16-byte aligned coefficient rows, and the band-4 plane is neither read nor (backward) written.
+static inline SpfDims dims_for_kernels(const SpfDims& d, int deg) {
+    SpfDims k = d;
+    if (d.sh_layout == 2 && deg < 4) { k.sh_layout = 1; k.K = 16; }
+    return k;
+}
 #define SPF_DISPATCH_DEG(FN, ...)                                        \
+    if (d.sh_layout == 2 && deg == 4) { FN<4, 2>(__VA_ARGS__); } else    \
     switch (deg * 2 + (native ? 1 : 0)) {                                \
         case -2: case -1: FN<-1, false>(__VA_ARGS__); break;             \
         case 0: FN<0, false>(__VA_ARGS__); break;                        \
@@ -1266,10 +1308,11 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
         default: FN<4, true>(__VA_ARGS__); break;                        \
     }
 
-hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, int tiles_x, int tiles_y,
+hipError_t launch_project_fwd(const SpfDims& d_in, const SpfInputs& in, const SpfState& st, int tiles_x, int tiles_y,
                               hipStream_t stream) {
+    const int deg = in.colors ? -1 : sh_eval_degree(d_in);
+    const SpfDims d = dims_for_kernels(d_in, deg);
     dim3 grid((d.G + kBlock - 1) / kBlock, d.S);
-    const int deg = in.colors ? -1 : sh_eval_degree(d);
     const bool native = d.sh_layout != 0;
     const int T = tiles_x * tiles_y;
     const int lds = T <= max_lds_tiles() ? 1 : 0;
@@ -1286,10 +1329,11 @@ hipError_t launch_project_fwd(const SpfDims& d, const SpfInputs& in, const SpfSt
     return hipGetLastError();
 }
 
-hipError_t launch_project_bwd(const SpfDims& d, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
+hipError_t launch_project_bwd(const SpfDims& d_in, const SpfInputs& in, const SpfState& st, const SpfGrads& g,
                               int nblk, uint64_t capacity, hipStream_t stream) {
+    const int deg = in.colors ? -1 : sh_eval_degree(d_in);
+    const SpfDims d = dims_for_kernels(d_in, deg);
     dim3 grid(nblk, d.S);
-    const int deg = in.colors ? -1 : sh_eval_degree(d);
     const bool native = d.sh_layout != 0;
     SPF_DISPATCH_DEG(project_bwd_t, grid, stream, d, in, st, g, nblk, capacity)
     hipError_t e = hipGetLastError();

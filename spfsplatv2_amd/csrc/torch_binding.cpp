@@ -51,6 +51,7 @@ SpfInputs make_inputs(const Tensor& means3D, const Tensor& scales, const Tensor&
     in.viewmatrix = ptr<const float>(viewmatrix); in.projmatrix = ptr<const float>(projmatrix);
     in.tanfov = ptr<const float>(tanfov); in.bg = ptr<const float>(bg);
     in.view_scale = ptr<const float>(view_scale); in.viewmatrix64 = ptr<const double>(view64);
+    in.shs_high = nullptr;      // (the band-split layout is the batched decoder's: this per-view surface takes [G,K,3])
     return in;
 }
 
@@ -183,7 +184,7 @@ std::vector<Tensor> raster_backward(
     gr.gpair = ptr<float>(gpair); gr.vpartial = ptr<float>(vpartial);
     gr.dL_dmeans3D = ptr<float>(d_means); gr.dL_dscales = ptr<float>(d_scales); gr.dL_drotations = ptr<float>(d_rot);
     gr.dL_dopacities = ptr<float>(d_opac); gr.dL_dshs = ptr<float>(d_shs); gr.dL_dcolors = ptr<float>(d_col);
-    gr.dL_dviewmatrix = ptr<float>(d_view); gr.dL_dmeans2D = ptr<float>(d_m2d);
+    gr.dL_dviewmatrix = ptr<float>(d_view); gr.dL_dmeans2D = ptr<float>(d_m2d); gr.dL_dshs_high = nullptr;
     void* const stream = c10::hip::getCurrentHIPStream(means3D.device().index()).stream();
     check(spf_raster_backward(&dims, &in, &st, &gr, (uint64_t)capacity, (uint32_t)dense, stream), "spf_raster_backward");
     return {d_means, d_scales, d_rot, d_opac, d_shs, d_col, want_view == 2 ? vpartial : d_view, d_m2d};

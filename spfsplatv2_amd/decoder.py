@@ -63,8 +63,12 @@ class Gaussians:
     covariances: Tensor  # [b, g, 3, 3]   (carried, never read by the rasterizer: cuda_splatting.py:136)
     rotations: Tensor    # [b, g, 4]
     scales: Tensor       # [b, g, 3]
-    harmonics: Tensor    # [b, g, 3, d_sh]
+    harmonics: Tensor    # [b, g, 3, d_sh]   ([b, g, 3, 16] when `harmonics_band4` is given)
     opacities: Tensor    # [b, g]
+    # (not a field of the reference's dataclass) BAND-SPLIT harmonics of a d_sh = 25 model: `harmonics` holds bands 0 - 3
+    # and this [b, g, 3, 9] tensor band 4 -- what `UnifiedGaussianAdapter(..., split_harmonics=True)` produces.  The
+    # default evaluation depth (degree 3) then never moves band 4's bytes; None: `harmonics` is the reference's layout.
+    harmonics_band4: Optional[Tensor] = None
 
 
 @dataclass
@@ -118,7 +122,7 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
                  scale_invariant: bool = True, use_sh: bool = True, enable_cov_grad: bool = False,
                  enable_sh_grad: bool = False, max_pairs=None, sh_band4: Optional[bool] = None,
-                 return_radii: bool = False, record=None):
+                 return_radii: bool = False, record=None, gaussian_sh_band4: Optional[Tensor] = None):
     """Batched form of ``render_cuda``: b scenes x v views sharing each scene's Gaussians.
 
     extrinsics [b,v,4,4] (camera-to-world), intrinsics [b,v,3,3] (normalised), near/far [b,v],
@@ -127,10 +131,12 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     multiplies by near, decoder_splatting_cuda.py:72-76) and alpha [b,v,1,h,w] (+ radii [b,v,g] int32 with
     ``return_radii``).  ``sh_band4``: with d_sh = 25 (sh_degree 4, the reference's default) also evaluate SH band 4;
     None = the ``SPF_SH_BAND4`` environment variable, default off (see ``rasterizer.sh_band4_default``).
+    ``gaussian_sh_band4`` [b,g,3,9]: band 4 of BAND-SPLIT harmonics, ``gaussian_sh_coefficients`` then being [b,g,3,16]
+    (``Gaussians.harmonics_band4``).
     """
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     h, w = image_shape
-    n = gaussian_sh_coefficients.shape[-1]
+    n = gaussian_sh_coefficients.shape[-1] + (0 if gaussian_sh_band4 is None else gaussian_sh_band4.shape[-1])
     degree = isqrt(n) - 1
     # SH stays in the encoder's [b,g,3,d_sh] layout: the kernels index it directly (no transposed copy as at
     # cuda_splatting.py:79); colours-only mode takes the DC coefficient as the colour (cuda_splatting.py:132)
@@ -138,7 +144,7 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
         extrinsics, intrinsics, near, far, gaussian_means, gaussian_scales, gaussian_rotations, gaussian_opacities,
         gaussian_sh_coefficients if use_sh else None, None if use_sh else gaussian_sh_coefficients[..., 0],
         background_color, h, w, degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs=max_pairs,
-        sh_layout="g3k", sh_band4=sh_band4, record=record)
+        sh_layout="g3k", sh_band4=sh_band4, record=record, shs_high=gaussian_sh_band4 if use_sh else None)
     return (color, depth, alpha, _radii) if return_radii else (color, depth, alpha)
 
 
@@ -395,7 +401,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
             scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
             enable_sh_grad=self.enable_sh_grad, max_pairs=max_pairs, sh_band4=self.sh_band4, return_radii=True,
-            record=record)
+            record=record, gaussian_sh_band4=getattr(gaussians, "harmonics_band4", None))
         depth = depth[:, :, 0]                                   # "(b v) 1 h w -> b v h w"
         if self.make_scale_invariant:
             depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76
@@ -427,6 +433,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     def _render(self, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
         tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
                    gaussians.rotations, gaussians.scales)
+        if getattr(gaussians, "harmonics_band4", None) is not None:
+            tensors = tensors + (gaussians.harmonics_band4,)
         auto = (self.auto_plan and (self._max_pairs is None or self._auto_owned) and extrinsics.is_cuda
                 and not torch.cuda.is_current_stream_capturing())
         if not auto:
@@ -556,7 +564,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                 gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
                 scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
                 enable_sh_grad=self.enable_sh_grad, max_pairs=self.max_pairs, sh_band4=self.sh_band4, return_radii=True,
-                record=record)
+                record=record, gaussian_sh_band4=getattr(gaussians, "harmonics_band4", None))
             if self.make_scale_invariant:
                 depth4.mul_(near[:, :, None, None, None])            # decoder_splatting_cuda.py:72-76, in place: the buffer is ours
             depth = depth4[:, :, 0]

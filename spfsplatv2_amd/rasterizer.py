@@ -220,7 +220,7 @@ def _early_verdict(dev: torch.device):
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                   view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None, sh_band4=False,
-                  record=None, nothing_needs_grad=False, view64=None):
+                  record=None, nothing_needs_grad=False, view64=None, shs_high=None):
     """Launch the forward chain.  Returns (outputs, saved state tensors).  `camera` (an SpfCamera whose outputs are
     viewmatrix / projmatrix / tanfov / view_scale): the decoder fast path -- camera set-up and the clearing of the tile
     counters are one kernel."""
@@ -256,7 +256,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
                 _raise_if_plan_failed(counters, pairs.numel())
         return ((image, depth, alpha, radii_v),
                 (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, 0, pairs.numel()))
-    K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
+    K = 0 if shs is None else (25 if sh_layout == 2 else shs.shape[3 if sh_layout else 2])
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
     # DIRECT BINS (planned calls): every tile owns a fixed bin of `bin_cap` keys that the projection kernel fills itself
@@ -289,7 +289,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale), _ptr(view64))
+                         _ptr(view_scale), _ptr(view64), _ptr(shs_high))
     pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev) if bin_cap else None
     st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     stream = _stream_ptr(dev)
@@ -446,8 +446,10 @@ def _plan_mode(max_pairs) -> int:
 
 
 @_on_device_of_first_arg
-def _backward_impl(inputs, state, geom, grads_out, want):
-    """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D)."""
+def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
+    """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D).  `shs_high`: the
+    band-4 plane of the band-split harmonics (sh_layout 2); its gradient is appended to the result -- None unless band 4
+    was evaluated (a degree-3 evaluation neither reads the plane nor writes its gradient)."""
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, view64 = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
@@ -462,7 +464,7 @@ def _backward_impl(inputs, state, geom, grads_out, want):
                               (bin_cap, capacity, lib.spf_raster_pair_shards(S, G)) if bin_cap else None)
     from .shard import active_bucket
     bucket = active_bucket()
-    fast = _lib.fast() if bucket is None else None      # (a gradient bucket supplies the output buffers: ctypes path)
+    fast = _lib.fast() if (bucket is None and shs_high is None) else None   # (a gradient bucket supplies the output buffers, the split layout a second plane: ctypes path)
     if fast is not None:
         wv = want["view"]
         with _spf_errors():
@@ -488,6 +490,9 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     d_scales = out("scales", scales) if want["scales_rot"] else None
     d_rot = out("rotations", rotations) if want["scales_rot"] else None
     d_shs = out("harmonics", shs) if (shs is not None and want["shs"]) else None
+    d_shs_high = None
+    if d_shs is not None and sh_layout == 2 and sh_band4 and sh_degree == 4:
+        d_shs_high = out("harmonics_band4", shs_high)
     d_col = torch.empty_like(colors) if (colors is not None and want["colors"]) else None
     # want["view"] == "partials": leave the viewmatrix gradient as per-block partial sums (the decoder chains them to
     # the poses in one kernel, spf_camera_backward_partials); returned in place of d_view
@@ -496,14 +501,15 @@ def _backward_impl(inputs, state, geom, grads_out, want):
     d_m2d = torch.zeros((R, G, 3), **f32) if want["means2D"] else None
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale), _ptr(view64))
+                         _ptr(view_scale), _ptr(view64), _ptr(shs_high))
     st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(gpair), _ptr(vpartial),
                        _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
-                       _ptr(d_view), _ptr(d_m2d))
+                       _ptr(d_view), _ptr(d_m2d), _ptr(d_shs_high))
     _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity, dense,
                                        _stream_ptr(dev)), "spf_raster_backward")
-    return d_means, d_scales, d_rot, d_opac, d_shs, d_col, (vpartial if want["view"] == "partials" else d_view), d_m2d
+    res = (d_means, d_scales, d_rot, d_opac, d_shs, d_col, (vpartial if want["view"] == "partials" else d_view), d_m2d)
+    return res if shs_high is None else res + (d_shs_high,)
 
 
 class _RasterizeBatch(torch.autograd.Function):
@@ -550,7 +556,7 @@ class _DecoderRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
                 H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout, sh_band4,
-                record, grad_mode):
+                record, grad_mode, shs_high=None):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         S, V = extrinsics.shape[:2]
@@ -569,13 +575,13 @@ class _DecoderRender(torch.autograd.Function):
                                            bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam,
                                            sh_band4=sh_band4, record=record,
                                            nothing_needs_grad=not (grad_mode and any(ctx.needs_input_grad)),
-                                           view64=view64)
+                                           view64=view64, shs_high=shs_high)
         G = means3D.shape[1]
-        K = 0 if shs is None else shs.shape[3 if sh_layout else 2]
+        K = 0 if shs is None else (25 if sh_layout == 2 else shs.shape[3 if sh_layout else 2])
         ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout), bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
-                              view64, *state, near)
+                              view64, *state, near, shs_high)
         ctx.mark_non_differentiable(outs[3])
         return outs
 
@@ -587,8 +593,9 @@ class _DecoderRender(torch.autograd.Function):
         enable_cov_grad, enable_sh_grad, scale_invariant = ctx.flags
         want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
                     colors=need[9], view="partials" if need[0] else False, means2D=False)
-        d_means, d_scales, d_rot, d_opac, d_shs, d_col, vpartial, _ = _backward_impl(
-            saved[:12], saved[12:20], ctx.geom, (g_image, g_depth, g_alpha), want)
+        shs_high = saved[21]
+        d_means, d_scales, d_rot, d_opac, d_shs, d_col, vpartial, _, *d_high = _backward_impl(
+            saved[:12], saved[12:20], ctx.geom, (g_image, g_depth, g_alpha), want, shs_high=shs_high)
         d_ext = None
         if need[0]:
             view, near = saved[6], saved[20]
@@ -600,7 +607,7 @@ class _DecoderRender(torch.autograd.Function):
                                                             _ptr(d_ext), _stream_ptr(view.device)),
                            "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, d_high[0] if d_high else None)
 
 
 def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):
@@ -627,12 +634,16 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  shs: Optional[Tensor], colors_precomp: Optional[Tensor], bg: Tensor,
                  image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
                  enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs=None,
-                 sh_layout: str = "gk3", sh_band4: Optional[bool] = None, record: Optional[CallRecord] = None):
+                 sh_layout: str = "gk3", sh_band4: Optional[bool] = None, record: Optional[CallRecord] = None,
+                 shs_high: Optional[Tensor] = None):
     """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
 
     extrinsics [S,V,4,4] camera-to-world, intrinsics [S,V,3,3] normalised, near/far [S,V]; Gaussians as in
     ``rasterize_batch``; ``sh_layout="g3k"`` takes ``shs`` as [S,G,3,K] -- the encoder's native layout
-    (``Gaussians.harmonics``), so the transposed copy at cuda_splatting.py:79 never happens.  ``sh_band4``: evaluate
+    (``Gaussians.harmonics``), so the transposed copy at cuda_splatting.py:79 never happens; with ``shs_high`` [S,G,3,9]
+    (band 4) ``shs`` is [S,G,3,16] (bands 0 - 3): the BAND-SPLIT layout of d_sh = 25 the fused adapter writes
+    (``UnifiedGaussianAdapter(..., split_harmonics=True)``) -- a degree-3 evaluation then never touches band 4's bytes,
+    forward or backward.  ``sh_band4``: evaluate
     band 4 when ``sh_degree`` is 4 (None = ``sh_band4_default()``).  ``record``: a ``CallRecord`` that receives this
     call's statistics / plan counters.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units),
     alpha [S,V,1,H,W], radii [S,V,G]."""
@@ -651,10 +662,17 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     if sh_layout not in ("gk3", "g3k"):
         raise RuntimeError(f"sh_layout must be 'gk3' or 'g3k', got {sh_layout!r}")
     native = sh_layout == "g3k"
+    layout = 1 if native else 0
     if sh_band4 is None:
         sh_band4 = sh_band4_default()
         _note_band4_not_evaluated(sh_degree, sh_band4)
-    if shs is not None:
+    if shs_high is not None:
+        if shs is None or not native:
+            raise RuntimeError("shs_high (band 4 of the band-split layout) goes with shs [S,G,3,16] and sh_layout='g3k'")
+        shs = _f32c(shs, "shs", (S, G, 3, 16))
+        shs_high = _f32c(shs_high, "shs_high", (S, G, 3, 9))
+        layout = 2
+    elif shs is not None:
         K = shs.shape[3 if native else 2]
         if K < (min(sh_degree, 4 if sh_band4 else 3) + 1) ** 2:
             raise RuntimeError(f"shs holds {K} coefficients, too few for sh_degree {sh_degree}")
@@ -666,8 +684,8 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     bg = _background(bg, S, V)
     return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs,
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
-                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, 1 if native else 0,
-                                bool(sh_band4), record, torch.is_grad_enabled())
+                                bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, layout,
+                                bool(sh_band4), record, torch.is_grad_enabled(), shs_high)
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,

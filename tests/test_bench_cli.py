@@ -60,7 +60,9 @@ def test_secondary_children_parse_and_cover_the_verdict_list():
     accepted by the script's own parser and must not recurse."""
     b = _bench()
     names = [n for n, _, _ in b.SECONDARY]
-    assert names == ["C3", "C5", "REF2V", "REF2V_band4", "REF10V", "C2_stress", "C2_module", "C2_streams2", "eval_1x3", "rope2d"]
+    assert names == ["C3", "C5", "REF2V", "REF2V_band4", "REF10V", "REF2V_split", "REF10V_split", "REF2V_adapter",
+                     "REF2V_adapter_split", "REF10V_adapter_split", "C2_stress", "C2_module", "C2_streams2", "eval_1x3",
+                     "rope2d"]
     for _name, extra, env in b.SECONDARY:
         a = b.parse_args(["--gpus", "1", "--no-cpu-baseline", "--no-secondary", *extra])
         assert a.no_secondary and a.no_cpu_baseline

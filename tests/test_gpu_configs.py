@@ -231,6 +231,41 @@ def test_parity_k25_with_and_without_band4(hip_lib, band4):
     assert float((other["color"] - ref["color"]).abs().max()) > 1e-3   # the two conventions really differ here
 
 
+@pytest.mark.parametrize("band4", [False, True], ids=["split_deg3", "split_deg4"])
+def test_band_split_harmonics_are_the_dense_layout_bit_for_bit(hip_lib, band4):
+    """`Gaussians.harmonics_band4` (SpfDims.sh_layout 2: planes [.,3,16] | [.,3,9], what the fused adapter writes with
+    split_harmonics=True): the same coefficients in another place -- images and every gradient are BIT-identical to the
+    reference layout's [.,3,25], with band 4 evaluated or not, and hold against the oracle like it; a degree-3
+    evaluation hands NO gradient to the band-4 plane (not a zero tensor: nothing is written for it)."""
+    batch = syn.make_batch("TEST", 2, 2, seed=6, s_mult=10.0, G=1200, K=25, image_hw=(64, 48))
+    batch.harmonics[..., 1:] *= 4.0
+    ref = util.run_oracle(batch, torch.float64, background=(0.2, 0.1, 0.3), mask_fragile=True, band4=band4)
+    dense = util.run_product(batch, background=(0.2, 0.1, 0.3), pixel_mask=ref["pixel_mask"], band4=band4)
+    split = util.run_product(batch, background=(0.2, 0.1, 0.3), pixel_mask=ref["pixel_mask"], band4=band4, split=True)
+    rep = util.compare(split, ref)
+    assert not rep["fails"], rep
+    for k in ("color", "depth", "alpha", "radii"):
+        assert torch.equal(split[k], dense[k]), k
+    for n in util.GRAD_NAMES:
+        assert torch.equal(split["grads"][n], dense["grads"][n]), n
+    assert (float(split["grads"]["harmonics"][..., 16:].abs().max()) > 0) == band4
+
+
+def test_band_split_degree3_leaves_band4_without_a_gradient(hip_lib):
+    import spfsplatv2_amd as spf
+    b = syn.make_batch("TEST", 1, 2, seed=8, s_mult=10.0, G=700, K=25, image_hw=(48, 48)).to("cuda")
+    low = b.harmonics[..., :16].contiguous().requires_grad_(True)
+    high = b.harmonics[..., 16:].contiguous().requires_grad_(True)
+    d = util.product_decoder(band4=False)
+    out = d(spf.Gaussians(b.means, None, b.rotations, b.scales, low, b.opacities, harmonics_band4=high),
+            b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
+    out.color.square().mean().backward()
+    assert high.grad is None and float(low.grad.abs().max()) > 0
+    with pytest.raises(RuntimeError, match="shs_high"):          # the planes go together: [.,3,16] with [.,3,9]
+        d(spf.Gaussians(b.means, None, b.rotations, b.scales, b.harmonics, b.opacities, harmonics_band4=high),
+          b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
+
+
 def test_band4_switches(hip_lib, monkeypatch):
     """Default: SPF_SH_BAND4 unset -> degree 3; the environment variable, the decoder attribute and the settings field
     all turn it on."""

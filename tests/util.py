@@ -116,6 +116,25 @@ def run_oracle(batch, dtype=torch.float64, background=(0.0, 0.0, 0.0), scale_inv
     return res
 
 
+class _SplitLeaf:
+    """Two leaves standing in for one [.,3,25] harmonics leaf (run_product(split=True)): `.grad` joins them."""
+
+    def __init__(self, low, high):
+        self.low, self.high = low, high
+
+    @property
+    def grad(self):
+        if self.low.grad is None and self.high.grad is None:
+            return None
+        z = lambda t: torch.zeros_like(t) if t.grad is None else t.grad
+        return torch.cat((z(self.low), z(self.high)), dim=-1)
+
+    @grad.setter
+    def grad(self, value):
+        assert value is None
+        self.low.grad = self.high.grad = None
+
+
 def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cuda", max_pairs=None, band4=None,
                     auto_plan=None):
     """The product's decoder MODULE under the reference's registry name and config
@@ -132,16 +151,25 @@ def product_decoder(background=(0.0, 0.0, 0.0), scale_invariant=True, device="cu
 
 
 def run_product(batch, device="cuda", background=(0.0, 0.0, 0.0), scale_invariant=True, with_grads=True,
-                max_pairs=None, pixel_mask=None, band4=None, grad_names=GRAD_NAMES, unmasked_too=False):
+                max_pairs=None, pixel_mask=None, band4=None, grad_names=GRAD_NAMES, unmasked_too=False, split=False):
     """The product, end to end THROUGH ITS DECODER MODULE (`DecoderSplattingCUDA.render` = `forward` + the alpha and
     radii the reference's decoder drops): colour and depth are the module's own outputs, including its depth x near
-    post-processing (decoder_splatting_cuda.py:72-76) -- nothing of it is re-implemented here."""
+    post-processing (decoder_splatting_cuda.py:72-76) -- nothing of it is re-implemented here.  `split`: the d_sh = 25
+    harmonics go in BAND-SPLIT (two leaves, [.,3,16] and [.,3,9]: `Gaussians.harmonics_band4`); their gradients come back
+    joined to the [.,3,25] the oracle produces (a plane without a gradient -- band 4 not evaluated -- as zeros)."""
     from spfsplatv2_amd import decoder as dec
     bd = batch.to(device)
     leaves = {n: getattr(bd, n).detach().clone().requires_grad_(with_grads and n in grad_names) for n in GRAD_NAMES}
     d = product_decoder(background, scale_invariant, device, max_pairs, band4)
-    g = dec.Gaussians(leaves["means"], bd.covariances, leaves["rotations"], leaves["scales"], leaves["harmonics"],
-                      leaves["opacities"])
+    if split:
+        want = with_grads and "harmonics" in grad_names
+        leaves["harmonics"] = _SplitLeaf(bd.harmonics[..., :16].contiguous().requires_grad_(want),
+                                         bd.harmonics[..., 16:].contiguous().requires_grad_(want))
+        g = dec.Gaussians(leaves["means"], bd.covariances, leaves["rotations"], leaves["scales"], leaves["harmonics"].low,
+                          leaves["opacities"], harmonics_band4=leaves["harmonics"].high)
+    else:
+        g = dec.Gaussians(leaves["means"], bd.covariances, leaves["rotations"], leaves["scales"], leaves["harmonics"],
+                          leaves["opacities"])
     out, alpha, radii = d.render(g, leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)
     color, depth = out.color, out.depth
     res = dict(color=color.detach().cpu(), depth=depth.detach().cpu(), alpha=alpha.detach().cpu(),
