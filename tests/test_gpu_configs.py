@@ -244,10 +244,14 @@ def test_band_split_harmonics_are_the_dense_layout_bit_for_bit(hip_lib, band4):
     split = util.run_product(batch, background=(0.2, 0.1, 0.3), pixel_mask=ref["pixel_mask"], band4=band4, split=True)
     rep = util.compare(split, ref)
     assert not rep["fails"], rep
+    # degree 3: the SAME kernel instantiation reads plane 0 as a K = 16 block -> bit-identical.  Degree 4 runs the split
+    # instantiation of the kernels (two base pointers): the same sums in the same order, but the compiler is free to
+    # contract a multiply-add differently from one instantiation to the next -> equal to a few ulp
+    same = torch.equal if not band4 else (lambda a, b: util.rel_linf(a, b) < 2e-6)
     for k in ("color", "depth", "alpha", "radii"):
-        assert torch.equal(split[k], dense[k]), k
+        assert same(split[k], dense[k]), (k, util.rel_linf(split[k], dense[k]))
     for n in util.GRAD_NAMES:
-        assert torch.equal(split["grads"][n], dense["grads"][n]), n
+        assert same(split["grads"][n], dense["grads"][n]), (n, util.rel_linf(split["grads"][n], dense["grads"][n]))
     assert (float(split["grads"]["harmonics"][..., 16:].abs().max()) > 0) == band4
 
 
