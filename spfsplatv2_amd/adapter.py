@@ -63,9 +63,13 @@ def _rows(raw: Tensor, d_in: int) -> Tensor:
 
 class _AdapterFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, raw, mask, eps, split):
+    def forward(ctx, raw_any, mask, eps, split, d_in):
+        # (`raw_any`: the caller's tensor, whatever its shape; its [N, d_in] rows are taken HERE, outside autograd's view --
+        #  as an autograd op the as_strided of a view costs a zero fill and a scatter copy of the whole tensor in backward)
         ctx.set_materialize_grads(False)
         lib = _lib.load()
+        raw = _rows(raw_any.detach(), d_in)
+        ctx.raw_shape = tuple(raw_any.shape)
         N, Cn = raw.shape
         K = (Cn - 7) // 3
         f32 = dict(dtype=torch.float32, device=raw.device)
@@ -98,7 +102,7 @@ class _AdapterFn(torch.autograd.Function):
                                                 _p(g_sh), _p(g_sh_hi), 1 if ctx.split else 0, _p(g_raw),
                                                 C.c_void_p(torch.cuda.current_stream(raw.device).cuda_stream)),
                        "spf_adapter_backward")
-        return g_raw, None, None, None
+        return g_raw.view(ctx.raw_shape), None, None, None, None
 
 
 class UnifiedGaussianAdapter(nn.Module):
@@ -138,13 +142,13 @@ class UnifiedGaussianAdapter(nn.Module):
         if not raw_gaussians.is_cuda:
             raise RuntimeError("UnifiedGaussianAdapter: tensors are on the CPU; this build only runs on a HIP device")
         batch = raw_gaussians.shape[:-1]
-        raw = _rows(raw_gaussians, self.d_in)
+        raw = raw_gaussians
         sh_hi = None
         if self.split_harmonics:
-            scales, rot, sh, sh_hi = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, True)
+            scales, rot, sh, sh_hi = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, True, self.d_in)
             sh_hi = sh_hi.reshape(*batch, 3, 9).broadcast_to((*opacities.shape, 3, 9))
         else:
-            scales, rot, sh = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, False)
+            scales, rot, sh = _AdapterFn.apply(raw, self.sh_mask.to(raw.device), eps, False, self.d_in)
         scales, rot = scales.reshape(*batch, 3), rot.reshape(*batch, 4)
         sh = sh.reshape(*batch, 3, sh.shape[-1]).broadcast_to((*opacities.shape, 3, sh.shape[-1]))
         if with_covariances:

@@ -30,6 +30,29 @@ __device__ __forceinline__ int plane_src(int e, int KP, int k0, int K, int C, in
     return n * C + 7 + c * K + k;
 }
 
+// ---- forward ------------------------------------------------------------------------------------------------------
+// The group's rows as registers: element i = lane + 64 t of the group's kAdRows * C floats (flat or row-strided source).
+template <int KT, int NT>
+__device__ __forceinline__ void adapter_load_rows(const float* __restrict__ raw, int64_t stride, bool flat, int64_t n0,
+                                                  int rows, int lane, float (&v)[NT]) {
+    constexpr int C = 7 + 3 * KT;
+    const int nflt = rows * C;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int i = lane + kWave * t;
+        float x = 0.f;
+        if (i < nflt) {
+            if (flat) {
+                x = raw[n0 * C + i];
+            } else {
+                const int r = i / C;
+                x = raw[(n0 + r) * stride + (i - r * C)];
+            }
+        }
+        v[t] = x;
+    }
+}
+
 template <int KT>
 __global__ __launch_bounds__(kBlock) void spf_adapter_fwd_kernel(const float* __restrict__ raw, int64_t stride, int64_t N,
                                                                 int K_rt, const float* __restrict__ mask, float eps,
@@ -45,23 +68,25 @@ __global__ __launch_bounds__(kBlock) void spf_adapter_fwd_kernel(const float* __
     __syncthreads();                                                    // (the only one: the mask)
     const int64_t ngroup = (N + kAdRows - 1) / kAdRows;
     const bool flat = stride == C;
-    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroup; grp += (int64_t)gridDim.x * 4) {
+    const int64_t gstep = (int64_t)gridDim.x * 4;
+    constexpr int NT = KT ? (kAdRows * (7 + 3 * KT) + kWave - 1) / kWave : 1;
+    float v[NT], vn[NT];
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    if (KT && grp < ngroup)
+        adapter_load_rows<KT ? KT : 1, NT>(raw, stride, flat, grp * kAdRows, (int)min((int64_t)kAdRows, N - grp * kAdRows), lane, v);
+    for (; grp < ngroup; grp += gstep) {
         const int64_t n0 = grp * kAdRows;
         const int rows = (int)min((int64_t)kAdRows, N - n0);
         const int nflt = rows * C;
-        if (flat && KT && rows == kAdRows) {
-            // (a full group with a compile-time row length: every load of the group is in flight before the first wait)
-            const float* __restrict__ src = raw + n0 * C;
-            constexpr int NF = kAdRows * (7 + 3 * KT), NT = (NF + kWave - 1) / kWave;
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = (lane + kWave * t < NF) ? src[lane + kWave * t] : 0.f;
+        if (KT) {
+            // software pipeline: the NEXT group's loads go out before this group is touched -- a wave keeps two groups
+            // (5 KB) in flight instead of alternating between waiting for loads and waiting for stores
+            const int64_t nx = grp + gstep;
+            if (nx < ngroup)
+                adapter_load_rows<KT ? KT : 1, NT>(raw, stride, flat, nx * kAdRows, (int)min((int64_t)kAdRows, N - nx * kAdRows), lane, vn);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                if (lane + kWave * t < NF) s_row[lane + kWave * t] = v[t];
-        } else if (flat) {
-            const float* __restrict__ src = raw + n0 * C;
-            for (int i = lane; i < nflt; i += kWave) s_row[i] = src[i];
+                if (lane + kWave * t < nflt) s_row[lane + kWave * t] = v[t];
         } else {
             for (int i = lane; i < nflt; i += kWave) {
                 const int r = i / C;
@@ -83,16 +108,20 @@ __global__ __launch_bounds__(kBlock) void spf_adapter_fwd_kernel(const float* __
         // ---- harmonics: flat planes ----
         if (sh_hi) {
             float* __restrict__ lo = sh + n0 * 3 * kAdLow;
-            for (int e = lane; e < rows * 3 * kAdLow; e += kWave) {
+#pragma unroll
+            for (int t = 0; t < kAdRows * 3 * kAdLow / kWave; ++t) {
+                const int e = lane + kWave * t;
                 int k;
                 const int src = plane_src(e, kAdLow, 0, K, C, k);
-                lo[e] = s_row[src] * s_mask[k];
+                if (e < rows * 3 * kAdLow) lo[e] = s_row[src] * s_mask[k];
             }
             float* __restrict__ hi = sh_hi + n0 * 3 * kAdHigh;
-            for (int e = lane; e < rows * 3 * kAdHigh; e += kWave) {
+#pragma unroll
+            for (int t = 0; t < (kAdRows * 3 * kAdHigh + kWave - 1) / kWave; ++t) {
+                const int e = lane + kWave * t;
                 int k;
                 const int src = plane_src(e, kAdHigh, kAdLow, K, C, k);
-                hi[e] = s_row[src] * s_mask[k];
+                if (e < rows * 3 * kAdHigh) hi[e] = s_row[src] * s_mask[k];
             }
         } else {
             float* __restrict__ o = sh + n0 * 3 * K;
@@ -103,10 +132,54 @@ __global__ __launch_bounds__(kBlock) void spf_adapter_fwd_kernel(const float* __
             }
         }
         __builtin_amdgcn_wave_barrier();                               // (the rows are rewritten by the next trip)
+        if (KT) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = vn[t];
+        }
     }
 }
 
-// dL/draw [N, 7+3K] (contiguous): a group's rows are assembled in the wave's LDS and leave as one flat store.
+// ---- backward -----------------------------------------------------------------------------------------------------
+// dL/draw [N, 7+3K] (contiguous): a group's rows are assembled in the wave's LDS and leave as one flat store.  What a
+// group reads -- its gradient planes, the seven geometric raw channels of its rows, dL/dscales, dL/drotations -- is
+// requested for the NEXT group before this one is assembled.
+template <int KT>
+struct AdapterGradRegs {
+    static constexpr int NS = KT ? (kAdRows * 3 * KT + kWave - 1) / kWave : 1;     // dense plane, or:
+    static constexpr int NLO = kAdRows * 3 * kAdLow / kWave, NHI = (kAdRows * 3 * kAdHigh + kWave - 1) / kWave;
+    float sh[NS > NLO + NHI ? NS : NLO + NHI];
+    float raw7, gs, gr;
+};
+template <int KT>
+__device__ __forceinline__ void adapter_load_grads(AdapterGradRegs<KT>& g, const float* __restrict__ raw, int64_t stride,
+                                                   const float* __restrict__ g_scales, const float* __restrict__ g_rot,
+                                                   const float* __restrict__ g_sh, const float* __restrict__ g_sh_hi,
+                                                   int split, int64_t n0, int rows, int lane) {
+    using R = AdapterGradRegs<KT>;
+    if (split) {
+#pragma unroll
+        for (int t = 0; t < R::NLO; ++t) {
+            const int e = lane + kWave * t;
+            g.sh[t] = (g_sh && e < rows * 3 * kAdLow) ? g_sh[n0 * 3 * kAdLow + e] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < R::NHI; ++t) {
+            const int e = lane + kWave * t;
+            g.sh[R::NLO + t] = (g_sh_hi && e < rows * 3 * kAdHigh) ? g_sh_hi[n0 * 3 * kAdHigh + e] : 0.f;   // (NULL: band 4 not evaluated)
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < R::NS; ++t) {
+            const int e = lane + kWave * t;
+            g.sh[t] = (g_sh && e < rows * 3 * KT) ? g_sh[n0 * 3 * KT + e] : 0.f;
+        }
+    }
+    const int r7 = lane / 7;
+    g.raw7 = lane < rows * 7 ? raw[(n0 + r7) * stride + (lane - 7 * r7)] : 0.f;
+    g.gs = (g_scales && lane < rows * 3) ? g_scales[n0 * 3 + lane] : 0.f;
+    g.gr = (g_rot && lane < rows * 4) ? g_rot[n0 * 4 + lane] : 0.f;
+}
+
 template <int KT>
 __global__ __launch_bounds__(kBlock) void spf_adapter_bwd_kernel(const float* __restrict__ raw, int64_t stride, int64_t N,
                                                                 int K_rt, const float* __restrict__ mask, float eps,
@@ -121,15 +194,69 @@ __global__ __launch_bounds__(kBlock) void spf_adapter_bwd_kernel(const float* __
     float* const s_row = s_ad + wave * (kAdRows * C);
     const float* const s_mask = s_ad + 4 * kAdRows * C;
     float* const s_mask_w = s_ad + 4 * kAdRows * C;
+    float* const s_geo = s_ad + 4 * kAdRows * C + ((K + 3) & ~3) + wave * 128;     // raw7 [56] | gs [24] | gr [32]
     for (int k = threadIdx.x; k < K; k += kBlock) s_mask_w[k] = mask[k];
     __syncthreads();
     const int64_t ngroup = (N + kAdRows - 1) / kAdRows;
-    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroup; grp += (int64_t)gridDim.x * 4) {
+    const int64_t gstep = (int64_t)gridDim.x * 4;
+    using R = AdapterGradRegs<KT>;
+    R cur, nxt;
+    int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+    if (KT && grp < ngroup)
+        adapter_load_grads<KT>(cur, raw, stride, g_scales, g_rot, g_sh, g_sh_hi, split, grp * kAdRows,
+                               (int)min((int64_t)kAdRows, N - grp * kAdRows), lane);
+    for (; grp < ngroup; grp += gstep) {
         const int64_t n0 = grp * kAdRows;
         const int rows = (int)min((int64_t)kAdRows, N - n0);
+        if (KT) {
+            const int64_t nx = grp + gstep;
+            if (nx < ngroup)
+                adapter_load_grads<KT>(nxt, raw, stride, g_scales, g_rot, g_sh, g_sh_hi, split, nx * kAdRows,
+                                       (int)min((int64_t)kAdRows, N - nx * kAdRows), lane);
+            // ---- harmonics into the rows ----
+            if (split) {
+#pragma unroll
+                for (int t = 0; t < R::NLO; ++t) {
+                    const int e = lane + kWave * t;
+                    int k;
+                    const int dst = plane_src(e, kAdLow, 0, K, C, k);
+                    if (e < rows * 3 * kAdLow) s_row[dst] = cur.sh[t] * s_mask[k];
+                }
+#pragma unroll
+                for (int t = 0; t < R::NHI; ++t) {
+                    const int e = lane + kWave * t;
+                    int k;
+                    const int dst = plane_src(e, kAdHigh, kAdLow, K, C, k);
+                    if (e < rows * 3 * kAdHigh) s_row[dst] = cur.sh[R::NLO + t] * s_mask[k];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < R::NS; ++t) {
+                    const int e = lane + kWave * t;
+                    int k;
+                    const int dst = plane_src(e, K, 0, K, C, k);
+                    if (e < rows * 3 * K) s_row[dst] = cur.sh[t] * s_mask[k];
+                }
+            }
+            if (lane < 56) s_geo[lane] = cur.raw7;
+            if (lane < 24) s_geo[56 + lane] = cur.gs;
+            if (lane < 32) s_geo[80 + lane] = cur.gr;
+        } else {
+            for (int e = lane; e < rows * 3 * K; e += kWave) {
+                int k;                                          // (the split layout is K = 25: always a template instance)
+                const int dst = plane_src(e, K, 0, K, C, k);
+                s_row[dst] = g_sh ? g_sh[n0 * 3 * K + e] * s_mask[k] : 0.f;
+            }
+            const int r7 = lane / 7;
+            if (lane < rows * 7) s_geo[lane] = raw[(n0 + r7) * stride + (lane - 7 * r7)];
+            if (lane < 24) s_geo[56 + lane] = (g_scales && lane < rows * 3) ? g_scales[n0 * 3 + lane] : 0.f;
+            if (lane < 32) s_geo[80 + lane] = (g_rot && lane < rows * 4) ? g_rot[n0 * 4 + lane] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- geometry (one Gaussian per lane: the chain through the quaternion norm needs all four components) ----
         if (lane < rows) {
-            const float* __restrict__ r = raw + (n0 + lane) * stride;
+            const float* __restrict__ r = s_geo + 7 * lane;
             float* __restrict__ o = s_row + lane * C;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -137,60 +264,29 @@ __global__ __launch_bounds__(kBlock) void spf_adapter_bwd_kernel(const float* __
                 const float sp = softplus_torch(x);
                 const float dsp = x > 20.f ? 1.f : 1.f / (1.f + expf(-x));          // softplus' = sigmoid
                 const float pass = (0.001f * sp <= 0.3f) ? 1.f : 0.f;               // clamp_max passes the gradient up to the bound
-                o[i] = g_scales ? g_scales[(n0 + lane) * 3 + i] * 0.001f * dsp * pass : 0.f;
+                o[i] = s_geo[56 + 3 * lane + i] * 0.001f * dsp * pass;
             }
             const float q[4] = {r[3], r[4], r[5], r[6]};
-            float g[4] = {0.f, 0.f, 0.f, 0.f};
-            if (g_rot) {
-                const float4 tq = *reinterpret_cast<const float4*>(g_rot + (n0 + lane) * 4);
-                g[0] = tq.x; g[1] = tq.y; g[2] = tq.z; g[3] = tq.w;
-            }
+            const float g[4] = {s_geo[80 + 4 * lane], s_geo[81 + 4 * lane], s_geo[82 + 4 * lane], s_geo[83 + 4 * lane]};
             const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
             const float d = nrm + eps, dot = g[0] * q[0] + g[1] * q[1] + g[2] * q[2] + g[3] * q[3];
             const float k = nrm > 0.f ? dot / (nrm * d * d) : 0.f;                  // r = q/(|q|+eps): dr = dq/d - q (q.dq)/(|q| d^2)
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[3 + i] = g[i] / d - q[i] * k;
         }
-        // ---- harmonics ----
-        if (split && g_sh && rows == kAdRows) {
-            constexpr int NT = kAdRows * 3 * kAdLow / kWave;         // 6 coalesced loads in flight
-            float v[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = g_sh[n0 * 3 * kAdLow + lane + kWave * t];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                int k;
-                const int dst = plane_src(lane + kWave * t, kAdLow, 0, K, C, k);
-                s_row[dst] = v[t] * s_mask[k];
-            }
-            for (int e = lane; e < rows * 3 * kAdHigh; e += kWave) {
-                int k;
-                const int dst = plane_src(e, kAdHigh, kAdLow, K, C, k);
-                s_row[dst] = g_sh_hi ? g_sh_hi[n0 * 3 * kAdHigh + e] * s_mask[k] : 0.f;     // (NULL: band 4 was not evaluated)
-            }
-        } else if (split) {
-            for (int e = lane; e < rows * 3 * kAdLow; e += kWave) {
-                int k;
-                const int dst = plane_src(e, kAdLow, 0, K, C, k);
-                s_row[dst] = g_sh ? g_sh[n0 * 3 * kAdLow + e] * s_mask[k] : 0.f;
-            }
-            for (int e = lane; e < rows * 3 * kAdHigh; e += kWave) {
-                int k;
-                const int dst = plane_src(e, kAdHigh, kAdLow, K, C, k);
-                s_row[dst] = g_sh_hi ? g_sh_hi[n0 * 3 * kAdHigh + e] * s_mask[k] : 0.f;     // (NULL: band 4 was not evaluated)
-            }
-        } else {
-            for (int e = lane; e < rows * 3 * K; e += kWave) {
-                int k;
-                const int dst = plane_src(e, K, 0, K, C, k);
-                s_row[dst] = g_sh ? g_sh[n0 * 3 * K + e] * s_mask[k] : 0.f;
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float* __restrict__ dst = g_raw + n0 * C;
-        for (int i = lane; i < rows * C; i += kWave) dst[i] = s_row[i];
+        if (KT) {
+            constexpr int NF = (kAdRows * (7 + 3 * KT) + kWave - 1) / kWave;
+#pragma unroll
+            for (int t = 0; t < NF; ++t)
+                if (lane + kWave * t < rows * C) dst[lane + kWave * t] = s_row[lane + kWave * t];
+        } else {
+            for (int i = lane; i < rows * C; i += kWave) dst[i] = s_row[i];
+        }
         __builtin_amdgcn_wave_barrier();
+        if (KT) cur = nxt;
     }
 }
 
@@ -198,7 +294,7 @@ static unsigned adapter_grid(int64_t N) {
     const int64_t nblk = ((N + kAdRows - 1) / kAdRows + 3) / 4;
     return (unsigned)(nblk < 256 * 16 ? (nblk < 1 ? 1 : nblk) : 256 * 16);
 }
-static size_t adapter_lds(int K) { return sizeof(float) * ((size_t)4 * kAdRows * (7 + 3 * K) + (size_t)K); }
+static size_t adapter_lds(int K) { return sizeof(float) * ((size_t)4 * kAdRows * (7 + 3 * K) + (size_t)((K + 3) & ~3) + 4 * 128); }
 
 #define SPF_ADAPTER_K(FN, ...)                      \
     switch (K) {                                    \
