@@ -69,6 +69,10 @@ struct StageScope {
     int slot = -1;
     StageScope(int st, hipStream_t s) : stage(st), stream(s) {
         if (!((g_timing >> stage) & 1u)) return;
+        // (a stream that is being captured launches nothing now: an event recorded here would become a graph node and
+        //  could never be timed -- a caller that captures while stage timing is on simply gets no sample)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;
         if (g_calls[stage]++ % g_sample_every != 0) return;
         StageLog& L = g_log[stage];
         if (L.used >= SPF_STAGE_LOG) return;

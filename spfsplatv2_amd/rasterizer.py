@@ -24,7 +24,7 @@ from . import _lib
 
 import os
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_batch", "render_batch", "camera_forward", "StaticStep",
            "last_forward_stats", "PairBudget", "plan_pair_budget", "last_plan_flags", "plan_flags", "CallRecord",
            "sh_band4_default", "gaussian_normals"]
 
@@ -267,25 +267,9 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     rec_cap = _record_capacity(_plan_numbers(max_pairs, R * T)[0], S, G) if bin_cap else 0
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
                         bin_cap, rec_cap)
-    i32 = dict(dtype=torch.int32, device=dev)
-    f32 = dict(dtype=torch.float32, device=dev)
-
-    rec = torch.empty((R * G, _REC), **f32)
-    radii = torch.empty((R * G,), **i32)
-    rect = torch.empty((2 * R * G + (R * G + 3) // 4,), **i32)   # packed tile rect | depth key (float bits) | SH clamp masks (bytes)
     nblk = lib.spf_raster_view_partial_blocks(G)
-    pair_idx = torch.empty((2 * R * G + 2 * R * nblk,), **i32)   # pair_off (rect, first pair) | blk_total | blk_base
-    # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | pair cursors (8) | padding to 16 bytes
-    tiles = torch.empty((4 * R * T + 16,), **i32)
+    rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha = _alloc_forward(dev, S, V, G, H, W, T, nblk)
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
-    final_T = torch.empty((R * P,), **f32)
-    n_contrib = torch.empty((R * P,), **i32)
-    # colour and depth in ONE allocation, colour first (two contiguous tensors as ever: the decoder module's captured
-    # evaluation graphs copy both out with a single clone)
-    img_dep = torch.empty((R * 4 * P,), **f32)
-    image = img_dep[:R * 3 * P].view(S, V, 3, H, W)
-    depth = img_dep[R * 3 * P:].view(S, V, 1, H, W)
-    alpha = torch.empty((S, V, 1, H, W), **f32)
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
@@ -350,6 +334,29 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         _raise_if_plan_failed(tiles[4 * R * T + 1:], capacity, rec_out.get("plan"))
     return ((image, depth, alpha, radii.view(S, V, G)),
             (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, bin_cap, max(int(capacity), 1)))
+
+
+def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: int):
+    """Everything a forward call writes besides the pair lists: (rec, radii, rect, pair_idx, tiles, final_T, n_contrib,
+    image, depth, alpha)."""
+    R, P = S * V, H * W
+    i32 = dict(dtype=torch.int32, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    rec = torch.empty((R * G, _REC), **f32)
+    radii = torch.empty((R * G,), **i32)
+    rect = torch.empty((2 * R * G + (R * G + 3) // 4,), **i32)   # packed tile rect | depth key (float bits) | SH clamp masks (bytes)
+    pair_idx = torch.empty((2 * R * G + 2 * R * nblk,), **i32)   # pair_off (rect, first pair) | blk_total | blk_base
+    # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | pair cursors (8) | padding to 16 bytes
+    tiles = torch.empty((4 * R * T + 16,), **i32)
+    final_T = torch.empty((R * P,), **f32)
+    n_contrib = torch.empty((R * P,), **i32)
+    # colour and depth in ONE allocation, colour first (two contiguous tensors as ever: the decoder module's captured
+    # evaluation graphs copy both out with a single clone)
+    img_dep = torch.empty((R * 4 * P,), **f32)
+    image = img_dep[:R * 3 * P].view(S, V, 3, H, W)
+    depth = img_dep[R * 3 * P:].view(S, V, 1, H, W)
+    alpha = torch.empty((S, V, 1, H, W), **f32)
+    return rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha
 
 
 def _direct_bin_cap(max_pairs, RT: int, T: int) -> int:
@@ -608,6 +615,114 @@ class _DecoderRender(torch.autograd.Function):
                            "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
                 None, None, None, None, None, None, None, None, None, None, None, d_high[0] if d_high else None)
+
+
+class StaticStep:
+    """One planned decoder step (camera -> projection + bins -> sort -> composite; composite backward -> projection
+    backward -> pose chain) on buffers that are allocated ONCE: every launch reads and writes fixed addresses, so the
+    chain can be captured in HIP graphs and replayed -- `DecoderSplattingCUDA` does that for training calls whose input
+    addresses repeat (decoder.py).  Direct bins only (a plan with a list-length class); the inputs are borrowed by
+    address, exactly as a captured graph borrows them.
+
+    `launch_project()` / `launch_render()`: the forward in the two pieces the "early" plan check sits between;
+    `launch_backward()`: reads `g_image` (the caller copies dL/dimage there), writes `grads` / `d_ext`.
+    `inputs` / `state` / `geom` are what `_backward_impl` takes: a backward that cannot run from the graph (a depth or
+    alpha gradient, a gradient bucket, a second backward) runs through it on the same state."""
+
+    def __init__(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high, bg,
+                 H, W, sh_degree, scale_invariant, plan: PairBudget, sh_band4, want: dict):
+        lib = _lib.load()
+        self.lib = lib
+        S, G, _ = means3D.shape
+        V = extrinsics.shape[1]
+        R, dev = S * V, means3D.device
+        self.dev = dev
+        T = lib.spf_raster_num_tiles(H, W)
+        bin_cap = _direct_bin_cap(plan, R * T, T)
+        if not bin_cap:
+            raise RuntimeError("StaticStep needs a plan that runs with direct bins")
+        layout = 2 if shs_high is not None else 1
+        K = 25 if layout == 2 else shs.shape[3]
+        rec_cap = _record_capacity(int(plan.capacity), S, G)
+        self.dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, 1.0, layout, int(bool(sh_band4)), bin_cap, rec_cap)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.view, self.proj = torch.empty((S, V, 4, 4), **f32), torch.empty((S, V, 4, 4), **f32)
+        self.tanfov = torch.empty((S, V, 2), **f32)
+        self.vscale = torch.empty((S, V), **f32) if scale_invariant else None
+        self.view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
+        nblk = lib.spf_raster_view_partial_blocks(G)
+        (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib, self.image, self.depth,
+         self.alpha) = _alloc_forward(dev, S, V, G, H, W, T, nblk)
+        if self.tiles.data_ptr() % 16:
+            raise RuntimeError("StaticStep: the tile bookkeeping buffer is not 16-byte aligned")
+        self.pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev)
+        self.counters = self.tiles[4 * R * T + 1:4 * R * T + 5]
+        self.capacity, self.bin_cap, self.RT = rec_cap, bin_cap, R * T
+        self.plan_info = (int(bin_cap), int(rec_cap), lib.spf_raster_pair_shards(S, G))
+        bgx = _background(bg, S, V)
+        self.inputs = (means3D, scales, rotations, opacities, shs, None, self.view, self.proj, self.tanfov, bgx,
+                       self.vscale, self.view64)
+        self.shs_high = shs_high
+        self.state = (self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T, self.n_contrib)
+        self.geom = (S, V, G, K, sh_degree, H, W, 1.0, 2, (0xFFFFFFFF, bin_cap, rec_cap), layout, bool(sh_band4))
+        self.near, self.scale_invariant = near, bool(scale_invariant)
+        self.cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(self.view),
+                                  _ptr(self.proj), _ptr(self.tanfov), _ptr(self.vscale), R, 1 if scale_invariant else 0,
+                                  _ptr(self.view64))
+        self.inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), None,
+                                  _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov), _ptr(bgx), _ptr(self.vscale),
+                                  _ptr(self.view64), _ptr(shs_high))
+        self.st = _state_struct(self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T,
+                                self.n_contrib, R * T, R * G, R * nblk)
+        self.out = _lib.SpfOutputs(_ptr(self.image), _ptr(self.depth), _ptr(self.alpha))
+        self.max_tile = int(plan.max_tile_list)
+        # ---- backward ----
+        self.want = dict(want)
+        self.g_image = torch.empty((S, V, 3, H, W), **f32)
+        self.gpair = torch.empty((rec_cap, 10), **f32)
+        g = {"means": torch.empty_like(means3D), "opacities": torch.empty_like(opacities)}
+        if want["scales_rot"]:
+            g["scales"], g["rotations"] = torch.empty_like(scales), torch.empty_like(rotations)
+        if want["shs"]:
+            g["harmonics"] = torch.empty_like(shs)
+            if layout == 2 and sh_band4 and sh_degree == 4:
+                g["harmonics_band4"] = torch.empty_like(shs_high)
+        self.grads = g
+        self.vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
+        self.d_ext = torch.empty((S, V, 4, 4), **f32) if want["view"] else None
+        self.gr = _lib.SpfGrads(_ptr(self.g_image), None, None, _ptr(self.gpair), _ptr(self.vpartial), _ptr(g["means"]),
+                                _ptr(g.get("scales")), _ptr(g.get("rotations")), _ptr(g["opacities"]),
+                                _ptr(g.get("harmonics")), None, None, None, _ptr(g.get("harmonics_band4")))
+        self.cam_b = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(self.view), None, None, None, R,
+                                    1 if scale_invariant else 0)
+        self.nblk = nblk
+        self.nbytes = sum(t.numel() * t.element_size() for t in
+                          (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
+                           self.image, self.depth, self.alpha, self.pairs, self.g_image, self.gpair, *g.values()))
+
+    def launch_project(self) -> None:
+        lib, stream = self.lib, _stream_ptr(self.dev)
+        _lib.check(lib.spf_decoder_prepare(C.byref(self.cam), _ptr(self.tiles), 4 * self.tiles.numel(), stream),
+                   "spf_decoder_prepare")
+        _lib.check(lib.spf_raster_forward_project_prepared(C.byref(self.dims), C.byref(self.inp), C.byref(self.st),
+                                                           4 * self.tiles.numel(), stream),
+                   "spf_raster_forward_project_prepared")
+
+    def launch_render(self) -> None:
+        _lib.check(self.lib.spf_raster_forward_render(C.byref(self.dims), C.byref(self.inp), C.byref(self.st),
+                                                      C.byref(self.out), self.capacity, self.max_tile, 0xFFFFFFFF,
+                                                      _stream_ptr(self.dev)), "spf_raster_forward_render")
+
+    def launch_backward(self) -> None:
+        lib, stream = self.lib, _stream_ptr(self.dev)
+        _lib.check(lib.spf_raster_backward(C.byref(self.dims), C.byref(self.inp), C.byref(self.st), C.byref(self.gr),
+                                           self.capacity, 0xFFFFFFFF, stream), "spf_raster_backward")
+        if self.d_ext is not None:
+            _lib.check(lib.spf_camera_backward_partials(C.byref(self.cam_b), _ptr(self.vpartial), self.nblk,
+                                                        _ptr(self.d_ext), stream), "spf_camera_backward_partials")
+
+    def raise_if_failed(self) -> None:
+        _raise_if_plan_failed(self.tiles[4 * self.RT + 1:], self.capacity, self.plan_info)
 
 
 def camera_forward(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, scale_invariant: bool = True):

@@ -215,3 +215,116 @@ def test_auto_plan_deferred_training_reads_the_verdict_one_call_late(hip_lib):
     assert torch.equal(c, want_big[0]) and util.rel_linf(g, want_big[1]) < 1e-5 and d.max_pairs.capacity > cap
     c, g = step(d, big)                                               # planned under the new plan
     assert torch.equal(c, want_big[0]) and spf.plan_flags(d.last_call) == 0
+
+
+# ---- training calls: the module's own HIP graphs (round 6) -----------------------------------------------------------
+def _train_setup(seed=31, split=False):
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import decoder as dec
+    b = syn.make_batch("TEST", 2, 2, seed=seed, s_mult=4.0, G=2500, K=25, image_hw=(96, 80)).to("cuda")
+    leaves = {n: getattr(b, n).clone().requires_grad_(True) for n in util.GRAD_NAMES}
+    high = None
+    if split:
+        high = b.harmonics[..., 16:].contiguous().requires_grad_(True)
+        leaves["harmonics"] = b.harmonics[..., :16].contiguous().requires_grad_(True)
+    g = dec.Gaussians(leaves["means"], None, leaves["rotations"], leaves["scales"], leaves["harmonics"], leaves["opacities"],
+                      harmonics_band4=high)
+    probe = util.product_decoder()
+    with torch.no_grad():
+        probe.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+    plan = spf.plan_pair_budget(probe.last_call, slack=1.3, check="deferred")
+    w = torch.rand(2, 2, 3, 96, 80, device="cuda", generator=torch.Generator("cuda").manual_seed(5))
+
+    def step(d, with_depth=False, retain=False):
+        for t in leaves.values():
+            t.grad = None
+        out = d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+        loss = (out.color * w).sum() + (0.1 * (out.depth * w[:, :, 0]).sum() if with_depth else 0.0)
+        loss.backward(retain_graph=retain)
+        return out, loss, {n: t.grad.clone() for n, t in leaves.items()}
+
+    return spf, b, leaves, g, plan, step
+
+
+def _same(a, b):
+    return torch.equal(a[0].color, b[0].color) and torch.equal(a[0].depth, b[0].depth) and \
+        all(torch.equal(a[2][n], b[2][n]) for n in a[2])
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["dense_sh", "split_sh"])
+def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
+    """VERDICT r5 task 5: a planned training call whose input addresses repeat is captured (projection | sort + compositing
+    | backward) and replayed -- images, depth and every gradient bit-identical to the eager path; what a call returned
+    stays the caller's; an in-place update of an input (an optimizer step) is seen by the replay; a depth gradient, a
+    retained graph's second backward and a forward issued before the previous backward all take the eager kernels on the
+    same state and give the same numbers."""
+    spf, b, leaves, g, plan, step = _train_setup(split=split)
+    eager, d = util.product_decoder(max_pairs=plan), util.product_decoder(max_pairs=plan)
+    eager.train_graphs = False
+    want = step(eager)
+    first = step(d)
+    assert not d._train_graphs and _same(first, want)                 # first sight of the key: launched as usual
+    second = step(d)
+    assert len(d._train_graphs) == 1 and _same(second, want)          # captured, replayed
+    held = second[0].color.clone()
+    third = step(d)
+    assert _same(third, want) and torch.equal(second[0].color, held) and third[0].color.data_ptr() != second[0].color.data_ptr()
+    assert spf.plan_flags(d.last_call) == 0 and eager._train_graphs == {}
+    # an optimizer step: same addresses, new values
+    with torch.no_grad():
+        leaves["means"].add_(0.01 * torch.randn_like(leaves["means"]))
+        leaves["extrinsics"][:, :, 0, 3] += 0.02
+    moved = step(d)
+    assert _same(moved, step(eager)) and not torch.equal(moved[0].color, want[0].color)
+    # a gradient of the depth output: not what the backward graph was captured for -> eager kernels, same state
+    assert _same(step(d, with_depth=True), step(eager, with_depth=True))
+    # a retained graph: its second backward runs eagerly into fresh buffers
+    out, loss, g1 = step(d, retain=True)
+    for t in leaves.values():
+        t.grad = None
+    loss.backward()
+    assert all(torch.equal(leaves[n].grad, g1[n]) for n in leaves)
+    # a forward before the previous one's backward: the second call is launched eagerly, both are right
+    for t in leaves.values():
+        t.grad = None
+    o1 = d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+    o2 = d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+    ((o1.color * w).sum() + (o2.color * w).sum()).backward()
+    ref = step(eager)
+    assert torch.equal(o1.color, o2.color) and torch.equal(o1.color, ref[0].color)
+    assert all(util.rel_linf(leaves[n].grad, 2 * ref[2][n]) < 1e-6 for n in leaves)
+    assert len(d._train_graphs) == 1
+    d.clear_train_graphs()
+    assert _same(step(d), step(eager))
+
+
+def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
+    """The module's own planning over replayed training calls: inputs that outgrow the plan AT THE SAME ADDRESSES (the
+    graphs exist) -> the forward's early check raises inside the module, the call is re-run in exact mode, re-planned and
+    captured again under the new plan."""
+    from spfsplatv2_amd import decoder as dec
+    small = syn.make_batch("TEST", 1, 3, seed=26, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    big = syn.make_batch("TEST", 1, 3, seed=26, s_mult=300.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
+    means, scales = small.means.clone().requires_grad_(True), small.scales.clone()
+    g = dec.Gaussians(means, None, small.rotations, scales, small.harmonics, small.opacities)
+
+    def step(d):
+        means.grad = None
+        out = d.forward(g, small.extrinsics, small.intrinsics, small.near, small.far, small.image_shape)
+        out.color.square().mean().backward()
+        return out.color.detach().clone(), means.grad.clone()
+
+    ref, d = util.product_decoder(), _auto_decoder(slack=1.5)
+    want = step(ref)
+    for i in range(4):                                               # exact, planned, captured, replayed
+        c, gr = step(d)
+        assert torch.equal(c, want[0]) and util.rel_linf(gr, want[1]) < 1e-5
+    assert len(d._train_graphs) == 1
+    cap = d.max_pairs.capacity
+    with torch.no_grad():
+        scales.copy_(big.scales)                                     # same address, footprints x 150
+    want_big = step(ref)
+    for i in range(4):
+        c, gr = step(d)
+        assert torch.equal(c, want_big[0]) and util.rel_linf(gr, want_big[1]) < 1e-5, i
+    assert d.max_pairs.capacity > cap and len(d._train_graphs) >= 1
