@@ -243,7 +243,7 @@ def _train_setup(seed=31, split=False):
         loss.backward(retain_graph=retain)
         return out, loss, {n: t.grad.clone() for n, t in leaves.items()}
 
-    return spf, b, leaves, g, plan, step
+    return spf, b, leaves, g, plan, step, w
 
 
 def _same(a, b):
@@ -258,7 +258,7 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
     stays the caller's; an in-place update of an input (an optimizer step) is seen by the replay; a depth gradient, a
     retained graph's second backward and a forward issued before the previous backward all take the eager kernels on the
     same state and give the same numbers."""
-    spf, b, leaves, g, plan, step = _train_setup(split=split)
+    spf, b, leaves, g, plan, step, w = _train_setup(split=split)
     eager, d = util.product_decoder(max_pairs=plan), util.product_decoder(max_pairs=plan)
     eager.train_graphs = False
     want = step(eager)
