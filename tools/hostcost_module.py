@@ -48,3 +48,14 @@ for _ in range(n):
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / n
 print("train graphs:", len(d._train_graphs), "ms/step", round(wall * 1e3, 4), {k: round(v / n * 1e6, 1) for k, v in T.items()}, "us host per phase")
+
+if os.environ.get("SPF_CPROFILE"):
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        step(False)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
