@@ -279,7 +279,8 @@ class _EvalGraph:
 class _TrainGraph:
     """One captured TRAINING call of a decoder: the static step (buffers at fixed addresses, rasterizer.StaticStep) and
     its three graphs -- projection (+ camera, + bins), sort + compositing, and the whole backward chain."""
-    __slots__ = ("step", "g_project", "g_render", "g_backward", "record", "gen", "token", "nbytes", "__weakref__")
+    __slots__ = ("step", "g_project", "g_render", "g_backward", "record", "gen", "token", "nbytes", "alias_grads",
+                 "__weakref__")
 
     def busy(self) -> bool:
         """A forward of this entry is still waiting for its backward (its state must not be overwritten)."""
@@ -311,25 +312,27 @@ class _GraphedRender(torch.autograd.Function):
         entry.g_project.replay()
         early = None
         if check == "early":
-            # the verdict is final behind the projection kernel: copied out there, waited for once sort and compositing
-            # have been queued -- the GPU works through the wait
+            # the verdict is final behind the projection kernel: copied out there, waited for once everything else of the
+            # forward has been queued -- the GPU works through the wait
             early = rz._early_verdict(step.dev)
             early[0].copy_(step.counters[2:3], non_blocking=True)
             early[1].record()
-        entry.g_render.replay()
+        entry.g_render.replay()                      # sort + compositing (+ depth x near, in place on the graph's buffer)
+        # ONE copy-out: what the caller gets is the caller's (colour and depth share an allocation)
+        flat = step.img_dep.clone()
+        extra = (step.alpha.clone(), step.radii.view(step.alpha.shape[0], step.alpha.shape[1], -1).clone()) if want_extra \
+            else (None, None)
         if early is not None:
             early[1].synchronize()
             if int(early[0][0]) != 0:
                 token.consumed = True
                 step.raise_if_failed()
-        color = step.image.clone()                   # what the caller gets is the caller's
-        # (depth: handed out as it is when the module multiplies it by `near` right away -- a fresh tensor --, else copied)
-        depth = step.depth.view(step.depth.shape) if step.scale_invariant else step.depth.clone()
-        outs = (color, depth) + ((step.alpha.clone(), step.radii.view(step.alpha.shape[0], step.alpha.shape[1], -1).clone())
-                                 if want_extra else (None, None))
+        n = step.image.numel()
+        color = flat[:n].view(step.image.shape)
+        depth = flat[n:].view(step.depth.shape[0], step.depth.shape[1], step.depth.shape[3], step.depth.shape[4])
         if want_extra:
-            ctx.mark_non_differentiable(outs[3])
-        return outs
+            ctx.mark_non_differentiable(extra[1])
+        return (color, depth) + extra
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_alpha, _g_radii):
@@ -350,9 +353,14 @@ class _GraphedRender(torch.autograd.Function):
         if replay:
             step.g_image.copy_(g_color)
             entry.g_backward.replay()
-            g = step.grads
-            return (None, None, None, step.d_ext if need[3] else None, g["means"], g.get("scales"), g.get("rotations"),
-                    g["opacities"], g.get("harmonics"), g.get("harmonics_band4"))
+            # the gradients leave as ONE copy of the graph's flat gradient buffer (the graph's own pieces on request)
+            g = step.grads if entry.alias_grads else step.grad_views(step.grad_flat.clone())
+            return (None, None, None, g.get("extrinsics") if need[3] else None, g["means"], g.get("scales"),
+                    g.get("rotations"), g["opacities"], g.get("harmonics"), g.get("harmonics_band4"))
+        if g_depth is not None:
+            g_depth = g_depth[:, :, None]            # (the node's depth output is [b,v,h,w], already x near)
+            if step.scale_invariant:
+                g_depth = g_depth * step.near[:, :, None, None, None]
         # anything else (a depth / alpha gradient, a gradient bucket, a second backward of a retained graph): the same
         # kernels, launched one by one on the same state, into fresh buffers
         res = rz._backward_impl(step.inputs, step.state, step.geom, (g_color, g_depth, g_alpha),
@@ -437,10 +445,15 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # (the driver's box in round 5: 0.4765 ms per C2 step through this module launched kernel by kernel, against 0.357
         # for the same kernels replayed).  Results are bit-identical to the eager path.  One forward may be outstanding per
         # key: a second forward before the first one's backward runs eagerly.  `train_graphs = False` /
-        # SPF_TRAIN_GRAPHS=0: off.  What a replayed call hands out: colour / alpha / radii are copies; gradients are the
-        # graph's own buffers (leaves get a copy from autograd, a producer's backward consumes them in place) -- valid
-        # until the next backward of the same key.
+        # SPF_TRAIN_GRAPHS=0: off.  What a replayed call hands out -- colour, depth, alpha, radii, gradients -- are copies
+        # (one launch each way): nothing a caller holds is rewritten by a later call.
         self.train_graphs = os.environ.get("SPF_TRAIN_GRAPHS", "1") != "0"
+        # False (default): a replayed backward hands out a COPY of the graph's gradient buffer (one launch; 7 MB per C2
+        # step, 180 MB at the 2-view model's 16 x 131,072 Gaussians x 25 coefficients).  True: the graph's own buffers --
+        # right for the reference's model, whose decoder inputs are the encoder's outputs and whose producer consumes the
+        # gradients within the same backward; WRONG for leaves (or views of leaves) whose .grad is kept or accumulated
+        # across calls: the next backward of the key rewrites the memory such a .grad aliases.
+        self.train_graph_alias_grads = os.environ.get("SPF_TRAIN_GRAPH_ALIAS_GRADS", "0") == "1"
         self._train_graphs: dict = {}    # key -> _TrainGraph
         self._train_seen: dict = {}
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
@@ -561,8 +574,14 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                                   self.make_scale_invariant, self.max_pairs, band4, want)
                 entry = _TrainGraph()
                 entry.step, entry.gen, entry.token = step, 0, None
+                entry.alias_grads = bool(self.train_graph_alias_grads)
+
+                def render_and_scale():
+                    step.launch_render()
+                    if self.make_scale_invariant:
+                        step.depth.mul_(near[:, :, None, None, None])      # decoder_splatting_cuda.py:72-76, in place
                 graphs = []
-                for launch in (step.launch_project, step.launch_render, step.launch_backward):
+                for launch in (step.launch_project, render_and_scale, step.launch_backward):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         launch()
@@ -587,9 +606,6 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             entry, check, want_extra, extrinsics, gaussians.means, gaussians.scales, gaussians.rotations,
             gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
         self.last_call = entry.record
-        depth = depth[:, :, 0]
-        if self.make_scale_invariant:
-            depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76 (a fresh tensor)
         return DecoderOutput(color, depth), alpha, radii
 
     def _render_eager(self, gaussians, extrinsics, intrinsics, near, far, image_shape, max_pairs, record):

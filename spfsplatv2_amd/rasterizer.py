@@ -268,7 +268,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
                         bin_cap, rec_cap)
     nblk = lib.spf_raster_view_partial_blocks(G)
-    rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha = _alloc_forward(dev, S, V, G, H, W, T, nblk)
+    rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha, _ = _alloc_forward(dev, S, V, G, H, W, T, nblk)
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
@@ -338,7 +338,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
 
 def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: int):
     """Everything a forward call writes besides the pair lists: (rec, radii, rect, pair_idx, tiles, final_T, n_contrib,
-    image, depth, alpha)."""
+    image, depth, alpha, the flat colour | depth allocation)."""
     R, P = S * V, H * W
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
@@ -356,7 +356,7 @@ def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: in
     image = img_dep[:R * 3 * P].view(S, V, 3, H, W)
     depth = img_dep[R * 3 * P:].view(S, V, 1, H, W)
     alpha = torch.empty((S, V, 1, H, W), **f32)
-    return rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha
+    return rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha, img_dep
 
 
 def _direct_bin_cap(max_pairs, RT: int, T: int) -> int:
@@ -652,7 +652,7 @@ class StaticStep:
         self.view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
         nblk = lib.spf_raster_view_partial_blocks(G)
         (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib, self.image, self.depth,
-         self.alpha) = _alloc_forward(dev, S, V, G, H, W, T, nblk)
+         self.alpha, self.img_dep) = _alloc_forward(dev, S, V, G, H, W, T, nblk)
         if self.tiles.data_ptr() % 16:
             raise RuntimeError("StaticStep: the tile bookkeeping buffer is not 16-byte aligned")
         self.pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev)
@@ -680,16 +680,27 @@ class StaticStep:
         self.want = dict(want)
         self.g_image = torch.empty((S, V, 3, H, W), **f32)
         self.gpair = torch.empty((rec_cap, 10), **f32)
-        g = {"means": torch.empty_like(means3D), "opacities": torch.empty_like(opacities)}
+        # every gradient the chain writes lives in ONE flat allocation (16-byte aligned pieces): a call hands out a copy --
+        # one launch -- or, on request, the pieces themselves (see DecoderSplattingCUDA.train_graph_alias_grads)
+        like = {"means": means3D, "opacities": opacities}
         if want["scales_rot"]:
-            g["scales"], g["rotations"] = torch.empty_like(scales), torch.empty_like(rotations)
+            like["scales"], like["rotations"] = scales, rotations
         if want["shs"]:
-            g["harmonics"] = torch.empty_like(shs)
+            like["harmonics"] = shs
             if layout == 2 and sh_band4 and sh_degree == 4:
-                g["harmonics_band4"] = torch.empty_like(shs_high)
+                like["harmonics_band4"] = shs_high
+        if want["view"]:
+            like["extrinsics"] = self.view
+        offs, n = {}, 0
+        for name, t in like.items():
+            offs[name] = n
+            n += (t.numel() + 3) & ~3
+        self.grad_flat = torch.empty((max(n, 4),), **f32)
+        self.grad_layout = {name: (offs[name], tuple(t.shape)) for name, t in like.items()}
+        g = self.grad_views(self.grad_flat)
         self.grads = g
         self.vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
-        self.d_ext = torch.empty((S, V, 4, 4), **f32) if want["view"] else None
+        self.d_ext = g.get("extrinsics")
         self.gr = _lib.SpfGrads(_ptr(self.g_image), None, None, _ptr(self.gpair), _ptr(self.vpartial), _ptr(g["means"]),
                                 _ptr(g.get("scales")), _ptr(g.get("rotations")), _ptr(g["opacities"]),
                                 _ptr(g.get("harmonics")), None, None, None, _ptr(g.get("harmonics_band4")))
@@ -698,7 +709,16 @@ class StaticStep:
         self.nblk = nblk
         self.nbytes = sum(t.numel() * t.element_size() for t in
                           (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
-                           self.image, self.depth, self.alpha, self.pairs, self.g_image, self.gpair, *g.values()))
+                           self.img_dep, self.alpha, self.pairs, self.g_image, self.gpair, self.grad_flat))
+
+    def grad_views(self, flat: Tensor) -> dict:
+        out = {}
+        for name, (off, shape) in self.grad_layout.items():
+            numel = 1
+            for d in shape:
+                numel *= d
+            out[name] = flat[off:off + numel].view(shape)
+        return out
 
     def launch_project(self) -> None:
         lib, stream = self.lib, _stream_ptr(self.dev)
