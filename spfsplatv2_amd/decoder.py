@@ -277,10 +277,9 @@ class _EvalGraph:
 
 
 class _TrainGraph:
-    """One captured TRAINING call of a decoder: the static step (buffers at fixed addresses, rasterizer.StaticStep) and
-    its three graphs -- projection (+ camera, + bins), sort + compositing, and the whole backward chain."""
-    __slots__ = ("step", "g_project", "g_render", "g_backward", "record", "gen", "token", "nbytes", "alias_grads",
-                 "__weakref__")
+    """One prepared TRAINING call of a decoder: the static step (state at fixed addresses, argument structs built once:
+    rasterizer.StaticStep) and the captured graph of its state-only part -- camera set-up + projection + binning."""
+    __slots__ = ("step", "g_project", "record", "gen", "token", "nbytes", "__weakref__")
 
     def busy(self) -> bool:
         """A forward of this entry is still waiting for its backward (its state must not be overwritten)."""
@@ -289,50 +288,47 @@ class _TrainGraph:
 
 
 class _StepToken:
-    """Lives as long as the autograd node of one graphed forward."""
+    """Lives as long as the autograd node of one prepared forward."""
     __slots__ = ("consumed", "gen", "__weakref__")
 
     def __init__(self, gen):
         self.consumed, self.gen = False, gen
 
 
-class _GraphedRender(torch.autograd.Function):
-    """A training call replayed from HIP graphs: ONE autograd node, like the eager path's."""
+class _PreparedRender(torch.autograd.Function):
+    """A training call on a prepared step: ONE autograd node, like the eager path's; outputs and gradients are fresh
+    tensors, the state in between is the entry's."""
 
     @staticmethod
     def forward(ctx, entry, check, want_extra, extrinsics, means, scales, rotations, opacities, shs, shs_high):
+        import weakref
+
         from . import rasterizer as rz
         ctx.set_materialize_grads(False)
         step = entry.step
         entry.gen += 1
         token = _StepToken(entry.gen)
-        import weakref
         entry.token = weakref.ref(token)
         ctx.entry, ctx.token, ctx.check = entry, token, check
-        entry.g_project.replay()
-        early = None
-        if check == "early":
-            # the verdict is final behind the projection kernel: copied out there, waited for once everything else of the
-            # forward has been queued -- the GPU works through the wait
-            early = rz._early_verdict(step.dev)
-            early[0].copy_(step.counters[2:3], non_blocking=True)
-            early[1].record()
-        entry.g_render.replay()                      # sort + compositing (+ depth x near, in place on the graph's buffer)
-        # ONE copy-out: what the caller gets is the caller's (colour and depth share an allocation)
-        flat = step.img_dep.clone()
-        extra = (step.alpha.clone(), step.radii.view(step.alpha.shape[0], step.alpha.shape[1], -1).clone()) if want_extra \
-            else (None, None)
-        if early is not None:
-            early[1].synchronize()
-            if int(early[0][0]) != 0:
-                token.consumed = True
-                step.raise_if_failed()
-        n = step.image.numel()
-        color = flat[:n].view(step.image.shape)
-        depth = flat[n:].view(step.depth.shape[0], step.depth.shape[1], step.depth.shape[3], step.depth.shape[4])
+        with torch.cuda.device(step.dev):
+            entry.g_project.replay()
+            early = None
+            if check == "early":
+                # the verdict is final behind the projection kernel: copied out there, waited for once sort and compositing
+                # have been queued -- the GPU works through the wait
+                early = rz._early_verdict(step.dev)
+                early[0].copy_(step.counters[2:3], non_blocking=True)
+                early[1].record()
+            color, depth, alpha = step.render()
+            radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
+            if early is not None:
+                early[1].synchronize()
+                if early[0].item() != 0:
+                    token.consumed = True
+                    step.raise_if_failed()
         if want_extra:
-            ctx.mark_non_differentiable(extra[1])
-        return (color, depth) + extra
+            ctx.mark_non_differentiable(radii)
+        return color, depth, (alpha if want_extra else None), radii
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_alpha, _g_radii):
@@ -342,27 +338,20 @@ class _GraphedRender(torch.autograd.Function):
         step = entry.step
         if token.gen != entry.gen:
             raise RuntimeError("spfsplatv2_amd: this decoder call's saved state was overwritten by a later call of the same "
-                               "inputs (a second backward through a graph-replayed training call after a new forward); set "
-                               "decoder.train_graphs = False for such a loop")
+                               "inputs (a backward through a prepared training call after a NEWER forward of the same key); "
+                               "set decoder.train_graphs = False for such a loop")
         if ctx.check == "backward" and not token.consumed:
             step.raise_if_failed()                   # (one host sync, as in the eager path: a failed plan raises here)
-        replay = (not token.consumed and g_depth is None and g_alpha is None and g_color is not None
-                  and active_bucket() is None)
-        token.consumed = True
+        token.consumed = True                        # (a retained graph's second backward finds the same state: gen matches)
         need = ctx.needs_input_grad      # (entry, check, want_extra, extrinsics, means, scales, rotations, opacities, shs, shs_high)
-        if replay:
-            step.g_image.copy_(g_color)
-            entry.g_backward.replay()
-            # the gradients leave as ONE copy of the graph's flat gradient buffer (the graph's own pieces on request)
-            g = step.grads if entry.alias_grads else step.grad_views(step.grad_flat.clone())
+        if active_bucket() is None:
+            with torch.cuda.device(step.dev):
+                g = step.backward(g_color, g_depth, g_alpha)
             return (None, None, None, g.get("extrinsics") if need[3] else None, g["means"], g.get("scales"),
                     g.get("rotations"), g["opacities"], g.get("harmonics"), g.get("harmonics_band4"))
+        # a gradient bucket supplies the output buffers (shard.GradBucket): the general launcher, same state
         if g_depth is not None:
-            g_depth = g_depth[:, :, None]            # (the node's depth output is [b,v,h,w], already x near)
-            if step.scale_invariant:
-                g_depth = g_depth * step.near[:, :, None, None, None]
-        # anything else (a depth / alpha gradient, a gradient bucket, a second backward of a retained graph): the same
-        # kernels, launched one by one on the same state, into fresh buffers
+            g_depth = g_depth[:, :, None] * step.near_b if step.scale_invariant else g_depth[:, :, None]
         res = rz._backward_impl(step.inputs, step.state, step.geom, (g_color, g_depth, g_alpha),
                                 dict(step.want, view="partials" if step.want["view"] else False), shs_high=step.shs_high)
         d_means, d_scales, d_rot, d_opac, d_shs, _d_col, vpartial, _ = res[:8]
@@ -370,6 +359,7 @@ class _GraphedRender(torch.autograd.Function):
         d_ext = None
         if need[3] and vpartial is not None:
             import ctypes as C
+
             from . import _lib
             d_ext = torch.empty_like(step.view)
             with torch.cuda.device(step.dev):
@@ -438,22 +428,17 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self.auto_plan = _auto_plan_from_env()
         self.auto_plan_defer = os.environ.get("SPF_AUTO_PLAN_DEFER", "0") == "1"
         self._auto_verdict = None        # the one pinned word + event all of them use
-        # TRAINING calls (planned, something requires grad): the module records ONE autograd node per call either way; when
-        # a call's input addresses repeat (key as for evaluation calls, plus which inputs require grad) its launch chain is
-        # captured on static buffers -- projection | sort + compositing | the whole backward -- and later calls replay the
-        # three graphs: a step's ~9 launches, its allocations and struct marshalling leave the host's critical path
-        # (the driver's box in round 5: 0.4765 ms per C2 step through this module launched kernel by kernel, against 0.357
-        # for the same kernels replayed).  Results are bit-identical to the eager path.  One forward may be outstanding per
-        # key: a second forward before the first one's backward runs eagerly.  `train_graphs = False` /
-        # SPF_TRAIN_GRAPHS=0: off.  What a replayed call hands out -- colour, depth, alpha, radii, gradients -- are copies
-        # (one launch each way): nothing a caller holds is rewritten by a later call.
+        # TRAINING calls (planned, something requires grad): what the GPU runs per call is ~9 kernels of 5 - 130 us; what the
+        # host runs to launch them kernel by kernel -- validation, a dozen allocations, argument structs, autograd
+        # bookkeeping -- is longer than that on a slow host (the driver's box in round 5: 0.4765 ms per C2 step through
+        # this module against 0.357 for the same kernels replayed from a caller's graph).  So, when a call's input
+        # addresses repeat (key as for evaluation calls, plus which inputs require grad), the module PREPARES the step once
+        # (rasterizer.StaticStep: the chain's state at fixed addresses, argument structs built once; camera + projection +
+        # binning, which touch state only, captured in a HIP graph) and later calls are one graph replay plus three C-ABI
+        # calls.  Outputs and gradients are fresh tensors per call -- nothing a caller holds is rewritten, leaves may
+        # accumulate as ever --; results are bit-identical to the eager path.  One forward may be outstanding per key: a
+        # second forward before the first one's backward runs eagerly.  `train_graphs = False` / SPF_TRAIN_GRAPHS=0: off.
         self.train_graphs = os.environ.get("SPF_TRAIN_GRAPHS", "1") != "0"
-        # False (default): a replayed backward hands out a COPY of the graph's gradient buffer (one launch; 7 MB per C2
-        # step, 180 MB at the 2-view model's 16 x 131,072 Gaussians x 25 coefficients).  True: the graph's own buffers --
-        # right for the reference's model, whose decoder inputs are the encoder's outputs and whose producer consumes the
-        # gradients within the same backward; WRONG for leaves (or views of leaves) whose .grad is kept or accumulated
-        # across calls: the next backward of the key rewrites the memory such a .grad aliases.
-        self.train_graph_alias_grads = os.environ.get("SPF_TRAIN_GRAPH_ALIAS_GRADS", "0") == "1"
         self._train_graphs: dict = {}    # key -> _TrainGraph
         self._train_seen: dict = {}
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
@@ -543,7 +528,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                 self.make_scale_invariant, self.enable_cov_grad, self.enable_sh_grad)
 
     def _capture_train(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape):
-        """Build the static step and capture its three graphs; None (and train_graphs off) when that fails."""
+        """Prepare the static step and capture its state-only part; None (and train_graphs off) when that fails."""
         from .rasterizer import StaticStep, _direct_bin_cap, _f32c
         from ._lib import load
         h, w = image_shape
@@ -574,25 +559,15 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                                   self.make_scale_invariant, self.max_pairs, band4, want)
                 entry = _TrainGraph()
                 entry.step, entry.gen, entry.token = step, 0, None
-                entry.alias_grads = bool(self.train_graph_alias_grads)
-
-                def render_and_scale():
-                    step.launch_render()
-                    if self.make_scale_invariant:
-                        step.depth.mul_(near[:, :, None, None, None])      # decoder_splatting_cuda.py:72-76, in place
-                graphs = []
-                for launch in (step.launch_project, render_and_scale, step.launch_backward):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                        launch()
-                    graphs.append(g)
-                entry.g_project, entry.g_render, entry.g_backward = graphs
+                entry.g_project = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(entry.g_project, capture_error_mode="thread_local"):
+                    step.launch_project()
         except Exception as e:                      # noqa: BLE001
             import warnings
             self.train_graphs = False
             self._train_seen.pop(key, None)
-            warnings.warn(f"spfsplatv2_amd: capturing the training call in HIP graphs failed ({type(e).__name__}: {e}); this "
-                          "decoder launches its training calls kernel by kernel from now on")
+            warnings.warn(f"spfsplatv2_amd: preparing the training call (static state + HIP graph) failed ({type(e).__name__}: "
+                          f"{e}); this decoder launches its training calls the general way from now on")
             return None
         entry.record = CallRecord(counters=step.counters, plan=step.plan_info)
         entry.nbytes = step.nbytes
@@ -602,7 +577,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
 
     def _render_train_graph(self, entry, gaussians, extrinsics, near, want_extra: bool):
         check = self.max_pairs.check
-        color, depth, alpha, radii = _GraphedRender.apply(
+        color, depth, alpha, radii = _PreparedRender.apply(
             entry, check, want_extra, extrinsics, gaussians.means, gaussians.scales, gaussians.rotations,
             gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
         self.last_call = entry.record

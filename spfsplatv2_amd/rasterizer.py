@@ -619,15 +619,16 @@ class _DecoderRender(torch.autograd.Function):
 
 class StaticStep:
     """One planned decoder step (camera -> projection + bins -> sort -> composite; composite backward -> projection
-    backward -> pose chain) on buffers that are allocated ONCE: every launch reads and writes fixed addresses, so the
-    chain can be captured in HIP graphs and replayed -- `DecoderSplattingCUDA` does that for training calls whose input
-    addresses repeat (decoder.py).  Direct bins only (a plan with a list-length class); the inputs are borrowed by
-    address, exactly as a captured graph borrows them.
+    backward -> pose chain) PREPARED once: the state the chain keeps between its kernels (records, bins, tile bookkeeping,
+    per-pixel state, gradient records, pose partials) lives at fixed addresses, the argument structs are built once, and
+    what a call costs the host is a handful of C-ABI calls -- no allocation besides its OUTPUTS, no validation, no struct
+    marshalling.  Outputs (image | depth, alpha; every gradient) are fresh tensors per call: nothing a caller holds is
+    ever rewritten.  `DecoderSplattingCUDA` uses it for training calls whose input addresses repeat (decoder.py); the
+    inputs are borrowed by address, as a captured graph would borrow them.  Direct bins only.
 
-    `launch_project()` / `launch_render()`: the forward in the two pieces the "early" plan check sits between;
-    `launch_backward()`: reads `g_image` (the caller copies dL/dimage there), writes `grads` / `d_ext`.
-    `inputs` / `state` / `geom` are what `_backward_impl` takes: a backward that cannot run from the graph (a depth or
-    alpha gradient, a gradient bucket, a second backward) runs through it on the same state."""
+    `launch_project()` touches state only -- the decoder captures it (camera + projection) in a HIP graph; `render()` and
+    `backward()` launch eagerly into fresh outputs.  Between a `launch_project()` and the `backward()` that belongs to
+    it the state must stay as it is: one step at a time."""
 
     def __init__(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high, bg,
                  H, W, sh_degree, scale_invariant, plan: PairBudget, sh_band4, want: dict):
@@ -645,14 +646,18 @@ class StaticStep:
         K = 25 if layout == 2 else shs.shape[3]
         rec_cap = _record_capacity(int(plan.capacity), S, G)
         self.dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, 1.0, layout, int(bool(sh_band4)), bin_cap, rec_cap)
+        self.shape = (S, V, G, H, W)
         f32 = dict(dtype=torch.float32, device=dev)
+        self.f32 = f32
         self.view, self.proj = torch.empty((S, V, 4, 4), **f32), torch.empty((S, V, 4, 4), **f32)
         self.tanfov = torch.empty((S, V, 2), **f32)
         self.vscale = torch.empty((S, V), **f32) if scale_invariant else None
         self.view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
         nblk = lib.spf_raster_view_partial_blocks(G)
-        (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib, self.image, self.depth,
-         self.alpha, self.img_dep) = _alloc_forward(dev, S, V, G, H, W, T, nblk)
+        (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib, _i, _d, _a,
+         _f) = _alloc_forward(dev, S, V, G, 1, 1, T, nblk)       # (state only: the H x W outputs are the calls' own)
+        self.final_T = torch.empty((R * H * W,), **f32)
+        self.n_contrib = torch.empty((R * H * W,), dtype=torch.int32, device=dev)
         if self.tiles.data_ptr() % 16:
             raise RuntimeError("StaticStep: the tile bookkeeping buffer is not 16-byte aligned")
         self.pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev)
@@ -674,14 +679,13 @@ class StaticStep:
                                   _ptr(self.view64), _ptr(shs_high))
         self.st = _state_struct(self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T,
                                 self.n_contrib, R * T, R * G, R * nblk)
-        self.out = _lib.SpfOutputs(_ptr(self.image), _ptr(self.depth), _ptr(self.alpha))
+        self.out = _lib.SpfOutputs(None, None, None)
         self.max_tile = int(plan.max_tile_list)
+        self.near_b = near[:, :, None, None, None]               # depth x near (decoder_splatting_cuda.py:72-76)
         # ---- backward ----
         self.want = dict(want)
-        self.g_image = torch.empty((S, V, 3, H, W), **f32)
         self.gpair = torch.empty((rec_cap, 10), **f32)
-        # every gradient the chain writes lives in ONE flat allocation (16-byte aligned pieces): a call hands out a copy --
-        # one launch -- or, on request, the pieces themselves (see DecoderSplattingCUDA.train_graph_alias_grads)
+        # every gradient of a call lives in ONE fresh flat allocation (16-byte aligned pieces)
         like = {"means": means3D, "opacities": opacities}
         if want["scales_rot"]:
             like["scales"], like["rotations"] = scales, rotations
@@ -691,36 +695,22 @@ class StaticStep:
                 like["harmonics_band4"] = shs_high
         if want["view"]:
             like["extrinsics"] = self.view
-        offs, n = {}, 0
+        self.grad_layout, n = {}, 0
         for name, t in like.items():
-            offs[name] = n
+            self.grad_layout[name] = (n, t.numel(), tuple(t.shape))
             n += (t.numel() + 3) & ~3
-        self.grad_flat = torch.empty((max(n, 4),), **f32)
-        self.grad_layout = {name: (offs[name], tuple(t.shape)) for name, t in like.items()}
-        g = self.grad_views(self.grad_flat)
-        self.grads = g
+        self.grad_numel = max(n, 4)
         self.vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
-        self.d_ext = g.get("extrinsics")
-        self.gr = _lib.SpfGrads(_ptr(self.g_image), None, None, _ptr(self.gpair), _ptr(self.vpartial), _ptr(g["means"]),
-                                _ptr(g.get("scales")), _ptr(g.get("rotations")), _ptr(g["opacities"]),
-                                _ptr(g.get("harmonics")), None, None, None, _ptr(g.get("harmonics_band4")))
+        self.gr = _lib.SpfGrads(None, None, None, _ptr(self.gpair), _ptr(self.vpartial))
         self.cam_b = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(self.view), None, None, None, R,
                                     1 if scale_invariant else 0)
         self.nblk = nblk
         self.nbytes = sum(t.numel() * t.element_size() for t in
                           (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
-                           self.img_dep, self.alpha, self.pairs, self.g_image, self.gpair, self.grad_flat))
-
-    def grad_views(self, flat: Tensor) -> dict:
-        out = {}
-        for name, (off, shape) in self.grad_layout.items():
-            numel = 1
-            for d in shape:
-                numel *= d
-            out[name] = flat[off:off + numel].view(shape)
-        return out
+                           self.pairs, self.gpair))
 
     def launch_project(self) -> None:
+        """Camera set-up + clearing of the tile bookkeeping, projection + binning (state only: capturable)."""
         lib, stream = self.lib, _stream_ptr(self.dev)
         _lib.check(lib.spf_decoder_prepare(C.byref(self.cam), _ptr(self.tiles), 4 * self.tiles.numel(), stream),
                    "spf_decoder_prepare")
@@ -728,18 +718,42 @@ class StaticStep:
                                                            4 * self.tiles.numel(), stream),
                    "spf_raster_forward_project_prepared")
 
-    def launch_render(self) -> None:
+    def render(self):
+        """Sort + compositing into FRESH outputs: (colour [S,V,3,H,W], depth [S,V,H,W] -- x near when scale-invariant --,
+        alpha [S,V,1,H,W])."""
+        S, V, G, H, W = self.shape
+        n = S * V * 3 * H * W
+        img_dep = torch.empty((n + S * V * H * W,), **self.f32)
+        alpha = torch.empty((S, V, 1, H, W), **self.f32)
+        self.out.image, self.out.depth, self.out.alpha = img_dep.data_ptr(), img_dep.data_ptr() + 4 * n, alpha.data_ptr()
         _lib.check(self.lib.spf_raster_forward_render(C.byref(self.dims), C.byref(self.inp), C.byref(self.st),
                                                       C.byref(self.out), self.capacity, self.max_tile, 0xFFFFFFFF,
                                                       _stream_ptr(self.dev)), "spf_raster_forward_render")
+        depth = img_dep[n:].view(S, V, 1, H, W)
+        if self.scale_invariant:
+            depth.mul_(self.near_b)
+        return img_dep[:n].view(S, V, 3, H, W), depth.view(S, V, H, W), alpha
 
-    def launch_backward(self) -> None:
+    def backward(self, g_image, g_depth, g_alpha) -> dict:
+        """The whole backward chain into a fresh flat gradient buffer; returns {name: gradient} (`extrinsics`: the poses')."""
+        c = lambda g: None if g is None else g.contiguous().float()
+        g_image, g_alpha = c(g_image), c(g_alpha)
+        if g_depth is not None:                          # (the node's depth output is [S,V,H,W], already x near)
+            g_depth = c(g_depth * self.near_b[:, :, 0] if self.scale_invariant else g_depth)
+        flat = torch.empty((self.grad_numel,), **self.f32)
+        g = {name: flat[off:off + numel].view(shape) for name, (off, numel, shape) in self.grad_layout.items()}
+        gr = self.gr
+        gr.dL_dimage, gr.dL_ddepth, gr.dL_dalpha = _ptr(g_image), _ptr(g_depth), _ptr(g_alpha)
+        gr.dL_dmeans3D, gr.dL_dopacities = _ptr(g["means"]), _ptr(g["opacities"])
+        gr.dL_dscales, gr.dL_drotations = _ptr(g.get("scales")), _ptr(g.get("rotations"))
+        gr.dL_dshs, gr.dL_dshs_high = _ptr(g.get("harmonics")), _ptr(g.get("harmonics_band4"))
         lib, stream = self.lib, _stream_ptr(self.dev)
-        _lib.check(lib.spf_raster_backward(C.byref(self.dims), C.byref(self.inp), C.byref(self.st), C.byref(self.gr),
+        _lib.check(lib.spf_raster_backward(C.byref(self.dims), C.byref(self.inp), C.byref(self.st), C.byref(gr),
                                            self.capacity, 0xFFFFFFFF, stream), "spf_raster_backward")
-        if self.d_ext is not None:
+        if "extrinsics" in g:
             _lib.check(lib.spf_camera_backward_partials(C.byref(self.cam_b), _ptr(self.vpartial), self.nblk,
-                                                        _ptr(self.d_ext), stream), "spf_camera_backward_partials")
+                                                        _ptr(g["extrinsics"]), stream), "spf_camera_backward_partials")
+        return g
 
     def raise_if_failed(self) -> None:
         _raise_if_plan_failed(self.tiles[4 * self.RT + 1:], self.capacity, self.plan_info)
