@@ -152,6 +152,13 @@ typedef struct SpfState {
                                         coefficients BEFORE the basis derivatives (three accumulators instead of twelve: the
                                         degree-4 kernel fits two waves per SIMD) and so needs the clamp decision up front
                                         instead of re-evaluating the colour */
+    uint32_t* verdict_host; /* [1]      may be NULL.  A HOST-MAPPED word (hipHostMalloc / pinned memory, device-accessible) that
+                                        the projection kernel of a direct-bins call stores a non-zero value to when it raises
+                                        a plan flag (counters[2]); the caller zeroes it before the call.  A host that wants the
+                                        verdict EARLY then needs no device->host copy on the stream (a 4-byte copy is a trip
+                                        through the copy engine that the next kernel of the stream waits for): it records
+                                        an event behind spf_raster_forward_project*, queues the rest of the chain, waits for the
+                                        event and reads the word */
 } SpfState;
 
 typedef struct SpfOutputs {

@@ -741,14 +741,21 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                   }
           }
           if (threadIdx.x == 0) {
-              if ((uint64_t)at + tot > shard_cap) atomicOr(&st.counters[2], 1u);        // gradient records would not fit
+              if ((uint64_t)at + tot > shard_cap) {                                     // gradient records would not fit
+                  atomicOr(&st.counters[2], 1u);
+                  if (st.verdict_host) __hip_atomic_store(st.verdict_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              }
               s_vbase[VG] = (uint32_t)shard_base + at;
           }
           longest = wave_max_u32(longest);
           // (counters[1], the longest list, is NOT maintained with direct bins: one word visited by every wave of the launch
           //  -- 8,192 atomicMax, or even 8,192 write-through loads to look first -- serialises at ~11 ns each: 55 us / 180 us
           //  measured on a 52 us kernel.  The verdict the plan needs is local: a bin that overflows raises flag 2.)
-          if (lane == 0 && longest > (uint32_t)d.bin_cap) atomicOr(&st.counters[2], 2u);
+          if (lane == 0 && longest > (uint32_t)d.bin_cap) {
+              atomicOr(&st.counters[2], 2u);
+              // (a host that wants the verdict early reads this host-mapped word behind an event: any non-zero value)
+              if (st.verdict_host) __hip_atomic_store(st.verdict_host, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
           __syncthreads();
           const uint32_t pbase = s_vbase[VG];
           for (int vi = 0; vi < nv; ++vi) {

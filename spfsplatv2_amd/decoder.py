@@ -311,19 +311,19 @@ class _PreparedRender(torch.autograd.Function):
         entry.token = weakref.ref(token)
         ctx.entry, ctx.token, ctx.check = entry, token, check
         with torch.cuda.device(step.dev):
+            early = check == "early"
+            if early:
+                step.verdict.zero_()                 # (host memory: the projection kernel stores here if it raises a flag)
             entry.g_project.replay()
-            early = None
-            if check == "early":
-                # the verdict is final behind the projection kernel: copied out there, waited for once sort and compositing
-                # have been queued -- the GPU works through the wait
-                early = rz._early_verdict(step.dev)
-                early[0].copy_(step.counters[2:3], non_blocking=True)
-                early[1].record()
+            if early:
+                # the verdict is final behind the projection kernel: an event there, waited for once sort and compositing
+                # have been queued -- the GPU works through the wait, and nothing is copied on the stream
+                step.verdict_event.record()
             color, depth, alpha = step.render()
             radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
-            if early is not None:
-                early[1].synchronize()
-                if early[0].item() != 0:
+            if early:
+                step.verdict_event.synchronize()
+                if step.verdict.item() != 0:
                     token.consumed = True
                     step.raise_if_failed()
         if want_extra:

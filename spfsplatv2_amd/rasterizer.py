@@ -275,7 +275,14 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
                          _ptr(view_scale), _ptr(view64), _ptr(shs_high))
     pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev) if bin_cap else None
-    st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
+    # check="early" with direct bins: the projection kernel mirrors a raised plan flag into a pinned word the host reads
+    # behind an event -- no device->host copy on the stream (SpfState.verdict_host)
+    early = None
+    if isinstance(max_pairs, PairBudget) and max_pairs.check == "early" and not torch.cuda.is_current_stream_capturing():
+        early = _early_verdict(dev)
+        early[0].zero_()
+    st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk,
+                       verdict_host=early[0] if (early is not None and bin_cap) else None)
     stream = _stream_ptr(dev)
     if camera is not None and tiles.data_ptr() % 16 == 0:
         # camera set-up and the clearing of ALL the tile bookkeeping in one kernel (the scan then needs no single-block
@@ -306,12 +313,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         rec_out["counters"] = counters
         _last["counters"] = counters
         rec_out["plan"] = _last["plan"] = (int(bin_cap), int(capacity), lib.spf_raster_pair_shards(S, G) if bin_cap else 1)
-    early = None
-    if isinstance(max_pairs, PairBudget) and max_pairs.check == "early" and not torch.cuda.is_current_stream_capturing():
-        early = _early_verdict(dev)
-        if bin_cap:      # direct bins: the projection kernel has binned -- the verdict is final behind it
-            early[0].copy_(counters[2:3], non_blocking=True)
-            early[1].record()
+    if early is not None and bin_cap:      # direct bins: the projection kernel has binned -- the verdict is final behind it
+        early[1].record()
     if not bin_cap:
         pairs = torch.empty((max(capacity, 1),), dtype=torch.int64, device=dev)
         st.pairs = _ptr(pairs)
@@ -322,7 +325,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     if early is not None:
         if bin_cap:
             early[1].synchronize()                   # (waits for the projection kernel and 4 bytes, not for the chain)
-            failed = int(early[0][0]) != 0
+            failed = early[0].item() != 0
         else:
             failed = True                            # classic chain: the binning kernel decides -- read it the slow way
         if failed:
@@ -412,7 +415,7 @@ class _spf_errors:
         return False
 
 
-def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB):
+def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB, verdict_host=None):
     cursor = tiles[4 * RT + 5:4 * RT + 13] if tiles.numel() >= 4 * RT + 13 else None   # (the compiled binding's buffer has none)
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
                          _ptr(tiles[2 * RT:3 * RT + 1]),
@@ -420,7 +423,7 @@ def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, 
                          _ptr(tiles[4 * RT + 1:4 * RT + 5]), _ptr(pairs),
                          _ptr(pair_idx[:2 * RG]), _ptr(pair_idx[2 * RG:2 * RG + RB]), _ptr(pair_idx[2 * RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib), _ptr(cursor),
-                         _ptr(rect[2 * RG:]) if rect.numel() > 2 * RG else None)
+                         _ptr(rect[2 * RG:]) if rect.numel() > 2 * RG else None, _ptr(verdict_host))
 
 
 def _raise_if_plan_failed(counters: Tensor, capacity: int, plan=None) -> None:
@@ -677,8 +680,10 @@ class StaticStep:
         self.inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), None,
                                   _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov), _ptr(bgx), _ptr(self.vscale),
                                   _ptr(self.view64), _ptr(shs_high))
+        self.verdict = torch.zeros(1, dtype=torch.int32, pin_memory=True)      # SpfState.verdict_host: baked into the graph
+        self.verdict_event = torch.cuda.Event()
         self.st = _state_struct(self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T,
-                                self.n_contrib, R * T, R * G, R * nblk)
+                                self.n_contrib, R * T, R * G, R * nblk, verdict_host=self.verdict)
         self.out = _lib.SpfOutputs(None, None, None)
         self.max_tile = int(plan.max_tile_list)
         self.near_b = near[:, :, None, None, None]               # depth x near (decoder_splatting_cuda.py:72-76)
