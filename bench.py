@@ -811,7 +811,7 @@ def main():
         # library's stage events see nothing): the per-stage survey is taken from eager launches first
         _lib.stage_timing_enable(True)
         for m in micro:
-            m.decoder.train_graphs = False
+            m.decoder.prepare_steps = False
         n_survey = max(args.warmup, 3)
         for _ in range(n_survey):
             step()
@@ -819,7 +819,7 @@ def main():
         module_survey = {k: (v[0] / n_survey, 1) for k, v in _lib.stage_times().items() if k != "rope2d" and v[1] > 0}
         _lib.stage_timing_enable(False)
         for m in micro:
-            m.decoder.train_graphs = os.environ.get("SPF_TRAIN_GRAPHS", "1") != "0"
+            m.decoder.prepare_steps = os.environ.get("SPF_PREPARE_STEPS", "1") != "0"
     else:
         module_survey = None
     D_total = sum(m.record["num_pairs"] for m in micro)

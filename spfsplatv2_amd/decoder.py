@@ -276,10 +276,10 @@ class _EvalGraph:
         self.graph, self.outputs, self.record = graph, outputs, record
 
 
-class _TrainGraph:
+class _PreparedStep:
     """One prepared TRAINING call of a decoder: the static step (state at fixed addresses, argument structs built once:
-    rasterizer.StaticStep) and the captured graph of its state-only part -- camera set-up + projection + binning."""
-    __slots__ = ("step", "g_project", "record", "gen", "token", "nbytes", "__weakref__")
+    rasterizer.StaticStep) and who holds it at the moment."""
+    __slots__ = ("step", "record", "gen", "token", "nbytes", "__weakref__")
 
     def busy(self) -> bool:
         """A forward of this entry is still waiting for its backward (its state must not be overwritten)."""
@@ -314,7 +314,7 @@ class _PreparedRender(torch.autograd.Function):
             early = check == "early"
             if early:
                 step.verdict.zero_()                 # (host memory: the projection kernel stores here if it raises a flag)
-            entry.g_project.replay()
+            step.launch_project()
             if early:
                 # the verdict is final behind the projection kernel: an event there, waited for once sort and compositing
                 # have been queued -- the GPU works through the wait, and nothing is copied on the stream
@@ -339,7 +339,7 @@ class _PreparedRender(torch.autograd.Function):
         if token.gen != entry.gen:
             raise RuntimeError("spfsplatv2_amd: this decoder call's saved state was overwritten by a later call of the same "
                                "inputs (a backward through a prepared training call after a NEWER forward of the same key); "
-                               "set decoder.train_graphs = False for such a loop")
+                               "set decoder.prepare_steps = False for such a loop")
         if ctx.check == "backward" and not token.consumed:
             step.raise_if_failed()                   # (one host sync, as in the eager path: a failed plan raises here)
         token.consumed = True                        # (a retained graph's second backward finds the same state: gen matches)
@@ -429,18 +429,16 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self.auto_plan_defer = os.environ.get("SPF_AUTO_PLAN_DEFER", "0") == "1"
         self._auto_verdict = None        # the one pinned word + event all of them use
         # TRAINING calls (planned, something requires grad): what the GPU runs per call is ~9 kernels of 5 - 130 us; what the
-        # host runs to launch them kernel by kernel -- validation, a dozen allocations, argument structs, autograd
-        # bookkeeping -- is longer than that on a slow host (the driver's box in round 5: 0.4765 ms per C2 step through
-        # this module against 0.357 for the same kernels replayed from a caller's graph).  So, when a call's input
-        # addresses repeat (key as for evaluation calls, plus which inputs require grad), the module PREPARES the step once
-        # (rasterizer.StaticStep: the chain's state at fixed addresses, argument structs built once; camera + projection +
-        # binning, which touch state only, captured in a HIP graph) and later calls are one graph replay plus three C-ABI
-        # calls.  Outputs and gradients are fresh tensors per call -- nothing a caller holds is rewritten, leaves may
-        # accumulate as ever --; results are bit-identical to the eager path.  One forward may be outstanding per key: a
-        # second forward before the first one's backward runs eagerly.  `train_graphs = False` / SPF_TRAIN_GRAPHS=0: off.
-        self.train_graphs = os.environ.get("SPF_TRAIN_GRAPHS", "1") != "0"
-        self._train_graphs: dict = {}    # key -> _TrainGraph
-        self._train_seen: dict = {}
+        # host runs to launch them the general way -- validation, a dozen allocations, argument structs, autograd
+        # bookkeeping of 21 saved tensors -- approaches that on a slow host.  So, when a call's input addresses repeat (key as
+        # for evaluation calls, plus which inputs require grad), the module PREPARES the step once (rasterizer.StaticStep:
+        # the chain's state at fixed addresses, argument structs built once) and later calls are five C-ABI calls.  Outputs
+        # and gradients are fresh tensors per call -- nothing a caller holds is rewritten, leaves accumulate as ever --;
+        # results are bit-identical to the general path.  One forward may be outstanding per key: a second forward before
+        # the first one's backward takes the general path.  `prepare_steps = False` / SPF_PREPARE_STEPS=0: off.
+        self.prepare_steps = os.environ.get("SPF_PREPARE_STEPS", "1") != "0"
+        self._prepared_steps: dict = {}    # key -> _PreparedStep
+        self._prepare_seen: dict = {}
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
         self._graph_seen: dict = {}      # key -> None: keys seen once, not yet captured
         self._graph_unused = 0           # captures since the last replay hit
@@ -466,7 +464,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
 
     # a decoder is copied (EMA: copy.deepcopy(model)) and pickled (torch.save(model)) like any module -- both go through
     # __getstate__: captured graphs, events and pinned words stay with the original
-    _TRANSIENT = ("_graphs", "_graph_seen", "_auto_verdict", "_auto_pending", "_train_graphs", "_train_seen")
+    _TRANSIENT = ("_graphs", "_graph_seen", "_auto_verdict", "_auto_pending", "_prepared_steps", "_prepare_seen")
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -501,17 +499,17 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self._graph_seen.clear()
         self._graph_unused = 0
 
-    def clear_train_graphs(self) -> None:
-        self._train_graphs.clear()
-        self._train_seen.clear()
+    def clear_prepared_steps(self) -> None:
+        self._prepared_steps.clear()
+        self._prepare_seen.clear()
 
-    _TRAIN_GRAPH_SLOTS = 2
+    _PREPARED_SLOTS = 2
 
-    def _train_graph_key(self, tensors, image_shape):
-        """None unless this call may run from captured training graphs: planned with a list-length class (direct bins),
+    def _prepare_key(self, tensors, image_shape):
+        """None unless this call may run on a prepared step: planned with a list-length class (direct bins),
         gradients wanted, dense float32 device tensors, no capture going on, no gradient bucket waiting for the backward."""
         plan = self.max_pairs
-        if not (self.train_graphs and isinstance(plan, PairBudget) and plan.max_tile_list > 0):
+        if not (self.prepare_steps and isinstance(plan, PairBudget) and plan.max_tile_list > 0):
             return None
         if not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
             return None
@@ -527,8 +525,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                 tuple(image_shape), int(plan.capacity), int(plan.max_tile_list), band4, self.background_color.data_ptr(),
                 self.make_scale_invariant, self.enable_cov_grad, self.enable_sh_grad)
 
-    def _capture_train(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape):
-        """Prepare the static step and capture its state-only part; None (and train_graphs off) when that fails."""
+    def _prepare_step(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape):
+        """Prepare the static step; None (and prepare_steps off) when that fails."""
         from .rasterizer import StaticStep, _direct_bin_cap, _f32c
         from ._lib import load
         h, w = image_shape
@@ -550,32 +548,29 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         want = dict(scales_rot=self.enable_cov_grad and (gaussians.scales.requires_grad or gaussians.rotations.requires_grad),
                     shs=self.enable_sh_grad and gaussians.harmonics.requires_grad, colors=False,
                     view=bool(extrinsics.requires_grad), means2D=False)
-        while len(self._train_graphs) >= self._TRAIN_GRAPH_SLOTS:
-            self._train_graphs.pop(next(iter(self._train_graphs)))
+        while len(self._prepared_steps) >= self._PREPARED_SLOTS:
+            self._prepared_steps.pop(next(iter(self._prepared_steps)))
         try:
             with torch.no_grad(), torch.cuda.device(extrinsics.device):
                 step = StaticStep(extrinsics, intrinsics, near, far, gaussians.means, gaussians.scales, gaussians.rotations,
                                   gaussians.opacities, gaussians.harmonics, high, self.background_color, h, w, isqrt(n) - 1,
                                   self.make_scale_invariant, self.max_pairs, band4, want)
-                entry = _TrainGraph()
+                entry = _PreparedStep()
                 entry.step, entry.gen, entry.token = step, 0, None
-                entry.g_project = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(entry.g_project, capture_error_mode="thread_local"):
-                    step.launch_project()
         except Exception as e:                      # noqa: BLE001
             import warnings
-            self.train_graphs = False
-            self._train_seen.pop(key, None)
-            warnings.warn(f"spfsplatv2_amd: preparing the training call (static state + HIP graph) failed ({type(e).__name__}: "
-                          f"{e}); this decoder launches its training calls the general way from now on")
+            self.prepare_steps = False
+            self._prepare_seen.pop(key, None)
+            warnings.warn(f"spfsplatv2_amd: preparing the training call failed ({type(e).__name__}: {e}); this decoder "
+                          "launches its training calls the general way from now on")
             return None
         entry.record = CallRecord(counters=step.counters, plan=step.plan_info)
         entry.nbytes = step.nbytes
-        self._train_graphs[key] = entry
-        self._train_seen.pop(key, None)
+        self._prepared_steps[key] = entry
+        self._prepare_seen.pop(key, None)
         return entry
 
-    def _render_train_graph(self, entry, gaussians, extrinsics, near, want_extra: bool):
+    def _render_prepared(self, entry, gaussians, extrinsics, near, want_extra: bool):
         check = self.max_pairs.check
         color, depth, alpha, radii = _PreparedRender.apply(
             entry, check, want_extra, extrinsics, gaussians.means, gaussians.scales, gaussians.rotations,
@@ -674,17 +669,17 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         return result
 
     def _render_planned(self, tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
-        tkey = self._train_graph_key(tensors, image_shape)
+        tkey = self._prepare_key(tensors, image_shape)
         if tkey is not None:
-            entry = self._train_graphs.get(tkey)
-            if entry is None and tkey in self._train_seen:
-                entry = self._capture_train(tkey, gaussians, extrinsics, intrinsics, near, far, image_shape)
+            entry = self._prepared_steps.get(tkey)
+            if entry is None and tkey in self._prepare_seen:
+                entry = self._prepare_step(tkey, gaussians, extrinsics, intrinsics, near, far, image_shape)
             elif entry is None:
-                if len(self._train_seen) >= 64:
-                    self._train_seen.clear()
-                self._train_seen[tkey] = None            # first sight: run as usual; the second call of the key is captured
+                if len(self._prepare_seen) >= 64:
+                    self._prepare_seen.clear()
+                self._prepare_seen[tkey] = None            # first sight: run as usual; the second call of the key is captured
             if entry is not None and not entry.busy():
-                return self._render_train_graph(entry, gaussians, extrinsics, near, want_extra)
+                return self._render_prepared(entry, gaussians, extrinsics, near, want_extra)
         key = self._eval_graph_key(tensors, image_shape)
         if key is None:
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,

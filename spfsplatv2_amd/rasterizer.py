@@ -629,9 +629,12 @@ class StaticStep:
     ever rewritten.  `DecoderSplattingCUDA` uses it for training calls whose input addresses repeat (decoder.py); the
     inputs are borrowed by address, as a captured graph would borrow them.  Direct bins only.
 
-    `launch_project()` touches state only -- the decoder captures it (camera + projection) in a HIP graph; `render()` and
-    `backward()` launch eagerly into fresh outputs.  Between a `launch_project()` and the `backward()` that belongs to
-    it the state must stay as it is: one step at a time."""
+    `launch_project()` touches state only; `render()` and `backward()` write fresh outputs.  Between a
+    `launch_project()` and the `backward()` that belongs to it the state must stay as it is: one step at a time.
+    (Round 6 measured the same chain replayed from three HIP graphs with copies in and out -- no faster on the host, the
+    copies cost the GPU 8 - 290 us per step -- and its state-only part from one small graph: a two-kernel hipGraphLaunch
+    costs MORE host time than the two launches.  The step's host cost is allocation, validation and marshalling; that is
+    what is prepared here.)"""
 
     def __init__(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high, bg,
                  H, W, sh_degree, scale_invariant, plan: PairBudget, sh_band4, want: dict):
@@ -680,17 +683,16 @@ class StaticStep:
         self.inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), None,
                                   _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov), _ptr(bgx), _ptr(self.vscale),
                                   _ptr(self.view64), _ptr(shs_high))
-        self.verdict = torch.zeros(1, dtype=torch.int32, pin_memory=True)      # SpfState.verdict_host: baked into the graph
+        self.verdict = torch.zeros(1, dtype=torch.int32, pin_memory=True)      # SpfState.verdict_host
         self.verdict_event = torch.cuda.Event()
         self.st = _state_struct(self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T,
                                 self.n_contrib, R * T, R * G, R * nblk, verdict_host=self.verdict)
         self.out = _lib.SpfOutputs(None, None, None)
         self.max_tile = int(plan.max_tile_list)
-        self.near_b = near[:, :, None, None, None]               # depth x near (decoder_splatting_cuda.py:72-76)
+        self.near_b = near[:, :, None, None]                     # depth x near (decoder_splatting_cuda.py:72-76)
         # ---- backward ----
         self.want = dict(want)
         self.gpair = torch.empty((rec_cap, 10), **f32)
-        # every gradient of a call lives in ONE fresh flat allocation (16-byte aligned pieces)
         like = {"means": means3D, "opacities": opacities}
         if want["scales_rot"]:
             like["scales"], like["rotations"] = scales, rotations
@@ -700,11 +702,7 @@ class StaticStep:
                 like["harmonics_band4"] = shs_high
         if want["view"]:
             like["extrinsics"] = self.view
-        self.grad_layout, n = {}, 0
-        for name, t in like.items():
-            self.grad_layout[name] = (n, t.numel(), tuple(t.shape))
-            n += (t.numel() + 3) & ~3
-        self.grad_numel = max(n, 4)
+        self.grad_shapes = {name: tuple(t.shape) for name, t in like.items()}
         self.vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
         self.gr = _lib.SpfGrads(None, None, None, _ptr(self.gpair), _ptr(self.vpartial))
         self.cam_b = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(self.view), None, None, None, R,
@@ -727,29 +725,27 @@ class StaticStep:
         """Sort + compositing into FRESH outputs: (colour [S,V,3,H,W], depth [S,V,H,W] -- x near when scale-invariant --,
         alpha [S,V,1,H,W])."""
         S, V, G, H, W = self.shape
-        n = S * V * 3 * H * W
-        img_dep = torch.empty((n + S * V * H * W,), **self.f32)
+        color = torch.empty((S, V, 3, H, W), **self.f32)
+        depth = torch.empty((S, V, H, W), **self.f32)
         alpha = torch.empty((S, V, 1, H, W), **self.f32)
-        self.out.image, self.out.depth, self.out.alpha = img_dep.data_ptr(), img_dep.data_ptr() + 4 * n, alpha.data_ptr()
+        self.out.image, self.out.depth, self.out.alpha = color.data_ptr(), depth.data_ptr(), alpha.data_ptr()
         _lib.check(self.lib.spf_raster_forward_render(C.byref(self.dims), C.byref(self.inp), C.byref(self.st),
                                                       C.byref(self.out), self.capacity, self.max_tile, 0xFFFFFFFF,
                                                       _stream_ptr(self.dev)), "spf_raster_forward_render")
-        depth = img_dep[n:].view(S, V, 1, H, W)
         if self.scale_invariant:
             depth.mul_(self.near_b)
-        return img_dep[:n].view(S, V, 3, H, W), depth.view(S, V, H, W), alpha
+        return color, depth, alpha
 
     def backward(self, g_image, g_depth, g_alpha) -> dict:
-        """The whole backward chain into a fresh flat gradient buffer; returns {name: gradient} (`extrinsics`: the poses')."""
+        """The whole backward chain into fresh gradient tensors; returns {name: gradient} (`extrinsics`: the poses')."""
         c = lambda g: None if g is None else g.contiguous().float()
         g_image, g_alpha = c(g_image), c(g_alpha)
         if g_depth is not None:                          # (the node's depth output is [S,V,H,W], already x near)
-            g_depth = c(g_depth * self.near_b[:, :, 0] if self.scale_invariant else g_depth)
-        flat = torch.empty((self.grad_numel,), **self.f32)
-        g = {name: flat[off:off + numel].view(shape) for name, (off, numel, shape) in self.grad_layout.items()}
+            g_depth = c(g_depth * self.near_b if self.scale_invariant else g_depth)
+        g = {name: torch.empty(shape, **self.f32) for name, shape in self.grad_shapes.items()}
         gr = self.gr
         gr.dL_dimage, gr.dL_ddepth, gr.dL_dalpha = _ptr(g_image), _ptr(g_depth), _ptr(g_alpha)
-        gr.dL_dmeans3D, gr.dL_dopacities = _ptr(g["means"]), _ptr(g["opacities"])
+        gr.dL_dmeans3D, gr.dL_dopacities = g["means"].data_ptr(), g["opacities"].data_ptr()
         gr.dL_dscales, gr.dL_drotations = _ptr(g.get("scales")), _ptr(g.get("rotations"))
         gr.dL_dshs, gr.dL_dshs_high = _ptr(g.get("harmonics")), _ptr(g.get("harmonics_band4"))
         lib, stream = self.lib, _stream_ptr(self.dev)

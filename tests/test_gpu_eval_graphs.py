@@ -217,7 +217,7 @@ def test_auto_plan_deferred_training_reads_the_verdict_one_call_late(hip_lib):
     assert torch.equal(c, want_big[0]) and spf.plan_flags(d.last_call) == 0
 
 
-# ---- training calls: the module's own HIP graphs (round 6) -----------------------------------------------------------
+# ---- training calls: the module's prepared steps (round 6) ----------------------------------------------------------
 def _train_setup(seed=31, split=False):
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec
@@ -253,23 +253,23 @@ def _same(a, b):
 
 @pytest.mark.parametrize("split", [False, True], ids=["dense_sh", "split_sh"])
 def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
-    """VERDICT r5 task 5: a planned training call whose input addresses repeat is captured (projection | sort + compositing
-    | backward) and replayed -- images, depth and every gradient bit-identical to the eager path; what a call returned
-    stays the caller's; an in-place update of an input (an optimizer step) is seen by the replay; a depth gradient, a
-    retained graph's second backward and a forward issued before the previous backward all take the eager kernels on the
-    same state and give the same numbers."""
+    """VERDICT r5 task 5: a planned training call whose input addresses repeat runs on a PREPARED step (static state,
+    argument structs built once: five C-ABI calls) -- images, depth and every gradient bit-identical to the general path;
+    what a call returned stays the caller's; an in-place update of an input (an optimizer step) is seen; a depth gradient
+    and a retained graph's second backward give the same numbers, and a forward issued before the previous backward takes
+    the general path."""
     spf, b, leaves, g, plan, step, w = _train_setup(split=split)
     eager, d = util.product_decoder(max_pairs=plan), util.product_decoder(max_pairs=plan)
-    eager.train_graphs = False
+    eager.prepare_steps = False
     want = step(eager)
     first = step(d)
-    assert not d._train_graphs and _same(first, want)                 # first sight of the key: launched as usual
+    assert not d._prepared_steps and _same(first, want)                 # first sight of the key: launched as usual
     second = step(d)
-    assert len(d._train_graphs) == 1 and _same(second, want)          # captured, replayed
+    assert len(d._prepared_steps) == 1 and _same(second, want)          # captured, replayed
     held = second[0].color.clone()
     third = step(d)
     assert _same(third, want) and torch.equal(second[0].color, held) and third[0].color.data_ptr() != second[0].color.data_ptr()
-    assert spf.plan_flags(d.last_call) == 0 and eager._train_graphs == {}
+    assert spf.plan_flags(d.last_call) == 0 and eager._prepared_steps == {}
     # an optimizer step: same addresses, new values
     with torch.no_grad():
         leaves["means"].add_(0.01 * torch.randn_like(leaves["means"]))
@@ -294,15 +294,15 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
     ref = step(eager)
     assert torch.equal(o1.color, o2.color) and torch.equal(o1.color, ref[0].color)
     assert all(util.rel_linf(both[n], 2 * ref[2][n]) < 1e-6 for n in leaves)
-    assert len(d._train_graphs) == 1
-    d.clear_train_graphs()
+    assert len(d._prepared_steps) == 1
+    d.clear_prepared_steps()
     assert _same(step(d), step(eager))
 
 
 def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
-    """The module's own planning over replayed training calls: inputs that outgrow the plan AT THE SAME ADDRESSES (the
-    graphs exist) -> the forward's early check raises inside the module, the call is re-run in exact mode, re-planned and
-    captured again under the new plan."""
+    """The module's own planning over prepared training calls: inputs that outgrow the plan AT THE SAME ADDRESSES (the
+    prepared step exists) -> the forward's early check raises inside the module, the call is re-run in exact mode,
+    re-planned and prepared again under the new plan."""
     from spfsplatv2_amd import decoder as dec
     small = syn.make_batch("TEST", 1, 3, seed=26, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
     big = syn.make_batch("TEST", 1, 3, seed=26, s_mult=300.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
@@ -320,7 +320,7 @@ def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
     for i in range(4):                                               # exact, planned, captured, replayed
         c, gr = step(d)
         assert torch.equal(c, want[0]) and util.rel_linf(gr, want[1]) < 1e-5
-    assert len(d._train_graphs) == 1
+    assert len(d._prepared_steps) == 1
     cap = d.max_pairs.capacity
     with torch.no_grad():
         scales.copy_(big.scales)                                     # same address, footprints x 150
@@ -328,4 +328,4 @@ def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
     for i in range(4):
         c, gr = step(d)
         assert torch.equal(c, want_big[0]) and util.rel_linf(gr, want_big[1]) < 1e-5, i
-    assert d.max_pairs.capacity > cap and len(d._train_graphs) >= 1
+    assert d.max_pairs.capacity > cap and len(d._prepared_steps) >= 1
