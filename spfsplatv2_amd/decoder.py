@@ -705,11 +705,20 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                 return DecoderOutput(color, depth), alpha, radii
         else:
             self._graph_unused = 0
+        verdict = entry.record.get("verdict_host") if entry.record.get("verdict_mirrored") else None
+        if verdict is not None:
+            verdict.zero_()                          # (pinned host word the graph's projection kernel stores to on failure)
         entry.graph.replay()
         self.last_call = entry.record
         if self.max_pairs.check != "deferred":
             from .rasterizer import plan_flags
-            if plan_flags(entry.record) != 0:
+            if verdict is not None:
+                # direct bins: wait for the replay, read the host-mapped word -- no device->host copy of the counters
+                torch.cuda.current_stream(extrinsics.device).synchronize()
+                failed = verdict.item() != 0
+            else:
+                failed = plan_flags(entry.record) != 0
+            if failed:
                 # the plan did not hold for THESE inputs (the graph's outputs are NaN): this call in exact mode instead
                 # (on a record of its own: the graph's record must keep the counters its next replay is checked by)
                 self.last_call = CallRecord()
@@ -746,7 +755,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         return entry
 
     def _capture_unguarded(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "_EvalGraph":
-        record = CallRecord()
+        record = CallRecord(verdict_host=torch.zeros(1, dtype=torch.int32, pin_memory=True))
         graph = torch.cuda.CUDAGraph()
         dev = extrinsics.device
         before = torch.cuda.memory_allocated(dev)

@@ -281,8 +281,12 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     if isinstance(max_pairs, PairBudget) and max_pairs.check == "early" and not torch.cuda.is_current_stream_capturing():
         early = _early_verdict(dev)
         early[0].zero_()
+    # (a caller that captures the call in a graph hands its own pinned word over in the call record: the decoder's
+    #  evaluation graphs read it behind a stream synchronisation instead of copying counters[2] back)
+    vh = early[0] if early is not None else rec_out.get("verdict_host")
     st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk,
-                       verdict_host=early[0] if (early is not None and bin_cap) else None)
+                       verdict_host=vh if bin_cap else None)
+    rec_out["verdict_mirrored"] = bool(bin_cap and vh is not None)
     stream = _stream_ptr(dev)
     if camera is not None and tiles.data_ptr() % 16 == 0:
         # camera set-up and the clearing of ALL the tile bookkeeping in one kernel (the scan then needs no single-block
