@@ -710,6 +710,12 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             verdict.zero_()                          # (pinned host word the graph's projection kernel stores to on failure)
         entry.graph.replay()
         self.last_call = entry.record
+        flat, alpha, radii = entry.outputs
+        # ONE copy-out, queued right behind the replay (before any wait for the verdict): what the caller gets is the
+        # caller's (the graph's own buffers are rewritten by its next replay); colour and depth were packed into one flat
+        # buffer inside the graph
+        color, depth = flat.clone().split_with_sizes(entry.sizes)
+        extra = (alpha.clone(), radii.clone()) if want_extra else (None, None)
         if self.max_pairs.check != "deferred":
             from .rasterizer import plan_flags
             if verdict is not None:
@@ -726,14 +732,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
                                                                     image_shape, None, self.last_call)
                 return DecoderOutput(color, depth), alpha, radii
-        flat, alpha, radii = entry.outputs
-        # ONE copy-out: what the caller gets is the caller's (the graph's own buffers are rewritten by its next replay);
-        # colour and depth were packed into one flat buffer inside the graph
-        color, depth = flat.clone().split_with_sizes(entry.sizes)
         out = DecoderOutput(color.view(entry.color_shape), depth.view(entry.depth_shape))   # both contiguous, as ever
-        if not want_extra:
-            return out, None, None
-        return out, alpha.clone(), radii.clone()
+        return out, extra[0], extra[1]
 
     def _capture(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape) -> "Optional[_EvalGraph]":
         """Capture this evaluation call.  None when the capture failed: the key is forgotten, the cache is switched off
