@@ -353,64 +353,6 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const 
         sh_accumulate<WITH_GRAD>(k, dir, v, col, Dx, Dy, Dz);
     }
 }
-// ---- SH coefficients through LDS-DMA (gfx950 global_load_lds_dwordx4) ---------------------------------------------
-// The forward is latency-bound at three waves per SIMD: a wave's loads hang off each other -- geometry, then the
-// coefficient groups two at a time (more in flight costs registers, i.e. the third wave).  An LDS-DMA load costs NO
-// vector register: at the top of the kernel, next to the geometry loads, every wave requests coefficient groups 0 and 1
-// of its 64 Gaussians (six 1 KB pieces: piece p = 2 c + k4 holds, lane by lane, the four coefficients 4 k4 .. 4 k4 + 3 of
-// channel c) straight into ITS 6 KB of LDS; the colour section then starts with half of a degree-3 block on chip and
-// only the other half still to come.  Layout 1 with 16-byte aligned rows (K % 4 == 0: the band-split plane, BASELINE
-// config 5) only.  The pieces stay put for all the views of the scene.
-#ifndef SPF_SH_DMA
-#define SPF_SH_DMA 1
-#endif
-constexpr int kShDmaPieces = 6;
-typedef __attribute__((address_space(3))) void* lds_void_p;
-typedef const __attribute__((address_space(1))) void* global_cvoid_p;
-__device__ __forceinline__ void sh_dma_request(const float* __restrict__ sh, int K, float4* lds_wave) {
-#pragma unroll
-    for (int p = 0; p < kShDmaPieces; ++p) {
-        const float* src = sh + (p >> 1) * K + 4 * (p & 1);
-        __builtin_amdgcn_global_load_lds((global_cvoid_p)(uintptr_t)src, (lds_void_p)(uintptr_t)(uint32_t)(uintptr_t)(lds_wave + p * kWave),
-                                         16, 0, 0);
-    }
-}
-// colour = sum_k basis_k sh_k with groups 0 and 1 taken from the wave's DMA pieces (same order of accumulation as
-// sh_contract: bit-identical colours)
-template <int NB>
-__device__ __forceinline__ void sh_contract_dma(const float4* __restrict__ lds_wave, int lane, const float* __restrict__ sh,
-                                                int K, const ShDir& dir, float col[3]) {
-    constexpr int NV = NB / 4;
-    static_assert(NV >= 2, "two staged groups");
-    float v[2][4][3];
-    if (NV > 2) sh_load4<1, true>(sh, nullptr, K, 2, v[0]);          // the rest of the block: on its way while LDS is read
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the DMA pieces have landed; see the guide: the
-                                                                      //  issuing wave's covering vmcnt orders its ds_reads)
-#pragma unroll
-    for (int k4 = 0; k4 < 2; ++k4) {
-        float t[4][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float4 x = lds_wave[(2 * c + k4) * kWave + lane];
-            t[0][c] = x.x; t[1][c] = x.y; t[2][c] = x.z; t[3][c] = x.w;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sh_accumulate<false>(4 * k4 + i, dir, t[i], col, nullptr, nullptr, nullptr);
-    }
-#pragma unroll
-    for (int k4 = 2; k4 < NV; ++k4) {
-        if (k4 + 1 < NV) sh_load4<1, true>(sh, nullptr, K, k4 + 1, v[(k4 + 1) & 1]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) sh_accumulate<false>(4 * k4 + i, dir, v[k4 & 1][i], col, nullptr, nullptr, nullptr);
-        asm volatile("" ::: "memory");
-    }
-#pragma unroll
-    for (int k = 4 * NV; k < NB; ++k) {
-        const float t[3] = {sh_at<1>(sh, nullptr, K, k, 0), sh_at<1>(sh, nullptr, K, k, 1), sh_at<1>(sh, nullptr, K, k, 2)};
-        sh_accumulate<false>(k, dir, t, col, nullptr, nullptr, nullptr);
-    }
-}
-
 // Direction gradient of the SH colour with dL/dcolour contracted FIRST:  dd = sum_k grad basis_k(dir) * (sh_k . g).
 // Three accumulators (sh_contract<WITH_GRAD> carries sum_k grad basis_k sh_k[c] per channel -- nine -- plus the colour
 // itself, because it learns which channels the forward clamped only at the end of the pass; here `g` already has those
@@ -546,7 +488,7 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
 template <int DEG, int NATIVE>
 __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
-                                                                  int tiles_x, int tiles_y, int lds_hist, int sh_dma_off) {
+                                                                  int tiles_x, int tiles_y, int lds_hist) {
     // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
     // Nothing in the view loop waits for another wave: the histograms and the block's pair totals are flushed once per
     // group of views (normally: once), and a wave's 64 records leave through ITS staging buffer as full-wave contiguous
@@ -568,10 +510,6 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
     const int s = blockIdx.y;
     const bool live = g < d.G;
     const size_t sg = (size_t)s * d.G + (live ? g : 0);
-    // (sh_dma_off: byte offset of the waves' DMA pieces in the dynamic LDS, 0 = off -- see sh_dma_request)
-    constexpr bool kDmaKernel = SPF_SH_DMA && DEG >= 2 && DEG <= 3 && NATIVE == 1;
-    float4* const s_dma = reinterpret_cast<float4*>(reinterpret_cast<char*>(s_dyn) + sh_dma_off) + wave * (kShDmaPieces * kWave);
-    if (kDmaKernel && sh_dma_off) sh_dma_request(in.shs + sg * (size_t)d.K * 3, d.K, s_dma);
     const float p0[3] = {in.means3D[3 * sg], in.means3D[3 * sg + 1], in.means3D[3 * sg + 2]};
     const float sx = in.scales[3 * sg] * d.scale_modifier, sy = in.scales[3 * sg + 1] * d.scale_modifier,
                 sz = in.scales[3 * sg + 2] * d.scale_modifier;
@@ -654,14 +592,8 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                 const float* __restrict__ sh = in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
                 const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 col[0] = col[1] = col[2] = 0.f;
-                if constexpr (kDmaKernel) {
-                    if (sh_dma_off) sh_contract_dma<NB>(s_dma, lane, sh, d.K, sd, col);
-                    else if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                    else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                } else {
-                    if (NATIVE == 2 || d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                    else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                }
+                if (NATIVE == 2 || d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
+                else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -1338,16 +1270,7 @@ static inline int sh_eval_degree(const SpfDims& d) {
 template <int DEG, int NATIVE>
 static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDims& d, const SpfInputs& in,
                           const SpfState& st, int tiles_x, int tiles_y, int lds) {
-    // SH coefficients through LDS-DMA (see sh_dma_request): degree 2 - 3, layout 1, 16-byte aligned rows, and room for the
-    // four waves' pieces (24 KB) inside the 64 KB of dynamic LDS a launch gets without opting in
-    int dma_off = 0;
-    static const bool dma_on = !(getenv("SPF_SH_DMA") && getenv("SPF_SH_DMA")[0] == '0');
-    if (SPF_SH_DMA && dma_on && DEG >= 2 && DEG <= 3 && NATIVE == 1 && d.K % 4 == 0 &&
-        (reinterpret_cast<uintptr_t>(in.shs) & 15) == 0) {
-        const size_t at = (sm + 15) & ~(size_t)15, need = at + (size_t)4 * kShDmaPieces * kWave * sizeof(float4);
-        if (need <= 64 * 1024) { dma_off = (int)at; sm = need; }
-    }
-    spf_project_fwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds, dma_off);
+    spf_project_fwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds);
 }
 template <int DEG, int NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
