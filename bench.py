@@ -192,6 +192,10 @@ def parse_args(argv=None):
                     help="the step starts at the network's RAW channels: UnifiedGaussianAdapter.forward (fused HIP pre-pass, "
                          "gaussian_adapter.py:122-150) -> decoder -> MSE -> backward through the adapter to dL/draw: the "
                          "producer of the harmonics layout is inside the timed step (with --sh-split it writes the split)")
+    ap.add_argument("--raw-fused", action="store_true",
+                    help="like --with-adapter, but the adapter is FUSED INTO THE DECODER (UnifiedGaussianAdapter("
+                         "fuse_into_decoder=True), SpfDims.sh_layout 3): the projection kernels apply the adapter's "
+                         "activations as they read the raw rows and chain the backward into dL/draw -- no adapter pass")
     ap.add_argument("--allreduce", action="store_true",
                     help="outer-training-step variant (BASELINE config 5): every rank renders its own views of the "
                          "SAME scenes and the Gaussian-parameter gradients are summed with one RCCL all-reduce")
@@ -256,6 +260,9 @@ SECONDARY = (
     ("REF2V_adapter", ["--config", "REF2V", "--with-adapter"], {"SPF_SH_BAND4": "0"}),
     ("REF2V_adapter_split", ["--config", "REF2V", "--with-adapter", "--sh-split"], {"SPF_SH_BAND4": "0"}),
     ("REF10V_adapter_split", ["--config", "REF10V", "--with-adapter", "--sh-split"], {"SPF_SH_BAND4": "0"}),
+    # ... and with the adapter fused into the projection kernels (sh_layout 3): the same step, no adapter pass at all
+    ("REF2V_raw_fused", ["--config", "REF2V", "--raw-fused"], {"SPF_SH_BAND4": "0"}),
+    ("REF10V_raw_fused", ["--config", "REF10V", "--raw-fused"], {"SPF_SH_BAND4": "0"}),
     ("C2_stress", ["--config", "C2", "--s-mult", "10"], {}),     # SURVEY.md 8(d)'s stress regime: footprints x 10, dense tiles
     ("C2_module", ["--config", "C2", "--api", "module"], {}),    # an UNCHANGED caller: DecoderSplattingCUDA.forward, nothing configured
     ("C2_streams2", ["--config", "C2", "--streams", "2"], {}),
@@ -638,6 +645,10 @@ def main():
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")
     bg = torch.zeros(3, device=dev)
+    if args.raw_fused:
+        args.with_adapter = True
+        if args.sh_split:
+            sys.exit("bench.py: --raw-fused reads the raw rows themselves: there is no harmonics tensor to lay out")
     if (args.sh_split or args.with_adapter) and (K != 25 or args.allreduce or args.api == "per-view"):
         sys.exit("bench.py: --sh-split / --with-adapter are for the d_sh = 25 workloads (REF2V, REF10V), batched or module api")
     adapter_mod = raw_all = None
@@ -645,7 +656,8 @@ def main():
         # raw network channels that the adapter maps back onto the resident batch (same scales -> same pairs -> the same
         # decoder workload as the plain config): softplus^-1 of the scales, the unit quaternions, harmonics / sh_mask
         from spfsplatv2_amd import adapter as _ad
-        adapter_mod = _ad.UnifiedGaussianAdapter(_ad.GaussianAdapterCfg(0.5, 15.0, 4), split_harmonics=args.sh_split).to(dev)
+        adapter_mod = _ad.UnifiedGaussianAdapter(_ad.GaussianAdapterCfg(0.5, 15.0, 4), split_harmonics=args.sh_split,
+                                                 fuse_into_decoder=args.raw_fused).to(dev)
         y = (b.scales.double() / 0.001).clamp_min(1e-12)
         raw_scales = torch.where(y > 20.0, y, torch.log(torch.expm1(y.clamp_max(20.0)))).float()
         raw_all = torch.cat((raw_scales, b.rotations,
@@ -741,7 +753,7 @@ def main():
             if args.with_adapter:
                 ga = adapter_mod(L["means"], L["opacities"], L["raw"], with_covariances=False)
                 L = dict(L, scales=ga.scales, rotations=ga.rotations, harmonics=ga.harmonics,
-                         harmonics_band4=ga.harmonics_band4)
+                         harmonics_band4=ga.harmonics_band4, fused=ga.raw)
             if args.api == "module":
                 from spfsplatv2_amd import decoder as dec
                 if self.decoder is None:
@@ -751,7 +763,8 @@ def main():
                     if args.exact:
                         self.decoder.auto_plan = None
                 out = self.decoder.forward(dec.Gaussians(L["means"], None, L["rotations"], L["scales"], L["harmonics"],
-                                                         L["opacities"], harmonics_band4=L.get("harmonics_band4")),
+                                                         L["opacities"], harmonics_band4=L.get("harmonics_band4"),
+                                                         raw=L.get("fused")),
                                            L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w))
                 color = out.color
                 if "num_pairs" not in self.record:                  # (the first call of a shape is exact: statistics)
@@ -761,7 +774,7 @@ def main():
                     L["extrinsics"], b.intrinsics[sl], b.near[sl], b.far[sl], (h, w), bg, L["means"], L["harmonics"],
                     L["opacities"], L["rotations"], L["scales"], scale_invariant=True, enable_cov_grad=True,
                     enable_sh_grad=True, max_pairs=self.max_pairs, record=self.record,
-                    gaussian_sh_band4=L.get("harmonics_band4"))
+                    gaussian_sh_band4=L.get("harmonics_band4"), gaussian_raw=L.get("fused"))
             if args.torch_loss:
                 loss = torch.nn.functional.mse_loss(color, b.target[sl]) * self.weight
             else:
@@ -953,7 +966,7 @@ def main():
             except Exception:
                 traffic = None
         A = total_bytes(S, V, G, K_model, P, D_total)
-        if args.with_adapter:       # + the adapter, both directions: raw in / parameters out, gradients in / dL/draw out
+        if args.with_adapter and not args.raw_fused:   # + the adapter, both directions: raw in / parameters out, gradients in / dL/draw out
             A += 2.0 * S * G * (2 * (7 + 3 * K) * 4 - (0 if K_model == K else 4 * 3 * (K - K_model)))
         deg = int(K ** 0.5) - 1
         out = {
@@ -964,7 +977,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {G} pixel-aligned Gaussians/scene, {K} SH coefficient(s) per "
                                    f"channel (sh_degree {deg}), {h}x{w}, {S} scenes x {V} views per GPU per step, "
-                                   + ("fused Gaussian adapter (raw network channels in) + " if args.with_adapter else "")
+                                   + ("Gaussian adapter FUSED INTO the projection kernels (raw network channels in) + " if args.raw_fused
+                                      else "fused Gaussian adapter (raw network channels in) + " if args.with_adapter else "")
                                    + "decoder fwd + MSE + bwd to all Gaussian parameters and poses"
                                    + (" and through the adapter to the raw channels" if args.with_adapter else "")
                                    + ("; harmonics band-split [.,3,16] | [.,3,9] (sh_layout 2)" if args.sh_split else ""),

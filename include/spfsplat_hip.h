@@ -68,7 +68,15 @@ typedef struct SpfDims {
                             a second plane.  The reference ships d_sh = 25 (config/model/encoder/spfsplatv2.yaml:20) and
                             a degree-3 evaluation (sh_band4 = 0) then touches plane 0 only: the band-4 third of every
                             coefficient block neither crosses HBM in the forward nor is zero-written in the backward
-                            (in one [3,25] block it shares cache lines with the bands that are read) */
+                            (in one [3,25] block it shares cache lines with the bands that are read);
+                            3 ("raw rows"): the ADAPTER IS FUSED INTO THE PROJECTION KERNELS -- scales, rotations and shs are
+                            NULL and every Gaussian is one row of SpfInputs.raw, the network's 7 + 3K raw channels
+                            (UnifiedGaussianAdapter.forward, gaussian_adapter.py:122-150): the kernels form
+                            scales = min(0.001 softplus(raw[0:3]), 0.3), rotations = raw[3:7] / (|.| + adapter_eps) and
+                            sh[c][k] = raw[7 + c K + k] * sh_mask[k] as they read the row, and the backward chains through
+                            them into dL_draw -- the adapter's own pass over 656 + 576 bytes per Gaussian and step (more
+                            than the decoder's) never happens.  Same numbers as spf_adapter_forward -> sh_layout 1, bit
+                            for bit */
     int32_t sh_band4;    /* 0 (default): the reference's d_sh = 25 / sh_degree 4 (config/model/encoder/spfsplatv2.yaml:20,
                             cuda_splatting.py:77-78,114) is accepted as a stride and evaluated to degree 3 like the
                             published 3DGS kernels; 1: band 4 (coefficients 16..24) is evaluated too, forward and
@@ -84,6 +92,8 @@ typedef struct SpfDims {
                             backward is given); the projection kernel numbers the (Gaussian, tile) pairs and raises plan
                             flag 1 if they do not fit -- per SHARD of the numbering when it is sharded: each of the
                             spf_raster_pair_shards(S, G) shards owns pair_capacity / shards records (see there) */
+    int64_t raw_stride;  /* sh_layout 3 only: floats between two Gaussians' rows of SpfInputs.raw (>= 7 + 3K) */
+    float adapter_eps;   /* sh_layout 3 only: the eps of rotations = q / (|q| + eps) (gaussian_adapter.py:136) */
 } SpfDims;
 
 /* Inputs (all float32, contiguous, row-major). */
@@ -109,6 +119,9 @@ typedef struct SpfInputs {
                                 projection kernels form it in float64 -- from this matrix when given, else from the
                                 float32 one promoted -- and round once.  Everything else stays float32. */
     const float* shs_high;   /* sh_layout 2 only: [S,G,3,9], band 4; read only when sh_band4 is set (may be NULL otherwise) */
+    const float* raw;        /* sh_layout 3 only: [S*G rows of 7+3K floats at SpfDims.raw_stride]: the adapter's input, read in
+                                place (the encoder hands over gaussians[..., 1:], a view of its 83-channel head output) */
+    const float* sh_mask;    /* sh_layout 3 only: [K] per-coefficient scale of the harmonics (gaussian_adapter.py:47-48) */
 } SpfInputs;
 
 /* State written by the forward pass and read by the backward pass (owned by the caller, e.g. the
@@ -188,6 +201,8 @@ typedef struct SpfGrads {
     float* dL_dmeans2D;       /* [R,G,3]   NDC-scaled screen-space gradient (xy, 0) */
     float* dL_dshs_high;      /* sh_layout 2 with sh_band4 only: [S,G,3,9] (otherwise never touched, may be NULL: the
                                  gradient of band 4 is zero and its consumer, spf_adapter_backward, takes NULL for that) */
+    float* dL_draw;           /* sh_layout 3 only: [S*G, 7+3K] contiguous -- what spf_adapter_backward would have written;
+                                 dL_dscales / dL_drotations / dL_dshs are not used then */
 } SpfGrads;
 
 /* Camera set-up for R = S*V renders (all float32, contiguous). */

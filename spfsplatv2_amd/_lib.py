@@ -23,7 +23,7 @@ class SpfDims(C.Structure):
     _fields_ = [("S", C.c_int32), ("V", C.c_int32), ("G", C.c_int32), ("K", C.c_int32),
                 ("sh_degree", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("scale_modifier", C.c_float), ("sh_layout", C.c_int32), ("sh_band4", C.c_int32),
-                ("bin_cap", C.c_int32), ("pair_capacity", C.c_int64)]
+                ("bin_cap", C.c_int32), ("pair_capacity", C.c_int64), ("raw_stride", C.c_int64), ("adapter_eps", C.c_float)]
 
 
 def _ptr_struct(name, fields):
@@ -32,14 +32,15 @@ def _ptr_struct(name, fields):
 
 SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opacities", "shs", "colors",
                                       "viewmatrix", "projmatrix", "tanfov", "bg", "view_scale", "viewmatrix64",
-                                      "shs_high"])
+                                      "shs_high", "raw", "sh_mask"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
                                     "n_contrib", "pair_cursor", "sh_clamp", "verdict_host"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
 SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",
-                                    "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D", "dL_dshs_high"])
+                                    "dL_dshs", "dL_dcolors", "dL_dviewmatrix", "dL_dmeans2D", "dL_dshs_high",
+                                    "dL_draw"])
 
 
 

@@ -24,6 +24,7 @@ class Gaussians:                       # field order of the adapter's own datacl
     harmonics: Tensor
     opacities: Tensor
     harmonics_band4: Optional[Tensor] = None    # band-split harmonics: see decoder.Gaussians.harmonics_band4
+    raw: Optional[RawGaussians] = None          # fused mode: scales / rotations / harmonics are None, see RawGaussians
 
 
 @dataclass
@@ -37,28 +38,18 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _rows(raw: Tensor, d_in: int) -> Tensor:
-    """`raw` as [N, d_in] rows the kernel can read IN PLACE: unit stride along the channels, ONE row stride over all the
-    leading dimensions.  The encoder hands over `gaussians[..., 1:]`, a view into its 83-channel head output
-    (encoder_spfsplatv2.py:261-268): that qualifies -- no contiguous copy, 328 bytes per Gaussian read and written less.
-    Anything else (a permuted tensor, another dtype) is copied once, as before."""
-    if raw.dtype == torch.float32 and raw.stride(-1) == 1:
-        rs, span, ok = None, None, True
-        for size, stride in zip(reversed(raw.shape[:-1]), reversed(raw.stride()[:-1])):
-            if size == 1:
-                continue                       # (unit dimensions -- "b v r srf () c" -- carry no stride of their own)
-            if rs is None:
-                rs = span = stride
-                ok = rs >= d_in
-            elif stride != span:
-                ok = False
-            if not ok:
-                break
-            span *= size
-        if ok:
-            n = raw.numel() // d_in
-            return raw.as_strided((n, d_in), (d_in if rs is None else rs, 1), raw.storage_offset())
-    return raw.reshape(-1, d_in).contiguous().float()
+from .rasterizer import raw_rows as _rows          # (rows read in place: see there)
+
+
+@dataclass
+class RawGaussians:
+    """The adapter FUSED INTO THE DECODER (SpfDims.sh_layout 3): the network's raw channels as they are, plus what the
+    adapter would have applied to them.  `DecoderSplattingCUDA` consumes this directly -- the projection kernels form
+    scales, rotations and masked harmonics as they read a row and chain the backward through them -- so the adapter's own
+    pass over the tensor (656 bytes per Gaussian forward, 576 backward: more than the decoder itself moves) never runs."""
+    raw: Tensor          # [..., 7 + 3*d_sh]: any leading shape, unit stride along the channels (a view of the head output)
+    sh_mask: Tensor      # [d_sh]
+    eps: float
 
 
 class _AdapterFn(torch.autograd.Function):
@@ -108,13 +99,18 @@ class _AdapterFn(torch.autograd.Function):
 class UnifiedGaussianAdapter(nn.Module):
     """``forward(means, opacities, raw_gaussians, eps=1e-8) -> Gaussians`` with the reference's semantics."""
 
-    def __init__(self, cfg: GaussianAdapterCfg, split_harmonics: bool = False):
+    def __init__(self, cfg: GaussianAdapterCfg, split_harmonics: bool = False, fuse_into_decoder: bool = False):
         """``split_harmonics`` (d_sh = 25 only; not an argument of the reference's class): write the harmonics BAND-SPLIT,
         ``Gaussians.harmonics`` = bands 0 - 3 [.., 3, 16] and ``Gaussians.harmonics_band4`` = band 4 [.., 3, 9] -- the
         layout in which the decoder's default evaluation depth (degree 3) leaves band 4's third of every
         coefficient block in HBM, forward and backward (SpfDims.sh_layout 2)."""
         super().__init__()
         self.cfg = cfg
+        # `fuse_into_decoder` (not an argument of the reference's class): `forward` launches NOTHING -- it returns a
+        # `Gaussians` whose `raw` field carries the raw channels, the SH mask and eps, and whose scales / rotations /
+        # harmonics are None (`materialize()` produces them for any other consumer); the decoder applies the adapter inside
+        # its projection kernels.  Same images and gradients, bit for bit (tests/test_gpu_adapter.py).
+        self.fuse_into_decoder = bool(fuse_into_decoder)
         if split_harmonics and cfg.sh_degree != 4:
             raise ValueError("split_harmonics is the 16 + 9 split of sh_degree 4 (d_sh = 25)")
         self.split_harmonics = bool(split_harmonics)
@@ -141,6 +137,10 @@ class UnifiedGaussianAdapter(nn.Module):
             raise RuntimeError(f"raw_gaussians has {raw_gaussians.shape[-1]} channels, expected {self.d_in}")
         if not raw_gaussians.is_cuda:
             raise RuntimeError("UnifiedGaussianAdapter: tensors are on the CPU; this build only runs on a HIP device")
+        if self.fuse_into_decoder:
+            return Gaussians(means=means, covariances=None, scales=None, rotations=None, harmonics=None,
+                             opacities=opacities, raw=RawGaussians(raw_gaussians, self.sh_mask.to(raw_gaussians.device),
+                                                                   float(eps)))
         batch = raw_gaussians.shape[:-1]
         raw = raw_gaussians
         sh_hi = None
@@ -159,3 +159,22 @@ class UnifiedGaussianAdapter(nn.Module):
         return Gaussians(means=means, covariances=cov, scales=scales,
                          rotations=rot.broadcast_to((*scales.shape[:-1], 4)), harmonics=sh, opacities=opacities,
                          harmonics_band4=sh_hi)
+
+
+def materialize(g: Gaussians, split_harmonics: bool = False) -> Gaussians:
+    """The standard fields of a fused-mode `Gaussians` (scales, rotations, harmonics), through the adapter kernels -- for
+    the consumers that are not the decoder (visualisation dumps, export_ply)."""
+    if g.raw is None:
+        return g
+    raw = g.raw.raw
+    K = (raw.shape[-1] - 7) // 3
+    batch = raw.shape[:-1]
+    if split_harmonics:
+        scales, rot, sh, hi = _AdapterFn.apply(raw, g.raw.sh_mask, g.raw.eps, True, raw.shape[-1])
+        hi = hi.reshape(*batch, 3, 9)
+    else:
+        scales, rot, sh = _AdapterFn.apply(raw, g.raw.sh_mask, g.raw.eps, False, raw.shape[-1])
+        hi = None
+    return Gaussians(means=g.means, covariances=g.covariances, scales=scales.reshape(*batch, 3),
+                     rotations=rot.reshape(*batch, 4), harmonics=sh.reshape(*batch, 3, sh.shape[-1]), opacities=g.opacities,
+                     harmonics_band4=hi)

@@ -20,7 +20,6 @@ namespace spf {
 constexpr int kAdRows = 8;           // Gaussians per wave and trip
 constexpr int kAdLow = 16, kAdHigh = 9;
 
-__device__ __forceinline__ float softplus_torch(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
 // flat index e of a [rows, 3, KP] plane -> offset of raw channel 7 + c*K + k0 + k inside the group's rows (row stride C)
 __device__ __forceinline__ int plane_src(int e, int KP, int k0, int K, int C, int& k) {

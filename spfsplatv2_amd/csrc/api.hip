@@ -172,6 +172,7 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
         c.in.rotations = off(in.rotations, 4 * sg); c.in.opacities = off(in.opacities, sg);
         c.in.shs = off(in.shs, 3 * sg * (size_t)(d.sh_layout == 2 ? 16 : d.K)); c.in.colors = off(in.colors, 3 * sg);
         c.in.shs_high = off(in.shs_high, 3 * sg * 9);
+        c.in.raw = off(in.raw, sg * (size_t)d.raw_stride);
     }
     c.st = st;
     c.st.rec = off(st.rec, r * G * spf::kRec); c.st.radii = off(st.radii, r * G); c.st.rect = off(st.rect, r * G);
@@ -199,6 +200,7 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
             c.g.dL_drotations = off(g->dL_drotations, 4 * sg); c.g.dL_dopacities = off(g->dL_dopacities, sg);
             c.g.dL_dshs = off(g->dL_dshs, 3 * sg * (size_t)(d.sh_layout == 2 ? 16 : d.K)); c.g.dL_dcolors = off(g->dL_dcolors, 3 * sg);
             c.g.dL_dshs_high = off(g->dL_dshs_high, 3 * sg * 9);
+            c.g.dL_draw = off(g->dL_draw, sg * (size_t)(7 + 3 * d.K));
         }
     } else {
         memset(&c.g, 0, sizeof c.g);
@@ -218,7 +220,9 @@ int check_dims(const SpfDims* d) {
     if (d->sh_degree < 0 || d->sh_degree > 4) return fail(SPF_E_INVALID, "sh_degree %d outside 0..4", d->sh_degree);
     if (d->K < 0) return fail(SPF_E_INVALID, "K must be >= 0");
     if (d->sh_band4 != 0 && d->sh_band4 != 1) return fail(SPF_E_INVALID, "sh_band4 must be 0 or 1");
-    if (d->sh_layout < 0 || d->sh_layout > 2) return fail(SPF_E_INVALID, "sh_layout must be 0, 1 or 2");
+    if (d->sh_layout < 0 || d->sh_layout > 3) return fail(SPF_E_INVALID, "sh_layout must be 0 .. 3");
+    if (d->sh_layout == 3 && (d->K < 1 || d->raw_stride < 7 + 3 * (int64_t)d->K))
+        return fail(SPF_E_INVALID, "sh_layout 3 (raw rows): K >= 1 and raw_stride >= 7 + 3 K (got K = %d, raw_stride = %lld)", d->K, (long long)d->raw_stride);
     if (d->sh_layout == 2 && d->K != 25 && d->K != 0)
         return fail(SPF_E_INVALID, "sh_layout 2 (band split) is the 16 + 9 split of K = 25 coefficients (got K = %d)", d->K);
     if (d->bin_cap < 0) return fail(SPF_E_INVALID, "bin_cap must be >= 0");
@@ -235,12 +239,18 @@ int check_dims(const SpfDims* d) {
 
 int check_inputs(const SpfDims* d, const SpfInputs* in) {
     if (!in) return fail(SPF_E_INVALID, "inputs is null");
-    if (!in->means3D || !in->scales || !in->rotations || !in->opacities || !in->viewmatrix || !in->projmatrix ||
-        !in->tanfov || !in->bg)
+    const bool raw = d->sh_layout == 3;
+    if (!in->means3D || !in->opacities || !in->viewmatrix || !in->projmatrix || !in->tanfov || !in->bg)
         return fail(SPF_E_INVALID, "a required input pointer is null");
-    if ((in->shs == nullptr) == (in->colors == nullptr))
-        return fail(SPF_E_INVALID, "exactly one of shs / colors must be given");
-    if (in->shs) {
+    if (raw) {
+        if (!in->raw || !in->sh_mask) return fail(SPF_E_INVALID, "sh_layout 3: raw and sh_mask are required");
+        if (in->shs || in->colors) return fail(SPF_E_INVALID, "sh_layout 3: shs / colors must be null (the harmonics are in the raw rows)");
+    } else {
+        if (!in->scales || !in->rotations) return fail(SPF_E_INVALID, "a required input pointer is null");
+        if ((in->shs == nullptr) == (in->colors == nullptr))
+            return fail(SPF_E_INVALID, "exactly one of shs / colors must be given");
+    }
+    if (in->shs || raw) {
         const int cap = d->sh_band4 ? 4 : 3;
         const int deg = d->sh_degree > cap ? cap : d->sh_degree;
         if (d->K < (deg + 1) * (deg + 1))
@@ -316,7 +326,7 @@ static int forward_project(const SpfDims* d, const SpfInputs* in, SpfState* st, 
     if (!st || !st->rec || !st->radii || !st->rect || !st->zkey || !st->tile_count || !st->tile_start ||
         !st->tile_fill || !st->tile_flags || !st->counters || !st->blk_total || !st->blk_base)
         return fail(SPF_E_INVALID, "a state pointer needed by forward_project is null");
-    if (in->shs && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp is needed by forward_project when shs are given");
+    if ((in->shs || in->raw) && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp is needed by forward_project when shs are given");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles_x = (d->W + SPF_TILE - 1) / SPF_TILE, tiles_y = (d->H + SPF_TILE - 1) / SPF_TILE;
     const int RT = d->S * d->V * tiles_x * tiles_y;
@@ -488,7 +498,8 @@ int spf_raster_backward(const SpfDims* d, const SpfInputs* in, const SpfState* s
         return fail(SPF_E_INVALID, "a state pointer needed by backward is null");
     if (!g || !g->gpair || !g->dL_dmeans3D || !g->dL_dopacities)
         return fail(SPF_E_INVALID, "gpair, dL_dmeans3D and dL_dopacities are required");
-    if (in->shs && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp (written by the forward) is needed by backward when shs are given");
+    if (d->sh_layout == 3 && !g->dL_draw) return fail(SPF_E_INVALID, "sh_layout 3: dL_draw is required");
+    if ((in->shs || in->raw) && !st->sh_clamp) return fail(SPF_E_INVALID, "sh_clamp (written by the forward) is needed by backward when shs are given");
     if (g->dL_dviewmatrix && !g->vpartial) return fail(SPF_E_INVALID, "vpartial is required with dL_dviewmatrix");
     if ((g->dL_dscales == nullptr) != (g->dL_drotations == nullptr))
         return fail(SPF_E_INVALID, "dL_dscales and dL_drotations must be given together");

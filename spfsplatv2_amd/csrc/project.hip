@@ -247,10 +247,20 @@ __device__ __forceinline__ void st4(float* __restrict__ p, float a, float b, flo
 // NATIVE == 2 (band split, SpfDims.sh_layout 2): coefficients 0..15 of channel c at sh[16 c + k] (16-byte aligned rows),
 // 16..24 at hi[9 c + k - 16] (dword aligned).  Only the degree-4 kernels are instantiated with it: up to degree 3 the
 // launchers hand plane 0 to the NATIVE == 1 kernels as a K = 16 block (launch_project_fwd / _bwd).
+// NATIVE == 3 (raw rows, SpfDims.sh_layout 3): `sh` points at channel 7 of the Gaussian's RAW row -- the native [3][K]
+// arrangement at dword alignment -- and every coefficient is scaled by the adapter's sh_mask[k] as it is read (`mk`, in the
+// constant address space: scalar loads): raw * mask rounded to float32 first, exactly the value spf_adapter_forward
+// would have stored, so colours and gradients are bit-identical to the two-pass path.
 template <int NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_load4(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k4,
-                                         float v[4][3]) {
-    if (NATIVE == 2) {
+                                         float v[4][3], kfloat_p mk = nullptr) {
+    if (NATIVE == 3) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f4a t = ld4<false>(sh + c * K + 4 * k4);
+            v[0][c] = t.x * mk[4 * k4]; v[1][c] = t.y * mk[4 * k4 + 1]; v[2][c] = t.z * mk[4 * k4 + 2]; v[3][c] = t.w * mk[4 * k4 + 3];
+        }
+    } else if (NATIVE == 2) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const f4a t = k4 < 4 ? ld4<true>(sh + c * 16 + 4 * k4) : ld4<false>(hi + c * 9 + 4 * (k4 - 4));
@@ -293,7 +303,9 @@ __device__ __forceinline__ void zero_floats(float* __restrict__ p, int n) {
     for (; i < n; ++i) p[i] = 0.f;
 }
 template <int NATIVE>
-__device__ __forceinline__ float sh_at(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k, int c) {
+__device__ __forceinline__ float sh_at(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k, int c,
+                                       kfloat_p mk = nullptr) {
+    if (NATIVE == 3) return sh[c * K + k] * mk[k];
     if (NATIVE == 2) return k < 16 ? sh[c * 16 + k] : hi[c * 9 + k - 16];
     return NATIVE ? sh[c * K + k] : sh[3 * k + c];
 }
@@ -323,13 +335,14 @@ __device__ __forceinline__ void sh_accumulate(int k, const ShDir& dir, const flo
 }
 template <int NB, int NATIVE, bool ALIGNED, bool WITH_GRAD>
 __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const float* __restrict__ hi, int K,
-                                            const ShDir& dir, float col[3], float Dx[3], float Dy[3], float Dz[3]) {
+                                            const ShDir& dir, float col[3], float Dx[3], float Dy[3], float Dz[3],
+                                            kfloat_p mk = nullptr) {
     constexpr int NV = NB / 4;
     if (NV <= 1) {
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
             float v[4][3];
-            sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4, v);
+            sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4, v, mk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[i], col, Dx, Dy, Dz);
         }
@@ -338,10 +351,10 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const 
         // a compiler barrier after every group keeps the scheduler from hoisting ALL the loads to the top (which costs
         // 3*NB live registers -- with 16 / 25 coefficients that alone pushed the backward to one wave per SIMD).
         float v[2][4][3];
-        sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0]);
+        sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0], mk);
 #pragma unroll
         for (int k4 = 0; k4 < NV; ++k4) {
-            if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1]);
+            if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1], mk);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sh_accumulate<WITH_GRAD>(4 * k4 + i, dir, v[k4 & 1][i], col, Dx, Dy, Dz);
             asm volatile("" ::: "memory");
@@ -349,7 +362,7 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const 
     }
 #pragma unroll
     for (int k = 4 * NV; k < NB; ++k) {
-        const float v[3] = {sh_at<NATIVE>(sh, hi, K, k, 0), sh_at<NATIVE>(sh, hi, K, k, 1), sh_at<NATIVE>(sh, hi, K, k, 2)};
+        const float v[3] = {sh_at<NATIVE>(sh, hi, K, k, 0, mk), sh_at<NATIVE>(sh, hi, K, k, 1, mk), sh_at<NATIVE>(sh, hi, K, k, 2, mk)};
         sh_accumulate<WITH_GRAD>(k, dir, v, col, Dx, Dy, Dz);
     }
 }
@@ -360,7 +373,7 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const 
 // per SIMD instead of one).
 template <int NB, int NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ sh, const float* __restrict__ hi, int K,
-                                                      const ShDir& dir, const float g[3], float dd[3]) {
+                                                      const ShDir& dir, const float g[3], float dd[3], kfloat_p mk = nullptr) {
     constexpr int NV = NB / 4;
     auto acc = [&](int k, const float v[3]) {
         float gx, gy, gz;
@@ -372,17 +385,17 @@ __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ 
     };
     // groups of four coefficients, double-buffered by hand behind a compiler barrier (see sh_contract)
     float v[2][4][3];
-    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0]);
+    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0], mk);
 #pragma unroll
     for (int k4 = 0; k4 < NV; ++k4) {
-        if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1]);
+        if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1], mk);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc(4 * k4 + i, v[k4 & 1][i]);
         asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int k = 4 * NV; k < NB; ++k) {
-        const float t[3] = {sh_at<NATIVE>(sh, hi, K, k, 0), sh_at<NATIVE>(sh, hi, K, k, 1), sh_at<NATIVE>(sh, hi, K, k, 2)};
+        const float t[3] = {sh_at<NATIVE>(sh, hi, K, k, 0, mk), sh_at<NATIVE>(sh, hi, K, k, 1, mk), sh_at<NATIVE>(sh, hi, K, k, 2, mk)};
         acc(k, t);
     }
 }
@@ -393,7 +406,8 @@ __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ 
 // TO_LDS: `o` is the thread's own 3*K-float row of an LDS staging buffer (element-wise stores; `first` is true).
 template <int NB, int NATIVE, bool ALIGNED, bool TO_LDS = false>
 __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, float* __restrict__ o_hi, int K,
-                                                    const float* __restrict__ park, int nviews, bool first) {
+                                                    const float* __restrict__ park, int nviews, bool first,
+                                                    kfloat_p mk = nullptr) {
     static_assert(!(TO_LDS && NATIVE == 2), "the split layout writes its planes directly");
     constexpr int NV = NB / 4;
     const int sk = NATIVE ? 1 : 3, sc = NATIVE ? K : 1;
@@ -411,6 +425,11 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, float
                     const float b = sh_term<false>(k0 + i, dir, gx, gy, gz);
                     acc[i][0] += b * g[0]; acc[i][1] += b * g[1]; acc[i][2] += b * g[2];
                 }
+        }
+        if (NATIVE == 3) {       // raw rows: dL/draw = dL/dsh * sh_mask (what spf_adapter_backward does with dL/dsh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n) { acc[i][0] *= mk[k0 + i]; acc[i][1] *= mk[k0 + i]; acc[i][2] *= mk[k0 + i]; }
         }
     };
 #pragma unroll
@@ -487,7 +506,8 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
 template <int DEG, int NATIVE>
-__global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+// (raw rows at degree 3 sit five registers above the 168 of three waves per SIMD: asked for, the compiler finds them)
+__global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3) ? 3 : SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
     // Nothing in the view loop waits for another wave: the histograms and the block's pair totals are flushed once per
@@ -511,9 +531,25 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
     const bool live = g < d.G;
     const size_t sg = (size_t)s * d.G + (live ? g : 0);
     const float p0[3] = {in.means3D[3 * sg], in.means3D[3 * sg + 1], in.means3D[3 * sg + 2]};
-    const float sx = in.scales[3 * sg] * d.scale_modifier, sy = in.scales[3 * sg + 1] * d.scale_modifier,
-                sz = in.scales[3 * sg + 2] * d.scale_modifier;
-    const float4 q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+    // raw rows (sh_layout 3): the adapter's activations as the row is read -- the same expressions, in the same order,
+    // as spf_adapter_fwd_kernel (adapter.hip): bit-identical scales and rotations
+    constexpr bool kRaw = NATIVE == 3;
+    const float* __restrict__ raw_row = kRaw ? in.raw + sg * (size_t)d.raw_stride : nullptr;
+    const kfloat_p mk = kRaw ? as_const(in.sh_mask) : nullptr;
+    float sx, sy, sz;
+    float4 q;
+    if (kRaw) {
+        sx = fminf(0.001f * softplus_torch(raw_row[0]), 0.3f) * d.scale_modifier;
+        sy = fminf(0.001f * softplus_torch(raw_row[1]), 0.3f) * d.scale_modifier;
+        sz = fminf(0.001f * softplus_torch(raw_row[2]), 0.3f) * d.scale_modifier;
+        const float q0 = raw_row[3], q1 = raw_row[4], q2 = raw_row[5], q3 = raw_row[6];
+        const float inv = 1.0f / (sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) + d.adapter_eps);
+        q = make_float4(q0 * inv, q1 * inv, q2 * inv, q3 * inv);
+    } else {
+        sx = in.scales[3 * sg] * d.scale_modifier; sy = in.scales[3 * sg + 1] * d.scale_modifier;
+        sz = in.scales[3 * sg + 2] * d.scale_modifier;
+        q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+    }
     const float opac = in.opacities[sg];
     float N0[9];
     {
@@ -589,11 +625,11 @@ __global__ __launch_bounds__(kBlock, SPF_PFWD_BPC) void spf_project_fwd_kernel(S
                     dir[j] = p[j] + (Vm[12] * Vm[4 * j] + Vm[13] * Vm[4 * j + 1] + Vm[14] * Vm[4 * j + 2]);
                 const float inv = 1.0f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
                 const ShDir sd = sh_dir(dir[0] * inv, dir[1] * inv, dir[2] * inv);
-                const float* __restrict__ sh = in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
+                const float* __restrict__ sh = kRaw ? raw_row + 7 : in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
                 const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 col[0] = col[1] = col[2] = 0.f;
-                if (NATIVE == 2 || d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
+                if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
+                else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
@@ -843,8 +879,11 @@ constexpr int kShChunk = 8;
 // multiple of 16 bytes per channel row (K = 25: every 16-byte piece is misaligned and straddles sectors; with
 // K = 16 the direct stores are as fast: measured), all views fit one parked chunk and the block still fits twice on a
 // CU (<= 80 KB of LDS)
-__host__ __device__ inline bool sh_stage_out(int V, int K) {
-    return K % 4 != 0 && V <= kShChunk && (size_t)V * (6 * 256 + 48) * 4 + (size_t)128 * 3 * K * 4 <= 80 * 1024;
+// (raw rows, sh_layout 3: the staged row is the whole dL_draw row, 7 + 3K floats, and staging does not depend on K % 4)
+__host__ __device__ inline int sh_stage_row(int K, bool raw) { return raw ? 7 + 3 * K : 3 * K; }
+__host__ __device__ inline bool sh_stage_out(int V, int K, bool raw = false) {
+    return (raw || K % 4 != 0) && V <= kShChunk &&
+           (size_t)V * (6 * 256 + 48) * 4 + (size_t)128 * sh_stage_row(K, raw) * 4 <= 80 * 1024;
 }      // views parked per thread before their SH gradient is formed (6 floats each, in LDS)
 
 // (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
@@ -873,6 +912,10 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         for (int k = 0; k < 3; ++k) gr.dL_dmeans3D[3 * sg + k] = nan;
         gr.dL_dopacities[sg] = nan;
         if (gr.dL_dcolors) for (int k = 0; k < 3; ++k) gr.dL_dcolors[3 * sg + k] = nan;
+        if (NATIVE == 3) {
+            for (int k = 0; k < 7 + 3 * d.K; ++k) gr.dL_draw[sg * (size_t)(7 + 3 * d.K) + k] = nan;
+            return;
+        }
         if (gr.dL_dshs) {
             const int kk = NATIVE == 2 ? 16 : d.K;
             for (int k = 0; k < 3 * kk; ++k) gr.dL_dshs[sg * (size_t)kk * 3 + k] = nan;
@@ -885,11 +928,24 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     float p0[3] = {0.f, 0.f, 0.f};
     float sx = 1.f, sy = 1.f, sz = 1.f, opac = 0.f;
     float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+    constexpr bool kRaw = NATIVE == 3;
+    const float* __restrict__ raw_row = kRaw ? in.raw + sg * (size_t)d.raw_stride : nullptr;
+    const kfloat_p mk = kRaw ? as_const(in.sh_mask) : nullptr;
+    const int CR = 7 + 3 * d.K;                                       // floats of a raw row / of a dL_draw row
     if (live) {
         p0[0] = in.means3D[3 * sg]; p0[1] = in.means3D[3 * sg + 1]; p0[2] = in.means3D[3 * sg + 2];
-        sx = in.scales[3 * sg] * d.scale_modifier; sy = in.scales[3 * sg + 1] * d.scale_modifier;
-        sz = in.scales[3 * sg + 2] * d.scale_modifier;
-        q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+        if (kRaw) {      // (the adapter's activations, as in the forward kernel)
+            sx = fminf(0.001f * softplus_torch(raw_row[0]), 0.3f) * d.scale_modifier;
+            sy = fminf(0.001f * softplus_torch(raw_row[1]), 0.3f) * d.scale_modifier;
+            sz = fminf(0.001f * softplus_torch(raw_row[2]), 0.3f) * d.scale_modifier;
+            const float q0 = raw_row[3], q1 = raw_row[4], q2 = raw_row[5], q3 = raw_row[6];
+            const float inv = 1.0f / (sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) + d.adapter_eps);
+            q = make_float4(q0 * inv, q1 * inv, q2 * inv, q3 * inv);
+        } else {
+            sx = in.scales[3 * sg] * d.scale_modifier; sy = in.scales[3 * sg + 1] * d.scale_modifier;
+            sz = in.scales[3 * sg + 2] * d.scale_modifier;
+            q = *reinterpret_cast<const float4*>(in.rotations + 4 * sg);
+        }
         opac = in.opacities[sg];
     }
     (void)opac;
@@ -915,14 +971,15 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     // SH only: six floats per view that every thread parks for ITSELF (no barrier): see sh_grad_from_parked
     float* __restrict__ s_park = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + threadIdx.x;
     constexpr bool kPark = DEG >= 2;         // few coefficients (K = 1, 4): plain register accumulators are cheaper
-    const bool want_dsh = DEG >= 0 && gr.dL_dshs != nullptr;
-    float* __restrict__ dsh_out = want_dsh ? gr.dL_dshs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3 : nullptr;
+    const bool want_dsh = DEG >= 0 && (kRaw ? gr.dL_draw != nullptr : gr.dL_dshs != nullptr);
+    float* __restrict__ dsh_out = !want_dsh ? nullptr : kRaw ? gr.dL_draw + sg * (size_t)CR + 7
+                                                             : gr.dL_dshs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
     float* __restrict__ dsh_out_hi = (want_dsh && NATIVE == 2) ? gr.dL_dshs_high + sg * 27 : nullptr;
     // When every view fits the parked chunk, dL/dsh leaves through an LDS staging buffer (half a block at a time) and
     // is written with full-wave contiguous stores.  Per-thread stores of a 3*K-float block are 16-byte pieces at a
     // 12*K-byte stride: lines fill up piece by piece over the whole flush and the set of open lines outgrows the L2
     // -- at K = 25 the stores alone were 250 of the kernel's 439 us.
-    const bool stage_out = NATIVE != 2 && kPark && want_dsh && sh_stage_out(d.V, d.K);    // (split planes: direct stores)
+    const bool stage_out = NATIVE != 2 && kPark && want_dsh && sh_stage_out(d.V, d.K, kRaw);    // (split planes: direct stores)
     float dsh[kPark ? 1 : NB][3];
 #pragma unroll
     for (int k = 0; k < (kPark ? 1 : NB); ++k) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
@@ -1015,15 +1072,15 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                 const float inv = 1.0f / sqrtf(vdir[0] * vdir[0] + vdir[1] * vdir[1] + vdir[2] * vdir[2]);
                 const float x = vdir[0] * inv, y = vdir[1] * inv, z = vdir[2] * inv;
                 const ShDir sd = sh_dir(x, y, z);
-                const float* __restrict__ sh = in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
+                const float* __restrict__ sh = kRaw ? raw_row + 7 : in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
                 const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 float dd[3] = {0.f, 0.f, 0.f};
                 if (DEG == 0) {
                     // one term: re-evaluate the colour exactly as the forward kernel does (a colour clamped at 0 passes
                     // no gradient)
                     float col[3] = {0.f, 0.f, 0.f};
-                    if (d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
-                    else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr);
+                    if (!kRaw && d.K % 4 == 0) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
+                    else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)
                         if (col[ch] + 0.5f < 0.f) gcol[ch] = 0.f;
@@ -1034,8 +1091,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                     if (cm & 1u) gcol[0] = 0.f;
                     if (cm & 2u) gcol[1] = 0.f;
                     if (cm & 4u) gcol[2] = 0.f;
-                    if (NATIVE == 2 || d.K % 4 == 0) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd);
-                    else sh_direction_gradient<NB, NATIVE, false>(sh, sh_hi, d.K, sd, gcol, dd);
+                    if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd, mk);
+                    else sh_direction_gradient<NB, NATIVE, false>(sh, sh_hi, d.K, sd, gcol, dd, mk);
                 }
                 sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
                 if (!kPark) {
@@ -1127,8 +1184,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             if (live && !stage_out && ((v + 1) % kShChunk == 0 || v + 1 == d.V)) {
                 const int nv = v % kShChunk + 1;
                 const bool first = v < kShChunk;
-                if (NATIVE == 2 || d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, dsh_out_hi, d.K, s_park, nv, first);
-                else sh_grad_from_parked<NB, NATIVE, false>(dsh_out, dsh_out_hi, d.K, s_park, nv, first);
+                if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_grad_from_parked<NB, NATIVE, true>(dsh_out, dsh_out_hi, d.K, s_park, nv, first, mk);
+                else sh_grad_from_parked<NB, NATIVE, false>(dsh_out, dsh_out_hi, d.K, s_park, nv, first, mk);
             }
         }
         // ---- wave totals of the 12 viewmatrix partials of this view (no barrier inside the view loop) ----
@@ -1153,20 +1210,68 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
             }
         }
     }
+    // raw rows: dL/draw[0..6] -- the scale and rotation gradients chained through the adapter's activations, with the
+    // expressions (and their order) of spf_adapter_bwd_kernel: the row this kernel writes is bit for bit the one the
+    // adapter's backward would have produced from this kernel's dL/dscales, dL/drotations, dL/dsh
+    float graw[kRaw ? 7 : 1];
+    if constexpr (kRaw) {
+        float rr[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rr[i] = live ? raw_row[i] : (i == 3 ? 1.f : 0.f);
+        const float nrm = sqrtf(rr[3] * rr[3] + rr[4] * rr[4] + rr[5] * rr[5] + rr[6] * rr[6]);
+        const float dn = nrm + d.adapter_eps, inv = 1.0f / dn;
+        const float4 q2 = make_float4(rr[3] * inv, rr[4] * inv, rr[5] * inv, rr[6] * inv);
+        float R[9];
+        quat_rot(q2, R);
+        float ds[3], dR[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sv = fminf(0.001f * softplus_torch(rr[k]), 0.3f) * d.scale_modifier;
+            ds[k] = (dN0[k] * R[k] + dN0[3 + k] * R[3 + k] + dN0[6 + k] * R[6 + k]) * d.scale_modifier;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN0[3 * i + k] * sv;
+        }
+        const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
+        float dq[4];
+        dq[0] = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        dq[1] = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] -
+                       2.f * x * dR[8]);
+        dq[2] = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] -
+                       2.f * y * dR[8]);
+        dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] +
+                       y * dR[7]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float xx = rr[i];
+            const float sp = softplus_torch(xx);
+            const float dsp = xx > 20.f ? 1.f : 1.f / (1.f + expf(-xx));
+            const float pass = (0.001f * sp <= 0.3f) ? 1.f : 0.f;
+            graw[i] = ds[i] * 0.001f * dsp * pass;
+        }
+        const float dot = dq[0] * rr[3] + dq[1] * rr[4] + dq[2] * rr[5] + dq[3] * rr[6];
+        const float kk = nrm > 0.f ? dot / (nrm * dn * dn) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) graw[3 + i] = dq[i] / dn - rr[3 + i] * kk;
+    }
     if constexpr (NATIVE != 2) if (stage_out) {
-        const int row = 3 * d.K;
+        const int row = sh_stage_row(d.K, kRaw);
         float* __restrict__ s_out = s_part + (d.V < kViewChunk ? d.V : kViewChunk) * 48 + d.V * 6 * kBlock;
         for (int half = 0; half < 2; ++half) {
             __syncthreads();                                  // (buffer free; the parked views are complete)
             if ((int)(threadIdx.x >> 7) == half && live) {
                 float* __restrict__ mine = s_out + (threadIdx.x & 127) * row;
-                if (d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true, true>(mine, nullptr, d.K, s_park, d.V, true);
-                else sh_grad_from_parked<NB, NATIVE, false, true>(mine, nullptr, d.K, s_park, d.V, true);
+                if constexpr (kRaw) {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) mine[i] = graw[i];
+                    mine += 7;
+                }
+                if (!kRaw && d.K % 4 == 0) sh_grad_from_parked<NB, NATIVE, true, true>(mine, nullptr, d.K, s_park, d.V, true, mk);
+                else sh_grad_from_parked<NB, NATIVE, false, true>(mine, nullptr, d.K, s_park, d.V, true, mk);
             }
             __syncthreads();
             const int g0 = blockIdx.x * kBlock + half * 128;
             const int nflt = min(128, d.G - g0) * row;        // (<= 0: nothing of this half exists)
-            float* __restrict__ dst = gr.dL_dshs + ((size_t)s * d.G + g0) * row;
+            float* __restrict__ dst = (kRaw ? gr.dL_draw : gr.dL_dshs) + ((size_t)s * d.G + g0) * row;
             for (int i = 4 * threadIdx.x; i < nflt; i += 4 * kBlock) {
                 if (i + 4 <= nflt) {
                     const float4 q = *reinterpret_cast<const float4*>(s_out + i);
@@ -1188,7 +1293,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         const int sk = NATIVE ? 1 : 3, sc = NATIVE ? d.K : 1;
 #pragma unroll
         for (int k = 0; k < (kPark ? 0 : NB); ++k) {
-            dsh_out[sk * k] = dsh[k][0]; dsh_out[sk * k + sc] = dsh[k][1]; dsh_out[sk * k + 2 * sc] = dsh[k][2];
+            const float m = kRaw ? mk[k] : 1.f;              // (raw rows: dL/draw = dL/dsh * sh_mask)
+            dsh_out[sk * k] = dsh[k][0] * m; dsh_out[sk * k + sc] = dsh[k][1] * m; dsh_out[sk * k + 2 * sc] = dsh[k][2] * m;
         }
         if (d.K > NB) {
             if (NATIVE) {
@@ -1197,6 +1303,14 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                 zero_floats(dsh_out + 3 * NB, 3 * (d.K - NB));
             }
         }
+    }
+    if constexpr (kRaw) {
+        if (!stage_out && gr.dL_draw) {                       // (staged: the seven geometric slots left with the row)
+            float* __restrict__ o = gr.dL_draw + sg * (size_t)CR;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) o[i] = graw[i];
+        }
+        return;
     }
     if (gr.dL_dscales && gr.dL_drotations) {
         // N[i][k] = R[i][k] s_k.  R is rebuilt from the quaternion here rather than carried through the view loop (nine
@@ -1278,7 +1392,8 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
     size_t lds = (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float);
     if (DEG >= 2 && g.dL_dshs) {
         lds += (size_t)(d.V < kShChunk ? d.V : kShChunk) * 6 * kBlock * sizeof(float);
-        if (sh_stage_out(d.V, d.K)) lds += (size_t)128 * 3 * d.K * sizeof(float);   // staged dL/dsh, half a block at a time
+        if (sh_stage_out(d.V, d.K, NATIVE == 3))      // staged dL/dsh (raw rows: the dL/draw rows), half a block at a time
+            lds += (size_t)128 * sh_stage_row(d.K, NATIVE == 3) * sizeof(float);
         if (lds > 64 * 1024) {
             // more than the default 64 KB of dynamic LDS: opt in, once per device and instantiation
             static std::atomic<bool> attr_set[64];      // (per instantiation; idempotent attribute, see binning.hip)
@@ -1300,7 +1415,15 @@ static inline SpfDims dims_for_kernels(const SpfDims& d, int deg) {
     return k;
 }
 #define SPF_DISPATCH_DEG(FN, ...)                                        \
-    if (d.sh_layout == 2 && deg == 4) { FN<4, 2>(__VA_ARGS__); } else    \
+    if (d.sh_layout == 3) {                                              \
+        switch (deg) {                                                   \
+            case 0: FN<0, 3>(__VA_ARGS__); break;                        \
+            case 1: FN<1, 3>(__VA_ARGS__); break;                        \
+            case 2: FN<2, 3>(__VA_ARGS__); break;                        \
+            case 3: FN<3, 3>(__VA_ARGS__); break;                        \
+            default: FN<4, 3>(__VA_ARGS__); break;                       \
+        }                                                                \
+    } else if (d.sh_layout == 2 && deg == 4) { FN<4, 2>(__VA_ARGS__); } else \
     switch (deg * 2 + (native ? 1 : 0)) {                                \
         case -2: case -1: FN<-1, false>(__VA_ARGS__); break;             \
         case 0: FN<0, false>(__VA_ARGS__); break;                        \

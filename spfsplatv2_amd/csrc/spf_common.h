@@ -53,6 +53,11 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 1e-4f;
 constexpr float kFovClamp = 1.3f;
 
+// torch.nn.functional.softplus (beta 1, threshold 20): the Gaussian adapter's scale activation
+// (/root/reference/src/model/encoder/common/gaussian_adapter.py:132-133) -- shared by adapter.hip and the projection
+// kernels' raw-row mode, which must produce the same bits
+__device__ __forceinline__ float softplus_torch(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float SH_C1 = 0.4886025119029199f;
 __device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f,

@@ -51,7 +51,7 @@ SpfInputs make_inputs(const Tensor& means3D, const Tensor& scales, const Tensor&
     in.viewmatrix = ptr<const float>(viewmatrix); in.projmatrix = ptr<const float>(projmatrix);
     in.tanfov = ptr<const float>(tanfov); in.bg = ptr<const float>(bg);
     in.view_scale = ptr<const float>(view_scale); in.viewmatrix64 = ptr<const double>(view64);
-    in.shs_high = nullptr;      // (the band-split layout is the batched decoder's: this per-view surface takes [G,K,3])
+    in.shs_high = nullptr; in.raw = nullptr; in.sh_mask = nullptr;   // (band-split / raw rows are the batched decoder's: this per-view surface takes [G,K,3])
     return in;
 }
 
@@ -81,7 +81,7 @@ SpfDims make_dims(int64_t S, int64_t V, int64_t G, int64_t K, int64_t sh_degree,
     d.S = (int32_t)S; d.V = (int32_t)V; d.G = (int32_t)G; d.K = (int32_t)K; d.sh_degree = (int32_t)sh_degree;
     d.H = (int32_t)H; d.W = (int32_t)W; d.scale_modifier = (float)scale_modifier; d.sh_layout = (int32_t)sh_layout;
     d.sh_band4 = sh_band4 ? 1 : 0;
-    d.bin_cap = (int32_t)bin_cap; d.pair_capacity = bin_cap ? pair_capacity : 0;
+    d.bin_cap = (int32_t)bin_cap; d.pair_capacity = bin_cap ? pair_capacity : 0; d.raw_stride = 0; d.adapter_eps = 0.f;
     return d;
 }
 
@@ -185,7 +185,7 @@ std::vector<Tensor> raster_backward(
     gr.gpair = ptr<float>(gpair); gr.vpartial = ptr<float>(vpartial);
     gr.dL_dmeans3D = ptr<float>(d_means); gr.dL_dscales = ptr<float>(d_scales); gr.dL_drotations = ptr<float>(d_rot);
     gr.dL_dopacities = ptr<float>(d_opac); gr.dL_dshs = ptr<float>(d_shs); gr.dL_dcolors = ptr<float>(d_col);
-    gr.dL_dviewmatrix = ptr<float>(d_view); gr.dL_dmeans2D = ptr<float>(d_m2d); gr.dL_dshs_high = nullptr;
+    gr.dL_dviewmatrix = ptr<float>(d_view); gr.dL_dmeans2D = ptr<float>(d_m2d); gr.dL_dshs_high = nullptr; gr.dL_draw = nullptr;
     void* const stream = c10::hip::getCurrentHIPStream(means3D.device().index()).stream();
     check(spf_raster_backward(&dims, &in, &st, &gr, (uint64_t)capacity, (uint32_t)dense, stream), "spf_raster_backward");
     return {d_means, d_scales, d_rot, d_opac, d_shs, d_col, want_view == 2 ? vpartial : d_view, d_m2d};

@@ -69,6 +69,10 @@ class Gaussians:
     # and this [b, g, 3, 9] tensor band 4 -- what `UnifiedGaussianAdapter(..., split_harmonics=True)` produces.  The
     # default evaluation depth (degree 3) then never moves band 4's bytes; None: `harmonics` is the reference's layout.
     harmonics_band4: Optional[Tensor] = None
+    # (not a field of the reference's dataclass) the adapter FUSED INTO THE DECODER: an `adapter.RawGaussians` (raw network
+    # channels [b, g, 7 + 3 d_sh] + SH mask + eps, from `UnifiedGaussianAdapter(..., fuse_into_decoder=True)`); scales,
+    # rotations and harmonics are then None and the projection kernels apply the adapter as they read a row.
+    raw: Optional[object] = None
 
 
 @dataclass
@@ -122,7 +126,8 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  gaussian_opacities: Tensor, gaussian_rotations: Tensor, gaussian_scales: Tensor,
                  scale_invariant: bool = True, use_sh: bool = True, enable_cov_grad: bool = False,
                  enable_sh_grad: bool = False, max_pairs=None, sh_band4: Optional[bool] = None,
-                 return_radii: bool = False, record=None, gaussian_sh_band4: Optional[Tensor] = None):
+                 return_radii: bool = False, record=None, gaussian_sh_band4: Optional[Tensor] = None,
+                 gaussian_raw=None):
     """Batched form of ``render_cuda``: b scenes x v views sharing each scene's Gaussians.
 
     extrinsics [b,v,4,4] (camera-to-world), intrinsics [b,v,3,3] (normalised), near/far [b,v],
@@ -134,8 +139,17 @@ def render_views(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     ``gaussian_sh_band4`` [b,g,3,9]: band 4 of BAND-SPLIT harmonics, ``gaussian_sh_coefficients`` then being [b,g,3,16]
     (``Gaussians.harmonics_band4``).
     """
-    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     h, w = image_shape
+    if gaussian_raw is not None:
+        # the adapter fused into the projection kernels (`Gaussians.raw`): scales / rotations / harmonics are not looked at
+        n = (gaussian_raw.raw.shape[-1] - 7) // 3
+        color, depth, alpha, _radii = render_batch(
+            extrinsics, intrinsics, near, far, gaussian_means, None, None, gaussian_opacities, None, None,
+            background_color, h, w, isqrt(n) - 1, scale_invariant, True, True, max_pairs=max_pairs, sh_layout="g3k",
+            sh_band4=sh_band4, record=record, raw=gaussian_raw.raw, sh_mask=gaussian_raw.sh_mask,
+            adapter_eps=gaussian_raw.eps)
+        return (color, depth, alpha, _radii) if return_radii else (color, depth, alpha)
+    assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     n = gaussian_sh_coefficients.shape[-1] + (0 if gaussian_sh_band4 is None else gaussian_sh_band4.shape[-1])
     degree = isqrt(n) - 1
     # SH stays in the encoder's [b,g,3,d_sh] layout: the kernels index it directly (no transposed copy as at
@@ -584,7 +598,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             gaussians.means, gaussians.harmonics, gaussians.opacities, gaussians.rotations, gaussians.scales,
             scale_invariant=self.make_scale_invariant, enable_cov_grad=self.enable_cov_grad,
             enable_sh_grad=self.enable_sh_grad, max_pairs=max_pairs, sh_band4=self.sh_band4, return_radii=True,
-            record=record, gaussian_sh_band4=getattr(gaussians, "harmonics_band4", None))
+            record=record, gaussian_sh_band4=getattr(gaussians, "harmonics_band4", None),
+            gaussian_raw=getattr(gaussians, "raw", None))
         depth = depth[:, :, 0]                                   # "(b v) 1 h w -> b v h w"
         if self.make_scale_invariant:
             depth = depth * near[:, :, None, None]               # decoder_splatting_cuda.py:72-76
@@ -614,8 +629,16 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         return self._render(gaussians, extrinsics, intrinsics, near, far, image_shape, True)
 
     def _render(self, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
-        tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
-                   gaussians.rotations, gaussians.scales)
+        fused = getattr(gaussians, "raw", None)
+        if fused is not None:
+            if not (self.enable_cov_grad and self.enable_sh_grad) and torch.is_grad_enabled() and fused.raw.requires_grad:
+                raise RuntimeError("Gaussians.raw (adapter fused into the decoder) chains the backward to ALL raw channels: "
+                                   "it needs enable_cov_grad and enable_sh_grad")
+            # (same positions as below for what the keys look at: [4] means, [5] stands in for the harmonics)
+            tensors = (extrinsics, intrinsics, near, far, gaussians.means, fused.raw, gaussians.opacities)
+        else:
+            tensors = (extrinsics, intrinsics, near, far, gaussians.means, gaussians.harmonics, gaussians.opacities,
+                       gaussians.rotations, gaussians.scales)
         if getattr(gaussians, "harmonics_band4", None) is not None:
             tensors = tensors + (gaussians.harmonics_band4,)
         auto = (self.auto_plan and (self._max_pairs is None or self._auto_owned) and extrinsics.is_cuda
@@ -625,8 +648,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # ---- the module's own planning (see __init__) ----
         from .rasterizer import plan_pair_budget
         run = lambda: self._render_planned(tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra)
-        shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(gaussians.harmonics.shape),
-                 tuple(image_shape))
+        shape = (tuple(extrinsics.shape[:2]), tuple(gaussians.means.shape), tuple(tensors[5].shape), tuple(image_shape))
         if self._auto_pending is not None:
             # (deferred mode) the last training step's verdict, an event long past: a failed plan is neither used again
             # nor remembered for its shape
@@ -669,6 +691,10 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         return result
 
     def _render_planned(self, tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
+        if getattr(gaussians, "raw", None) is not None:           # (fused adapter: the general launcher, planned or exact)
+            color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
+                                                            self.max_pairs, self.last_call)
+            return DecoderOutput(color, depth), alpha, radii
         tkey = self._prepare_key(tensors, image_shape)
         if tkey is not None:
             entry = self._prepared_steps.get(tkey)

@@ -187,6 +187,30 @@ def _tanfov_tensor(tx: float, ty: float, device) -> Tensor:
     return t
 
 
+def raw_rows(raw: Tensor, d_in: int) -> Tensor:
+    """`raw` as [N, d_in] rows a kernel can read IN PLACE: unit stride along the channels, ONE row stride over all the
+    leading dimensions.  The encoder hands over `gaussians[..., 1:]`, a view into its 83-channel head output
+    (encoder_spfsplatv2.py:261-268): that qualifies -- no contiguous copy, 328 bytes per Gaussian read and written less.
+    Anything else (a permuted tensor, another dtype) is copied once."""
+    if raw.dtype == torch.float32 and raw.stride(-1) == 1:
+        rs, span, ok = None, None, True
+        for size, stride in zip(reversed(raw.shape[:-1]), reversed(raw.stride()[:-1])):
+            if size == 1:
+                continue                       # (unit dimensions -- "b v r srf () c" -- carry no stride of their own)
+            if rs is None:
+                rs = span = stride
+                ok = rs >= d_in
+            elif stride != span:
+                ok = False
+            if not ok:
+                break
+            span *= size
+        if ok:
+            n = raw.numel() // d_in
+            return raw.as_strided((n, d_in), (d_in if rs is None else rs, 1), raw.storage_offset())
+    return raw.reshape(-1, d_in).contiguous().float()
+
+
 def _stream_ptr(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -220,7 +244,8 @@ def _early_verdict(dev: torch.device):
 @_on_device_of_first_arg
 def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg,
                   view_scale, H, W, sh_degree, scale_modifier, max_pairs, sh_layout=0, camera=None, sh_band4=False,
-                  record=None, nothing_needs_grad=False, view64=None, shs_high=None):
+                  record=None, nothing_needs_grad=False, view64=None, shs_high=None, raw=None, sh_mask=None,
+                  adapter_eps=0.0):
     """Launch the forward chain.  Returns (outputs, saved state tensors).  `camera` (an SpfCamera whose outputs are
     viewmatrix / projmatrix / tanfov / view_scale): the decoder fast path -- camera set-up and the clearing of the tile
     counters are one kernel."""
@@ -257,6 +282,8 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
         return ((image, depth, alpha, radii_v),
                 (rec, radii_v.view(-1), rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, 0, pairs.numel()))
     K = 0 if shs is None else (25 if sh_layout == 2 else shs.shape[3 if sh_layout else 2])
+    if raw is not None:                      # raw rows [S*G, 7 + 3K] (sh_layout 3): the adapter fused into the projection kernels
+        K = (raw.shape[1] - 7) // 3
     T = lib.spf_raster_num_tiles(H, W)
     P = H * W
     # DIRECT BINS (planned calls): every tile owns a fixed bin of `bin_cap` keys that the projection kernel fills itself
@@ -266,14 +293,14 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     # sharded (each of 8 shards owns an eighth: see _record_capacity)
     rec_cap = _record_capacity(_plan_numbers(max_pairs, R * T)[0], S, G) if bin_cap else 0
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
-                        bin_cap, rec_cap)
+                        bin_cap, rec_cap, 0 if raw is None else raw.stride(0), float(adapter_eps))
     nblk = lib.spf_raster_view_partial_blocks(G)
     rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha, _ = _alloc_forward(dev, S, V, G, H, W, T, nblk)
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale), _ptr(view64), _ptr(shs_high))
+                         _ptr(view_scale), _ptr(view64), _ptr(shs_high), _ptr(raw), _ptr(sh_mask))
     pairs = torch.empty((R * T * bin_cap,), dtype=torch.int64, device=dev) if bin_cap else None
     # check="early" with direct bins: the projection kernel mirrors a raised plan flag into a pinned word the host reads
     # behind an event -- no device->host copy on the stream (SpfState.verdict_host)
@@ -460,10 +487,11 @@ def _plan_mode(max_pairs) -> int:
 
 
 @_on_device_of_first_arg
-def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
+def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None, raw=None, sh_mask=None, adapter_eps=0.0):
     """Launch the backward chain.  `want`: dict of booleans (scales_rot, shs, colors, view, means2D).  `shs_high`: the
     band-4 plane of the band-split harmonics (sh_layout 2); its gradient is appended to the result -- None unless band 4
-    was evaluated (a degree-3 evaluation neither reads the plane nor writes its gradient)."""
+    was evaluated (a degree-3 evaluation neither reads the plane nor writes its gradient).  `raw` [S*G, 7+3K] (sh_layout
+    3): scales / rotations / shs are None and the result carries dL/draw [S*G, 7+3K] as its LAST element."""
     lib = _lib.load()
     means3D, scales, rotations, opacities, shs, colors, viewmatrix, projmatrix, tanfov, bg, view_scale, view64 = inputs
     rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib = state
@@ -478,7 +506,7 @@ def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
                               (bin_cap, capacity, lib.spf_raster_pair_shards(S, G)) if bin_cap else None)
     from .shard import active_bucket
     bucket = active_bucket()
-    fast = _lib.fast() if (bucket is None and shs_high is None) else None   # (a gradient bucket supplies the output buffers, the split layout a second plane: ctypes path)
+    fast = _lib.fast() if (bucket is None and shs_high is None and raw is None) else None   # (a gradient bucket supplies the output buffers, the split layout a second plane, raw rows another input: ctypes path)
     if fast is not None:
         wv = want["view"]
         with _spf_errors():
@@ -491,7 +519,7 @@ def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
                 2 if wv == "partials" else (1 if wv else 0), bool(want["means2D"]))
         return tuple(out)
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, scale_modifier, int(sh_layout), int(sh_band4), int(bin_cap),
-                        int(capacity) if bin_cap else 0)
+                        int(capacity) if bin_cap else 0, 0 if raw is None else raw.stride(0), float(adapter_eps))
     f32 = dict(dtype=torch.float32, device=dev)
     g_image, g_depth, g_alpha = (None if g is None else g.contiguous().float() for g in grads_out)
     nblk = lib.spf_raster_view_partial_blocks(G)
@@ -501,8 +529,9 @@ def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
         return torch.empty_like(like) if v is None else v
     d_means = out("means", means3D)
     d_opac = out("opacities", opacities)
-    d_scales = out("scales", scales) if want["scales_rot"] else None
-    d_rot = out("rotations", rotations) if want["scales_rot"] else None
+    d_scales = out("scales", scales) if (want["scales_rot"] and raw is None) else None
+    d_rot = out("rotations", rotations) if (want["scales_rot"] and raw is None) else None
+    d_raw = torch.empty((raw.shape[0], raw.shape[1]), **f32) if raw is not None else None
     d_shs = out("harmonics", shs) if (shs is not None and want["shs"]) else None
     d_shs_high = None
     if d_shs is not None and sh_layout == 2 and sh_band4 and sh_degree == 4:
@@ -515,14 +544,16 @@ def _backward_impl(inputs, state, geom, grads_out, want, shs_high=None):
     d_m2d = torch.zeros((R, G, 3), **f32) if want["means2D"] else None
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
                          _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(tanfov), _ptr(bg),
-                         _ptr(view_scale), _ptr(view64), _ptr(shs_high))
+                         _ptr(view_scale), _ptr(view64), _ptr(shs_high), _ptr(raw), _ptr(sh_mask))
     st = _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, R * T, R * G, R * nblk)
     gr = _lib.SpfGrads(_ptr(g_image), _ptr(g_depth), _ptr(g_alpha), _ptr(gpair), _ptr(vpartial),
                        _ptr(d_means), _ptr(d_scales), _ptr(d_rot), _ptr(d_opac), _ptr(d_shs), _ptr(d_col),
-                       _ptr(d_view), _ptr(d_m2d), _ptr(d_shs_high))
+                       _ptr(d_view), _ptr(d_m2d), _ptr(d_shs_high), _ptr(d_raw))
     _lib.check(lib.spf_raster_backward(C.byref(dims), C.byref(inp), C.byref(st), C.byref(gr), capacity, dense,
                                        _stream_ptr(dev)), "spf_raster_backward")
     res = (d_means, d_scales, d_rot, d_opac, d_shs, d_col, (vpartial if want["view"] == "partials" else d_view), d_m2d)
+    if raw is not None:
+        return res + (d_raw,)
     return res if shs_high is None else res + (d_shs_high,)
 
 
@@ -570,7 +601,7 @@ class _DecoderRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, colors, bg,
                 H, W, sh_degree, scale_invariant, enable_cov_grad, enable_sh_grad, max_pairs, sh_layout, sh_band4,
-                record, grad_mode, shs_high=None):
+                record, grad_mode, shs_high=None, raw=None, sh_mask=None, adapter_eps=0.0):
         ctx.set_materialize_grads(False)
         lib = _lib.load()
         S, V = extrinsics.shape[:2]
@@ -583,19 +614,29 @@ class _DecoderRender(torch.autograd.Function):
         # the pose once more in float64, world scale folded in: the projection kernels form the view-space position
         # from it (SpfInputs.viewmatrix64)
         view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
+        # raw rows (sh_layout 3): the caller's tensor, whatever its shape; its [S*G, 7+3K] rows are taken HERE, outside
+        # autograd's view (an as_strided under autograd costs a zero fill and a scatter of the whole tensor in backward)
+        rows = None
+        if raw is not None:
+            rows = raw_rows(raw.detach(), raw.shape[-1])
+            ctx.raw_shape = tuple(raw.shape)
         cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(view), _ptr(proj),
                              _ptr(tanfov), _ptr(vscale), S * V, 1 if scale_invariant else 0, _ptr(view64))
         outs, state, dense = _forward_impl(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov,
                                            bg, vscale, H, W, sh_degree, 1.0, max_pairs, sh_layout, camera=cam,
                                            sh_band4=sh_band4, record=record,
                                            nothing_needs_grad=not (grad_mode and any(ctx.needs_input_grad)),
-                                           view64=view64, shs_high=shs_high)
+                                           view64=view64, shs_high=shs_high, raw=rows, sh_mask=sh_mask,
+                                           adapter_eps=adapter_eps)
         G = means3D.shape[1]
         K = 0 if shs is None else (25 if sh_layout == 2 else shs.shape[3 if sh_layout else 2])
+        if rows is not None:
+            K = (rows.shape[1] - 7) // 3
+        ctx.adapter_eps = float(adapter_eps)
         ctx.geom = (S, V, G, K, sh_degree, H, W, 1.0, _plan_mode(max_pairs), dense, int(sh_layout), bool(sh_band4))
         ctx.flags = (bool(enable_cov_grad), bool(enable_sh_grad), bool(scale_invariant))
         ctx.save_for_backward(means3D, scales, rotations, opacities, shs, colors, view, proj, tanfov, bg, vscale,
-                              view64, *state, near, shs_high)
+                              view64, *state, near, shs_high, rows, sh_mask)
         ctx.mark_non_differentiable(outs[3])
         return outs
 
@@ -607,9 +648,15 @@ class _DecoderRender(torch.autograd.Function):
         enable_cov_grad, enable_sh_grad, scale_invariant = ctx.flags
         want = dict(scales_rot=enable_cov_grad and (need[5] or need[6]), shs=enable_sh_grad and need[8],
                     colors=need[9], view="partials" if need[0] else False, means2D=False)
-        shs_high = saved[21]
+        shs_high, rows, sh_mask = saved[21], saved[22], saved[23]
+        if rows is not None:
+            want = dict(want, scales_rot=True, shs=True)
         d_means, d_scales, d_rot, d_opac, d_shs, d_col, vpartial, _, *d_high = _backward_impl(
-            saved[:12], saved[12:20], ctx.geom, (g_image, g_depth, g_alpha), want, shs_high=shs_high)
+            saved[:12], saved[12:20], ctx.geom, (g_image, g_depth, g_alpha), want, shs_high=shs_high, raw=rows,
+            sh_mask=sh_mask, adapter_eps=ctx.adapter_eps)
+        d_raw = None
+        if rows is not None:
+            d_raw, d_high = d_high[0].view(ctx.raw_shape), []
         d_ext = None
         if need[0]:
             view, near = saved[6], saved[20]
@@ -621,7 +668,8 @@ class _DecoderRender(torch.autograd.Function):
                                                             _ptr(d_ext), _stream_ptr(view.device)),
                            "spf_camera_backward_partials")
         return (d_ext, None, None, None, d_means, d_scales, d_rot, d_opac, d_shs, d_col, None,
-                None, None, None, None, None, None, None, None, None, None, None, d_high[0] if d_high else None)
+                None, None, None, None, None, None, None, None, None, None, None, d_high[0] if d_high else None,
+                d_raw, None, None)
 
 
 class StaticStep:
@@ -789,7 +837,8 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                  image_height: int, image_width: int, sh_degree: int, scale_invariant: bool = True,
                  enable_cov_grad: bool = True, enable_sh_grad: bool = True, max_pairs=None,
                  sh_layout: str = "gk3", sh_band4: Optional[bool] = None, record: Optional[CallRecord] = None,
-                 shs_high: Optional[Tensor] = None):
+                 shs_high: Optional[Tensor] = None, raw: Optional[Tensor] = None, sh_mask: Optional[Tensor] = None,
+                 adapter_eps: float = 1e-8):
     """Poses in, images out: camera set-up (render_cuda's preamble) and rasterization in one autograd node.
 
     extrinsics [S,V,4,4] camera-to-world, intrinsics [S,V,3,3] normalised, near/far [S,V]; Gaussians as in
@@ -801,6 +850,9 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
     band 4 when ``sh_degree`` is 4 (None = ``sh_band4_default()``).  ``record``: a ``CallRecord`` that receives this
     call's statistics / plan counters.  Returns image [S,V,3,H,W], depth [S,V,1,H,W] (rasterizer units),
     alpha [S,V,1,H,W], radii [S,V,G]."""
+    if raw is not None:
+        return _render_batch_raw(extrinsics, intrinsics, near, far, means3D, opacities, raw, sh_mask, adapter_eps, bg,
+                                 image_height, image_width, sh_degree, scale_invariant, max_pairs, sh_band4, record)
     if (shs is None) == (colors_precomp is None):
         raise RuntimeError("provide exactly one of shs / colors_precomp")
     S, G, _ = means3D.shape
@@ -840,6 +892,42 @@ def render_batch(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tens
                                 colors_precomp, bg, int(image_height), int(image_width), int(sh_degree),
                                 bool(scale_invariant), enable_cov_grad, enable_sh_grad, max_pairs, layout,
                                 bool(sh_band4), record, torch.is_grad_enabled(), shs_high)
+
+
+def _render_batch_raw(extrinsics, intrinsics, near, far, means3D, opacities, raw, sh_mask, adapter_eps, bg, image_height,
+                      image_width, sh_degree, scale_invariant, max_pairs, sh_band4, record):
+    """render_batch on RAW ROWS (SpfDims.sh_layout 3): `raw` [S, G, 7+3K] -- any leading shape with S*G rows, unit stride
+    along the channels, e.g. a view of the encoder's 83-channel head output -- holds what UnifiedGaussianAdapter.forward
+    takes (gaussian_adapter.py:122-150); `sh_mask` [K] and `adapter_eps` are the adapter's.  The projection kernels
+    apply the adapter's activations as they read a row and chain the backward through them into dL/draw: same images
+    and gradients as adapter -> decoder, bit for bit, without the adapter's pass over the tensor in either direction."""
+    S, G, _ = means3D.shape
+    V = extrinsics.shape[1]
+    extrinsics = _f32c(extrinsics, "extrinsics", (S, V, 4, 4))
+    intrinsics = _f32c(intrinsics, "intrinsics", (S, V, 3, 3))
+    near = _f32c(near, "near", (S, V))
+    far = _f32c(far, "far", (S, V))
+    means3D = _f32c(means3D, "means3D", (S, G, 3))
+    opacities = _f32c(opacities.reshape(S, G), "opacities", (S, G))
+    if not isinstance(raw, Tensor) or not raw.is_cuda or raw.dtype != torch.float32:
+        raise RuntimeError("raw must be a float32 tensor on a HIP device (there is no CPU fallback)")
+    C_ = raw.shape[-1]
+    K = (C_ - 7) // 3
+    if C_ != 7 + 3 * K or K < 1 or raw.numel() != S * G * C_:
+        raise RuntimeError(f"raw must hold S*G = {S * G} rows of 7 + 3*d_sh channels, got {tuple(raw.shape)}")
+    if not (0 <= sh_degree <= 4) or K < (min(sh_degree, 4 if sh_band4 else 3) + 1) ** 2:
+        raise RuntimeError(f"raw holds {K} coefficients per channel, too few for sh_degree {sh_degree}")
+    if sh_mask is None:
+        raise RuntimeError("raw rows need the adapter's sh_mask")
+    sh_mask = _f32c(sh_mask, "sh_mask", (K,))
+    if sh_band4 is None:
+        sh_band4 = sh_band4_default()
+        _note_band4_not_evaluated(sh_degree, sh_band4)
+    bg = _background(bg, S, V)
+    return _DecoderRender.apply(extrinsics, intrinsics, near, far, means3D, None, None, opacities, None, None, bg,
+                                int(image_height), int(image_width), int(sh_degree), bool(scale_invariant), True, True,
+                                max_pairs, 3, bool(sh_band4), record, torch.is_grad_enabled(), None, raw, sh_mask,
+                                float(adapter_eps))
 
 
 def rasterize_batch(means3D: Tensor, scales: Tensor, rotations: Tensor, opacities: Tensor,

@@ -61,7 +61,7 @@ def test_secondary_children_parse_and_cover_the_verdict_list():
     b = _bench()
     names = [n for n, _, _ in b.SECONDARY]
     assert names == ["C3", "C5", "REF2V", "REF2V_band4", "REF10V", "REF2V_split", "REF10V_split", "REF2V_adapter",
-                     "REF2V_adapter_split", "REF10V_adapter_split", "C2_stress", "C2_module", "C2_streams2", "eval_1x3",
+                     "REF2V_adapter_split", "REF10V_adapter_split", "REF2V_raw_fused", "REF10V_raw_fused", "C2_stress", "C2_module", "C2_streams2", "eval_1x3",
                      "rope2d"]
     for _name, extra, env in b.SECONDARY:
         a = b.parse_args(["--gpus", "1", "--no-cpu-baseline", "--no-secondary", *extra])

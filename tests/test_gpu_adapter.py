@@ -78,3 +78,59 @@ def test_adapter_feeds_decoder(hip_lib):
               b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
     ((out.color - b.target) ** 2).mean().backward()
     assert bool(torch.isfinite(raw.grad).all()) and float(raw.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("deg,views,strided", [(4, 2, True), (1, 3, False), (0, 1, False), (4, 9, False)],
+                         ids=["d_sh25_view_of_head", "d_sh4", "d_sh1", "d_sh25_nine_views"])
+def test_adapter_fused_into_the_decoder_is_the_two_pass_path_bit_for_bit(hip_lib, deg, views, strided):
+    """`UnifiedGaussianAdapter(fuse_into_decoder=True)` + `DecoderSplattingCUDA` (SpfDims.sh_layout 3: the projection
+    kernels apply the adapter's activations as they read a raw row and chain the backward through them) against the
+    adapter's own kernels followed by the decoder on their outputs: images, depth, alpha, radii and EVERY gradient --
+    to the raw network channels, the means, the opacities, the poses -- bit-identical, with the raw rows read in place
+    from a strided view of an 83-channel head output (encoder_spfsplatv2.py:261-268); nine views: the gradient of the
+    harmonics leaves through the unstaged path."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import adapter, synthetic as syn
+    K = (deg + 1) ** 2
+    b = syn.make_batch("TEST", 2, views, seed=61 + deg, s_mult=8.0, G=900, K=K, image_hw=(64, 48)).to("cuda")
+    gen = torch.Generator("cuda").manual_seed(7)
+    cfg = adapter.GaussianAdapterCfg(0.5, 15.0, deg)
+    plain, fused = adapter.UnifiedGaussianAdapter(cfg).cuda(), adapter.UnifiedGaussianAdapter(cfg, fuse_into_decoder=True).cuda()
+    C = 7 + 3 * K
+    head = torch.randn(2, 900, C + 1, device="cuda", generator=gen)
+    head[..., 1:4] = head[..., 1:4] * 3.0 + 6.0                  # scales of a few per cent of the scene (some at the 0.3 clamp)
+    head[..., 8:] *= 30.0                                          # (the mask scales the higher bands down by 40 .. 2,560)
+    dec = spf.get_decoder(spf.DecoderSplattingCUDACfg("splatting_cuda", [0.1, 0.2, 0.3], True, True, True)).cuda()
+    dec.auto_plan = None
+    dec.sh_band4 = deg == 4
+    w = torch.rand(2, views, 3, 64, 48, device="cuda", generator=gen)
+
+    def run(ad, raw_leaf, raw_in):
+        leaves = {"means": b.means.clone().requires_grad_(True), "opacities": b.opacities.clone().requires_grad_(True),
+                  "extrinsics": b.extrinsics.clone().requires_grad_(True)}
+        g = ad(leaves["means"], leaves["opacities"], raw_in, with_covariances=False)
+        out, alpha, radii = dec.render(spf.Gaussians(g.means, None, g.rotations, g.scales, g.harmonics, g.opacities, raw=g.raw),
+                                       leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+        ((out.color * w).sum() + 0.1 * (out.depth * w[:, :, 0]).sum() + 0.1 * (alpha * w[:, :, :1]).sum()).backward()
+        return out, alpha, radii, {n: t.grad for n, t in leaves.items()}, raw_leaf.grad
+
+    if strided:
+        h1, h2 = head.clone().requires_grad_(True), head.clone().requires_grad_(True)
+        a = run(plain, h1, h1[..., 1:].contiguous())
+        f = run(fused, h2, h2[..., 1:])                           # a VIEW: row stride 7 + 3K + 1
+        ga, gf = a[4][..., 1:], f[4][..., 1:]
+        assert float(f[4][..., 0].abs().max()) == 0.0
+    else:
+        r1, r2 = head[..., 1:].contiguous().requires_grad_(True), head[..., 1:].contiguous().requires_grad_(True)
+        a, f = run(plain, r1, r1), run(fused, r2, r2)
+        ga, gf = a[4], f[4]
+    assert torch.equal(f[0].color, a[0].color) and torch.equal(f[0].depth, a[0].depth)
+    assert torch.equal(f[1], a[1]) and torch.equal(f[2], a[2])
+    for n in a[3]:
+        assert torch.equal(f[3][n], a[3][n]), (n, float((f[3][n] - a[3][n]).abs().max()))
+    assert torch.equal(gf, ga), float((gf - ga).abs().max() / ga.abs().max())
+    assert float(ga[..., :7].abs().max()) > 0 and float(ga[..., 7:].abs().max()) > 0
+    # the other consumers of a fused-mode Gaussians get the standard fields on request
+    g = fused(b.means, b.opacities, head[..., 1:], with_covariances=False)
+    m, p_ = adapter.materialize(g), plain(b.means, b.opacities, head[..., 1:].contiguous(), with_covariances=False)
+    assert g.scales is None and torch.equal(m.scales, p_.scales) and torch.equal(m.harmonics, p_.harmonics)
