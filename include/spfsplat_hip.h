@@ -75,8 +75,8 @@ typedef struct SpfDims {
                             scales = min(0.001 softplus(raw[0:3]), 0.3), rotations = raw[3:7] / (|.| + adapter_eps) and
                             sh[c][k] = raw[7 + c K + k] * sh_mask[k] as they read the row, and the backward chains through
                             them into dL_draw -- the adapter's own pass over 656 + 576 bytes per Gaussian and step (more
-                            than the decoder's) never happens.  Same numbers as spf_adapter_forward -> sh_layout 1, bit
-                            for bit */
+                            than the decoder's) never happens.  The same expressions in the same order as
+                            spf_adapter_forward -> sh_layout 1: results agree to float32 rounding */
     int32_t sh_band4;    /* 0 (default): the reference's d_sh = 25 / sh_degree 4 (config/model/encoder/spfsplatv2.yaml:20,
                             cuda_splatting.py:77-78,114) is accepted as a stride and evaluated to degree 3 like the
                             published 3DGS kernels; 1: band 4 (coefficients 16..24) is evaluated too, forward and

@@ -109,7 +109,7 @@ class UnifiedGaussianAdapter(nn.Module):
         # `fuse_into_decoder` (not an argument of the reference's class): `forward` launches NOTHING -- it returns a
         # `Gaussians` whose `raw` field carries the raw channels, the SH mask and eps, and whose scales / rotations /
         # harmonics are None (`materialize()` produces them for any other consumer); the decoder applies the adapter inside
-        # its projection kernels.  Same images and gradients, bit for bit (tests/test_gpu_adapter.py).
+        # its projection kernels.  Same images and gradients, to float32 rounding (tests/test_gpu_adapter.py).
         self.fuse_into_decoder = bool(fuse_into_decoder)
         if split_harmonics and cfg.sh_degree != 4:
             raise ValueError("split_harmonics is the 16 + 9 split of sh_degree 4 (d_sh = 25)")

@@ -250,7 +250,7 @@ __device__ __forceinline__ void st4(float* __restrict__ p, float a, float b, flo
 // NATIVE == 3 (raw rows, SpfDims.sh_layout 3): `sh` points at channel 7 of the Gaussian's RAW row -- the native [3][K]
 // arrangement at dword alignment -- and every coefficient is scaled by the adapter's sh_mask[k] as it is read (`mk`, in the
 // constant address space: scalar loads): raw * mask rounded to float32 first, exactly the value spf_adapter_forward
-// would have stored, so colours and gradients are bit-identical to the two-pass path.
+// would have stored (the two-pass path's numbers, to the rounding of a differently contracted multiply-add).
 template <int NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_load4(const float* __restrict__ sh, const float* __restrict__ hi, int K, int k4,
                                          float v[4][3], kfloat_p mk = nullptr) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3) ? 3 : SPF_PFWD_BP
     const size_t sg = (size_t)s * d.G + (live ? g : 0);
     const float p0[3] = {in.means3D[3 * sg], in.means3D[3 * sg + 1], in.means3D[3 * sg + 2]};
     // raw rows (sh_layout 3): the adapter's activations as the row is read -- the same expressions, in the same order,
-    // as spf_adapter_fwd_kernel (adapter.hip): bit-identical scales and rotations
+    // as spf_adapter_fwd_kernel (adapter.hip)
     constexpr bool kRaw = NATIVE == 3;
     const float* __restrict__ raw_row = kRaw ? in.raw + sg * (size_t)d.raw_stride : nullptr;
     const kfloat_p mk = kRaw ? as_const(in.sh_mask) : nullptr;
@@ -1211,8 +1211,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         }
     }
     // raw rows: dL/draw[0..6] -- the scale and rotation gradients chained through the adapter's activations, with the
-    // expressions (and their order) of spf_adapter_bwd_kernel: the row this kernel writes is bit for bit the one the
-    // adapter's backward would have produced from this kernel's dL/dscales, dL/drotations, dL/dsh
+    // expressions (and their order) of spf_adapter_bwd_kernel: the row this kernel writes is the one the adapter's
+    // backward would have produced from this kernel's dL/dscales, dL/drotations, dL/dsh
     float graw[kRaw ? 7 : 1];
     if constexpr (kRaw) {
         float rr[7];

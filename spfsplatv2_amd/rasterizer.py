@@ -900,7 +900,8 @@ def _render_batch_raw(extrinsics, intrinsics, near, far, means3D, opacities, raw
     along the channels, e.g. a view of the encoder's 83-channel head output -- holds what UnifiedGaussianAdapter.forward
     takes (gaussian_adapter.py:122-150); `sh_mask` [K] and `adapter_eps` are the adapter's.  The projection kernels
     apply the adapter's activations as they read a row and chain the backward through them into dL/draw: same images
-    and gradients as adapter -> decoder, bit for bit, without the adapter's pass over the tensor in either direction."""
+    and gradients as adapter -> decoder (to float32 rounding), without the adapter's pass over the tensor in either
+    direction."""
     S, G, _ = means3D.shape
     V = extrinsics.shape[1]
     extrinsics = _f32c(extrinsics, "extrinsics", (S, V, 4, 4))

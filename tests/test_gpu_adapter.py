@@ -82,13 +82,15 @@ def test_adapter_feeds_decoder(hip_lib):
 
 @pytest.mark.parametrize("deg,views,strided", [(4, 2, True), (1, 3, False), (0, 1, False), (4, 9, False)],
                          ids=["d_sh25_view_of_head", "d_sh4", "d_sh1", "d_sh25_nine_views"])
-def test_adapter_fused_into_the_decoder_is_the_two_pass_path_bit_for_bit(hip_lib, deg, views, strided):
+def test_adapter_fused_into_the_decoder_is_the_two_pass_path(hip_lib, deg, views, strided):
     """`UnifiedGaussianAdapter(fuse_into_decoder=True)` + `DecoderSplattingCUDA` (SpfDims.sh_layout 3: the projection
     kernels apply the adapter's activations as they read a raw row and chain the backward through them) against the
-    adapter's own kernels followed by the decoder on their outputs: images, depth, alpha, radii and EVERY gradient --
-    to the raw network channels, the means, the opacities, the poses -- bit-identical, with the raw rows read in place
-    from a strided view of an 83-channel head output (encoder_spfsplatv2.py:261-268); nine views: the gradient of the
-    harmonics leaves through the unstaged path."""
+    adapter's own kernels followed by the decoder on their outputs: the same expressions in the same order, so images,
+    depth, alpha and EVERY gradient -- to the raw network channels, the means, the opacities, the poses -- agree to
+    float32 rounding (another instantiation of the kernels: the compiler may contract a multiply-add differently; 2e-6 /
+    2e-5 of scale here, north_star asks for 1e-4 / 1e-3) and the radii exactly, with the raw rows read in place from a
+    strided view of an 83-channel head output (encoder_spfsplatv2.py:261-268); nine views: the gradient of the harmonics
+    leaves through the unstaged path."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import adapter, synthetic as syn
     K = (deg + 1) ** 2
@@ -124,11 +126,14 @@ def test_adapter_fused_into_the_decoder_is_the_two_pass_path_bit_for_bit(hip_lib
         r1, r2 = head[..., 1:].contiguous().requires_grad_(True), head[..., 1:].contiguous().requires_grad_(True)
         a, f = run(plain, r1, r1), run(fused, r2, r2)
         ga, gf = a[4], f[4]
-    assert torch.equal(f[0].color, a[0].color) and torch.equal(f[0].depth, a[0].depth)
-    assert torch.equal(f[1], a[1]) and torch.equal(f[2], a[2])
+    from tests import util
+    for got, want, what in ((f[0].color, a[0].color, "color"), (f[0].depth, a[0].depth, "depth"), (f[1], a[1], "alpha")):
+        assert util.rel_linf(got, want) < 2e-6, (what, util.rel_linf(got, want))
+    assert torch.equal(f[2], a[2])                                   # radii
     for n in a[3]:
-        assert torch.equal(f[3][n], a[3][n]), (n, float((f[3][n] - a[3][n]).abs().max()))
-    assert torch.equal(gf, ga), float((gf - ga).abs().max() / ga.abs().max())
+        assert util.rel_linf(f[3][n], a[3][n]) < 2e-5, (n, util.rel_linf(f[3][n], a[3][n]))
+    assert util.rel_linf(gf, ga) < 2e-5, util.rel_linf(gf, ga)
+    assert util.rel_linf(gf[..., :7], ga[..., :7]) < 2e-5 and util.rel_linf(gf[..., 7:], ga[..., 7:]) < 2e-5
     assert float(ga[..., :7].abs().max()) > 0 and float(ga[..., 7:].abs().max()) > 0
     # the other consumers of a fused-mode Gaussians get the standard fields on request
     g = fused(b.means, b.opacities, head[..., 1:], with_covariances=False)
