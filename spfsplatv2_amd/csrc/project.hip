@@ -1390,7 +1390,7 @@ template <int DEG, int NATIVE>
 static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const SpfInputs& in, const SpfState& st,
                           const SpfGrads& g, int nblk, uint64_t capacity) {
     size_t lds = (size_t)(d.V < kViewChunk ? d.V : kViewChunk) * 48 * sizeof(float);
-    if (DEG >= 2 && g.dL_dshs) {
+    if (DEG >= 2 && (g.dL_dshs || g.dL_draw)) {
         lds += (size_t)(d.V < kShChunk ? d.V : kShChunk) * 6 * kBlock * sizeof(float);
         if (sh_stage_out(d.V, d.K, NATIVE == 3))      // staged dL/dsh (raw rows: the dL/draw rows), half a block at a time
             lds += (size_t)128 * sh_stage_row(d.K, NATIVE == 3) * sizeof(float);
