@@ -446,7 +446,7 @@ __device__ __forceinline__ void sh_grad_from_parked(float* __restrict__ o, float
         }
         if (!first) {
             float old[4][3];
-            sh_load4<NATIVE, ALIGNED>(o, o_hi, K, k4, old);
+            sh_load4<(NATIVE == 3 ? 1 : NATIVE), ALIGNED>(o, o_hi, K, k4, old);      // (what an earlier chunk stored: already masked)
 #pragma unroll
             for (int i = 0; i < 4; ++i) { acc[i][0] += old[i][0]; acc[i][1] += old[i][1]; acc[i][2] += old[i][2]; }
         }
