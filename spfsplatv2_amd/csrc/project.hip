@@ -932,12 +932,22 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     const float* __restrict__ raw_row = kRaw ? in.raw + sg * (size_t)d.raw_stride : nullptr;
     const kfloat_p mk = kRaw ? as_const(in.sh_mask) : nullptr;
     const int CR = 7 + 3 * d.K;                                       // floats of a raw row / of a dL_draw row
+    float raw_dact[kRaw ? 3 : 1] = {};                                // (raw rows) d scale / d raw[0:3] without the 0.001
     if (live) {
         p0[0] = in.means3D[3 * sg]; p0[1] = in.means3D[3 * sg + 1]; p0[2] = in.means3D[3 * sg + 2];
         if (kRaw) {      // (the adapter's activations, as in the forward kernel)
-            sx = fminf(0.001f * softplus_torch(raw_row[0]), 0.3f) * d.scale_modifier;
-            sy = fminf(0.001f * softplus_torch(raw_row[1]), 0.3f) * d.scale_modifier;
-            sz = fminf(0.001f * softplus_torch(raw_row[2]), 0.3f) * d.scale_modifier;
+            float act[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                // ... and what their backward needs, formed here once (three registers through the view loop instead of
+                // three more softplus + exp chains and a second look at the row at the end): softplus' x the clamp's pass
+                const float xx = raw_row[i];
+                const float sp = softplus_torch(xx);
+                act[i] = fminf(0.001f * sp, 0.3f) * d.scale_modifier;
+                const float dsp = xx > 20.f ? 1.f : 1.f / (1.f + expf(-xx));
+                raw_dact[i] = (0.001f * sp <= 0.3f) ? dsp : 0.f;
+            }
+            sx = act[0]; sy = act[1]; sz = act[2];
             const float q0 = raw_row[3], q1 = raw_row[4], q2 = raw_row[5], q3 = raw_row[6];
             const float inv = 1.0f / (sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3) + d.adapter_eps);
             q = make_float4(q0 * inv, q1 * inv, q2 * inv, q3 * inv);
@@ -1215,18 +1225,19 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     // backward would have produced from this kernel's dL/dscales, dL/drotations, dL/dsh
     float graw[kRaw ? 7 : 1];
     if constexpr (kRaw) {
-        float rr[7];
+        float rr[7] = {0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 7; ++i) rr[i] = live ? raw_row[i] : (i == 3 ? 1.f : 0.f);
+        for (int i = 3; i < 7; ++i) rr[i] = live ? raw_row[i] : rr[i];         // (the quaternion: four floats from the L2)
         const float nrm = sqrtf(rr[3] * rr[3] + rr[4] * rr[4] + rr[5] * rr[5] + rr[6] * rr[6]);
         const float dn = nrm + d.adapter_eps, inv = 1.0f / dn;
         const float4 q2 = make_float4(rr[3] * inv, rr[4] * inv, rr[5] * inv, rr[6] * inv);
         float R[9];
         quat_rot(q2, R);
         float ds[3], dR[9];
+        const float svv[3] = {sx, sy, sz};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float sv = fminf(0.001f * softplus_torch(rr[k]), 0.3f) * d.scale_modifier;
+            const float sv = svv[k];
             ds[k] = (dN0[k] * R[k] + dN0[3 + k] * R[3 + k] + dN0[6 + k] * R[6 + k]) * d.scale_modifier;
 #pragma unroll
             for (int i = 0; i < 3; ++i) dR[3 * i + k] = dN0[3 * i + k] * sv;
@@ -1241,13 +1252,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
         dq[3] = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] +
                        y * dR[7]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float xx = rr[i];
-            const float sp = softplus_torch(xx);
-            const float dsp = xx > 20.f ? 1.f : 1.f / (1.f + expf(-xx));
-            const float pass = (0.001f * sp <= 0.3f) ? 1.f : 0.f;
-            graw[i] = ds[i] * 0.001f * dsp * pass;
-        }
+        for (int i = 0; i < 3; ++i) graw[i] = ds[i] * 0.001f * raw_dact[i];     // (= ds * 0.001 * softplus' * pass: pass is 0 or 1)
         const float dot = dq[0] * rr[3] + dq[1] * rr[4] + dq[2] * rr[5] + dq[3] * rr[6];
         const float kk = nrm > 0.f ? dot / (nrm * dn * dn) : 0.f;
 #pragma unroll

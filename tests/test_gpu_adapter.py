@@ -5,6 +5,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests import util  # noqa: E402
+
 
 @pytest.mark.parametrize("deg", [0, 2, 4])
 def test_adapter_matches_reference(hip_lib, golden_dir, deg):
@@ -139,3 +141,54 @@ def test_adapter_fused_into_the_decoder_is_the_two_pass_path(hip_lib, deg, views
     g = fused(b.means, b.opacities, head[..., 1:], with_covariances=False)
     m, p_ = adapter.materialize(g), plain(b.means, b.opacities, head[..., 1:].contiguous(), with_covariances=False)
     assert g.scales is None and torch.equal(m.scales, p_.scales) and torch.equal(m.harmonics, p_.harmonics)
+
+
+def test_adapter_fused_into_the_decoder_against_the_oracle(hip_lib):
+    """The fused path held against the ORACLE, not against the product's other path: raw rows -> a float64 torch
+    restatement of UnifiedGaussianAdapter.forward (gaussian_adapter.py:122-150: 0.001 softplus clamped at 0.3, q / (|q| +
+    eps), raw x sh_mask) -> oracle/splat_ref.py, its gradients chained back to the raw channels by autograd; the usual
+    gates (RGB 1e-4, gradients 1e-3 of scale and 1e-2 per element, radii exact, knife-edge pixels masked on both sides)."""
+    import spfsplatv2_amd as spf
+    from spfsplatv2_amd import adapter, synthetic as syn
+    K, S, V, G = 25, 2, 2, 1200
+    batch = syn.make_batch("TEST", S, V, seed=77, s_mult=10.0, G=G, K=K, image_hw=(64, 48))
+    gen = torch.Generator().manual_seed(78)
+    raw = torch.randn(S, G, 7 + 3 * K, generator=gen)
+    raw[..., :3] = raw[..., :3] * 8.0 + 60.0                    # scales of ~0.06 scene units (softplus' x > 20 branch) ...
+    raw[:, :G // 3, :3] = torch.randn(S, G // 3, 3, generator=gen) * 2.0 + 2.0      # ... a third of them tiny (x < 20) ...
+    raw[:, -10:, :3] = 400.0                                    # ... and ten at the 0.3 clamp (no gradient through it)
+    raw[..., 7:] *= torch.cat((torch.ones(1), torch.full((3,), 40.0), torch.full((5,), 160.0), torch.full((7,), 640.0),
+                               torch.full((9,), 2560.0))).repeat(3) * 0.5      # (so that the masked bands all matter)
+    cfg = adapter.GaussianAdapterCfg(0.5, 15.0, 4)
+    fused = adapter.UnifiedGaussianAdapter(cfg, fuse_into_decoder=True).cuda()
+    mask64, eps = fused.sh_mask.double().cpu(), 1e-8
+
+    def adapter64(r):                                          # gaussian_adapter.py:122-150, float64
+        scales = (0.001 * torch.nn.functional.softplus(r[..., :3])).clamp_max(0.3)
+        rot = r[..., 3:7] / (r[..., 3:7].norm(dim=-1, keepdim=True) + eps)
+        return scales, rot, r[..., 7:].reshape(*r.shape[:-1], 3, K) * mask64
+
+    with torch.no_grad():
+        sc, ro, sh = adapter64(raw.double())
+    batch.scales, batch.rotations, batch.harmonics = sc.float(), ro.float(), sh.float()
+    ref = util.run_oracle(batch, torch.float64, background=(0.1, 0.2, 0.3), mask_fragile=True, band4=False)
+    r64 = raw.double().requires_grad_(True)
+    (g_raw,) = torch.autograd.grad(adapter64(r64), r64, (ref["grads"]["scales"].double(), ref["grads"]["rotations"].double(),
+                                                        ref["grads"]["harmonics"].double()))
+    # ---- the product: raw rows straight into the decoder ----
+    bd = batch.to("cuda")
+    leaves = {n: getattr(bd, n).clone().requires_grad_(True) for n in ("means", "opacities", "extrinsics")}
+    raw_d = raw.cuda().requires_grad_(True)
+    dec = util.product_decoder(background=(0.1, 0.2, 0.3), band4=False)
+    g = fused(leaves["means"], leaves["opacities"], raw_d, with_covariances=False)
+    out, alpha, radii = dec.render(spf.Gaussians(g.means, None, None, None, None, g.opacities, raw=g.raw),
+                                   leaves["extrinsics"], bd.intrinsics, bd.near, bd.far, bd.image_shape)
+    wd, wa = util.loss_weights(batch)
+    util.scalar_loss(out.color, out.depth, alpha, bd.target, wd.cuda(), wa.cuda(), ref["pixel_mask"].cuda()).backward()
+    prod = dict(color=out.color.detach().cpu(), depth=out.depth.detach().cpu(), alpha=alpha.detach().cpu(), radii=radii.cpu(),
+                grads={**{n: t.grad.cpu() for n, t in leaves.items()}, "raw": raw_d.grad.cpu()})
+    ref2 = dict(ref, grads={**{n: ref["grads"][n] for n in leaves}, "raw": g_raw})
+    rep = util.compare(prod, ref2)
+    assert not rep["fails"], rep
+    assert rep["g_raw"] <= 1e-3 and rep["gel_raw"] <= 1e-2, rep
+    assert float(g_raw[..., :3].abs().max()) > 0 and float(g_raw[..., 3:7].abs().max()) > 0 and float(g_raw[..., 7:].abs().max()) > 0
