@@ -165,12 +165,6 @@ typedef struct SpfState {
                                         coefficients BEFORE the basis derivatives (three accumulators instead of twelve: the
                                         degree-4 kernel fits two waves per SIMD) and so needs the clamp decision up front
                                         instead of re-evaluating the colour */
-    float* sh_dir;         /* [R*G,9]   may be NULL.  SH colours of degree >= 3 only: when given, spf_raster_forward_project* also
-                                        writes D[c][xyz] = sum_k d basis_k / d(x,y,z) * sh_k[c] per (render, Gaussian) (rows of
-                                        clamped channels zeroed) and spf_raster_backward forms the direction gradient of the
-                                        colour from these 36 bytes instead of reading the coefficient block (12 K bytes per
-                                        Gaussian and view) again.  Pays while 72 V < 12 K, i.e. for few views per scene: the
-                                        reference's training shapes render ONE; pass the same pointer to both calls */
     uint32_t* verdict_host; /* [1]      may be NULL.  A HOST-MAPPED word (hipHostMalloc / pinned memory, device-accessible) that
                                         the projection kernel of a direct-bins call stores a non-zero value to when it raises
                                         a plan flag (counters[2]); the caller zeroes it before the call.  A host that wants the

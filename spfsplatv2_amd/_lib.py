@@ -35,7 +35,7 @@ SpfInputs = _ptr_struct("SpfInputs", ["means3D", "scales", "rotations", "opaciti
                                       "shs_high", "raw", "sh_mask"])
 SpfState = _ptr_struct("SpfState", ["rec", "radii", "rect", "zkey", "tile_count", "tile_start", "tile_fill",
                                     "tile_flags", "counters", "pairs", "pair_off", "blk_total", "blk_base", "final_T",
-                                    "n_contrib", "pair_cursor", "sh_clamp", "sh_dir", "verdict_host"])
+                                    "n_contrib", "pair_cursor", "sh_clamp", "verdict_host"])
 SpfOutputs = _ptr_struct("SpfOutputs", ["image", "depth", "alpha"])
 SpfGrads = _ptr_struct("SpfGrads", ["dL_dimage", "dL_ddepth", "dL_dalpha", "gpair", "vpartial",
                                     "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacities",

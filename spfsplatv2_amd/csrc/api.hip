@@ -182,7 +182,6 @@ Chunk make_chunk(const SpfDims& d, const SpfInputs& in, const SpfState& st, cons
     c.st.blk_total = off(st.blk_total, r * nblk); c.st.blk_base = off(st.blk_base, r * nblk);
     c.st.final_T = off(st.final_T, r * P); c.st.n_contrib = off(st.n_contrib, r * P);
     c.st.sh_clamp = off(st.sh_clamp, r * G);
-    c.st.sh_dir = off(st.sh_dir, 9 * r * G);
     if (out) {
         c.out.image = off(out->image, 3 * r * P); c.out.depth = off(out->depth, r * P);
         c.out.alpha = off(out->alpha, r * P);

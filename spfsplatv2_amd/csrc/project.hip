@@ -505,13 +505,9 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // numbers its (Gaussian, tile) pairs from a sharded global cursor, and every thread writes its keys
 // (depth bits << 32 | Gaussian) -- what spf_tile_scan_* + spf_bin_pairs_* did in two more launches and a second pass over
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
-// DIR (degree >= 3, few views per scene: SpfState.sh_dir): the forward ALSO leaves, per (render, Gaussian), the nine sums
-// D[c][xyz] = sum_k d basis_k / d(x, y, z) * sh_k[c] (rows of clamped channels zeroed) -- 36 bytes -- so that the backward
-// forms the direction gradient as D^T (dL/dcolour) without reading the coefficient block again: 12 K bytes per Gaussian and
-// view it does not fetch (192 at K = 16, 300 at K = 25; the reference's shapes render ONE view per scene and step).
-template <int DEG, int NATIVE, bool DIR = false>
+template <int DEG, int NATIVE>
 // (raw rows at degree 3 sit five registers above the 168 of three waves per SIMD: asked for, the compiler finds them)
-__global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3 && !DIR) ? 3 : SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+__global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3) ? 3 : SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
     // Nothing in the view loop waits for another wave: the histograms and the block's pair totals are flushed once per
@@ -632,25 +628,12 @@ __global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3 && !DIR) ? 3 : SPF
                 const float* __restrict__ sh = kRaw ? raw_row + 7 : in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
                 const float* __restrict__ sh_hi = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
                 col[0] = col[1] = col[2] = 0.f;
-                float Dx[3] = {0.f, 0.f, 0.f}, Dy[3] = {0.f, 0.f, 0.f}, Dz[3] = {0.f, 0.f, 0.f};
-                if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_contract<NB, NATIVE, true, DIR>(sh, sh_hi, d.K, sd, col, Dx, Dy, Dz, mk);
-                else sh_contract<NB, NATIVE, false, DIR>(sh, sh_hi, d.K, sd, col, Dx, Dy, Dz, mk);
+                if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_contract<NB, NATIVE, true, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
+                else sh_contract<NB, NATIVE, false, false>(sh, sh_hi, d.K, sd, col, nullptr, nullptr, nullptr, mk);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     col[ch] += 0.5f;
                     if (col[ch] < 0.f) { col[ch] = 0.f; clampmask |= 1 << ch; }
-                }
-                if (DIR && live) {
-                    float* __restrict__ o = st.sh_dir + ((size_t)r * d.G + g) * 9;
-                    float dd9[9];
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const bool cl = (clampmask >> ch) & 1;        // (a clamped channel passes no gradient: Appendix B #9)
-                        dd9[3 * ch] = cl ? 0.f : Dx[ch]; dd9[3 * ch + 1] = cl ? 0.f : Dy[ch]; dd9[3 * ch + 2] = cl ? 0.f : Dz[ch];
-                    }
-                    st4<false>(o, dd9[0], dd9[1], dd9[2], dd9[3]);
-                    st4<false>(o + 4, dd9[4], dd9[5], dd9[6], dd9[7]);
-                    o[8] = dd9[8];
                 }
             }
             // Conservative per-sub-tile cull radius: a pixel at squared distance d2 from the centre has
@@ -905,7 +888,7 @@ __host__ __device__ inline bool sh_stage_out(int V, int K, bool raw = false) {
 
 // (degree >= 2: 9..25 coefficients per channel.  Left alone the scheduler hoists every coefficient load to the top of
 // the SH section -- 300+ VGPRs, one wave per SIMD; asking for two blocks per CU caps it at 256 VGPRs)
-template <int DEG, int NATIVE, bool DIR = false>
+template <int DEG, int NATIVE>
 __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? SPF_PBWD_DEG4_BPC : SPF_PBWD_BPC))) void spf_project_bwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   SpfGrads gr, int nblk, uint64_t capacity) {
     (void)capacity;
@@ -1118,15 +1101,7 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                     if (cm & 1u) gcol[0] = 0.f;
                     if (cm & 2u) gcol[1] = 0.f;
                     if (cm & 4u) gcol[2] = 0.f;
-                    if (DIR) {
-                        // the forward left D[c][xyz] (SpfState.sh_dir): the direction gradient without the coefficients
-                        const float* __restrict__ dp9 = st.sh_dir + rg * 9;
-                        const f4a a0 = ld4<false>(dp9), a1 = ld4<false>(dp9 + 4);
-                        const float a8 = dp9[8];
-                        dd[0] = a0.x * gcol[0] + a0.w * gcol[1] + a1.z * gcol[2];
-                        dd[1] = a0.y * gcol[0] + a1.x * gcol[1] + a1.w * gcol[2];
-                        dd[2] = a0.z * gcol[0] + a1.y * gcol[1] + a8 * gcol[2];
-                    } else if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd, mk);
+                    if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd, mk);
                     else sh_direction_gradient<NB, NATIVE, false>(sh, sh_hi, d.K, sd, gcol, dd, mk);
                 }
                 sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
@@ -1414,12 +1389,6 @@ static inline int sh_eval_degree(const SpfDims& d) {
 template <int DEG, int NATIVE>
 static void project_fwd_t(dim3 grid, size_t sm, hipStream_t stream, const SpfDims& d, const SpfInputs& in,
                           const SpfState& st, int tiles_x, int tiles_y, int lds) {
-    if constexpr (DEG >= 3) {
-        if (st.sh_dir) {      // (the caller asked for the direction-gradient sums: see the kernel)
-            spf_project_fwd_kernel<DEG, NATIVE, true><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds);
-            return;
-        }
-    }
     spf_project_fwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), sm, stream>>>(d, in, st, tiles_x, tiles_y, lds);
 }
 template <int DEG, int NATIVE>
@@ -1439,15 +1408,6 @@ static void project_bwd_t(dim3 grid, hipStream_t stream, const SpfDims& d, const
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
             }
-        }
-    }
-    if constexpr (DEG >= 3) {
-        if (st.sh_dir) {
-            if (lds > 64 * 1024)
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spf_project_bwd_kernel<DEG, NATIVE, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            spf_project_bwd_kernel<DEG, NATIVE, true><<<grid, dim3(kBlock), lds, stream>>>(d, in, st, g, nblk, capacity);
-            return;
         }
     }
     spf_project_bwd_kernel<DEG, NATIVE><<<grid, dim3(kBlock), lds, stream>>>(d, in, st, g, nblk, capacity);

@@ -71,7 +71,7 @@ SpfState make_state(const Tensor& rec, const Tensor& radii, const Tensor& rect, 
     st.pair_off = pi; st.blk_total = pi + 2 * RG; st.blk_base = pi + 2 * RG + RB;      // pair_off: (rect, first pair) per (render, Gaussian)
     st.final_T = ptr<float>(final_T); st.n_contrib = ptr<uint32_t>(n_contrib);
     st.sh_clamp = rect.numel() > 2 * RG ? reinterpret_cast<uint8_t*>(ptr<uint32_t>(rect) + 2 * RG) : nullptr;   // SH clamp masks ride behind rect | zkey
-    st.verdict_host = nullptr; st.sh_dir = nullptr;
+    st.verdict_host = nullptr;
     return st;
 }
 

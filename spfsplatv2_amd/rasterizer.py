@@ -295,10 +295,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
     dims = _lib.SpfDims(S, V, G, K, sh_degree, H, W, float(scale_modifier), int(sh_layout), int(bool(sh_band4)),
                         bin_cap, rec_cap, 0 if raw is None else raw.stride(0), float(adapter_eps))
     nblk = lib.spf_raster_view_partial_blocks(G)
-    keep_dir = _want_sh_dir(shs is not None or raw is not None, sh_degree, bool(sh_band4), K, int(sh_layout), V,
-                            not nothing_needs_grad)
-    rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha, _ = _alloc_forward(dev, S, V, G, H, W, T, nblk,
-                                                                                                    sh_dir=keep_dir)
+    rec, radii, rect, pair_idx, tiles, final_T, n_contrib, image, depth, alpha, _ = _alloc_forward(dev, S, V, G, H, W, T, nblk)
     counters = tiles[4 * R * T + 1:4 * R * T + 5]
 
     inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs),
@@ -373,19 +370,7 @@ def _forward_impl(means3D, scales, rotations, opacities, shs, colors, viewmatrix
             (rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib), (dense, bin_cap, max(int(capacity), 1)))
 
 
-def _want_sh_dir(shs_or_raw: bool, sh_degree: int, sh_band4: bool, K: int, sh_layout: int, V: int, backward_will_come: bool) -> bool:
-    """Whether the forward should leave the direction-gradient sums (SpfState.sh_dir, 36 bytes per (render, Gaussian)) for
-    the backward: SH colours evaluated to degree >= 3, a backward that will come, and few enough views per scene that
-    writing + reading 72 V bytes beats re-reading the 12 K bytes of a coefficient block (the reference's training shapes
-    render one view per scene).  SPF_SH_DIR=0 switches it off (A/B runs, tests)."""
-    if not shs_or_raw or not backward_will_come or os.environ.get("SPF_SH_DIR", "1") == "0":
-        return False
-    deg = min(sh_degree, 4 if sh_band4 else 3)
-    k_read = 16 if (sh_layout == 2 and deg < 4) else K
-    return deg >= 3 and 6 * V < k_read
-
-
-def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: int, sh_dir: bool = False):
+def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: int):
     """Everything a forward call writes besides the pair lists: (rec, radii, rect, pair_idx, tiles, final_T, n_contrib,
     image, depth, alpha, the flat colour | depth allocation)."""
     R, P = S * V, H * W
@@ -393,8 +378,7 @@ def _alloc_forward(dev, S: int, V: int, G: int, H: int, W: int, T: int, nblk: in
     f32 = dict(dtype=torch.float32, device=dev)
     rec = torch.empty((R * G, _REC), **f32)
     radii = torch.empty((R * G,), **i32)
-    # packed tile rect | depth key (float bits) | SH clamp masks (bytes) [| direction-gradient sums, 9 floats each: sh_dir]
-    rect = torch.empty((2 * R * G + (R * G + 3) // 4 + (9 * R * G if sh_dir else 0),), **i32)
+    rect = torch.empty((2 * R * G + (R * G + 3) // 4,), **i32)   # packed tile rect | depth key (float bits) | SH clamp masks (bytes)
     pair_idx = torch.empty((2 * R * G + 2 * R * nblk,), **i32)   # pair_off (rect, first pair) | blk_total | blk_base
     # tile_count | tile_flags | tile_start (+1) | tile_fill | counters (4) | pair cursors (8) | padding to 16 bytes
     tiles = torch.empty((4 * R * T + 16,), **i32)
@@ -464,15 +448,13 @@ class _spf_errors:
 
 def _state_struct(rec, radii, rect, tiles, pairs, pair_idx, final_T, n_contrib, RT, RG, RB, verdict_host=None):
     cursor = tiles[4 * RT + 5:4 * RT + 13] if tiles.numel() >= 4 * RT + 13 else None   # (the compiled binding's buffer has none)
-    nclamp = (RG + 3) // 4
-    sh_dir = rect[2 * RG + nclamp:] if rect.numel() >= 2 * RG + nclamp + 9 * RG else None    # (rides behind the clamp masks)
     return _lib.SpfState(_ptr(rec), _ptr(radii), _ptr(rect[:RG]), _ptr(rect[RG:]), _ptr(tiles[:RT]),
                          _ptr(tiles[2 * RT:3 * RT + 1]),
                          _ptr(tiles[3 * RT + 1:4 * RT + 1]), _ptr(tiles[RT:2 * RT]),
                          _ptr(tiles[4 * RT + 1:4 * RT + 5]), _ptr(pairs),
                          _ptr(pair_idx[:2 * RG]), _ptr(pair_idx[2 * RG:2 * RG + RB]), _ptr(pair_idx[2 * RG + RB:]),
                          _ptr(final_T), _ptr(n_contrib), _ptr(cursor),
-                         _ptr(rect[2 * RG:]) if rect.numel() > 2 * RG else None, _ptr(sh_dir), _ptr(verdict_host))
+                         _ptr(rect[2 * RG:]) if rect.numel() > 2 * RG else None, _ptr(verdict_host))
 
 
 def _raise_if_plan_failed(counters: Tensor, capacity: int, plan=None) -> None:
@@ -730,9 +712,8 @@ class StaticStep:
         self.vscale = torch.empty((S, V), **f32) if scale_invariant else None
         self.view64 = torch.empty((S, V, 4, 4), dtype=torch.float64, device=dev)
         nblk = lib.spf_raster_view_partial_blocks(G)
-        keep_dir = _want_sh_dir(True, sh_degree, bool(sh_band4), K, layout, V, True)
         (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib, _i, _d, _a,
-         _f) = _alloc_forward(dev, S, V, G, 1, 1, T, nblk, sh_dir=keep_dir)   # (state only: the H x W outputs are the calls' own)
+         _f) = _alloc_forward(dev, S, V, G, 1, 1, T, nblk)       # (state only: the H x W outputs are the calls' own)
         self.final_T = torch.empty((R * H * W,), **f32)
         self.n_contrib = torch.empty((R * H * W,), dtype=torch.int32, device=dev)
         if self.tiles.data_ptr() % 16:

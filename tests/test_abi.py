@@ -26,7 +26,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.SpfDims) == 72          # ten 4-byte fields + bin_cap + the 8-byte aligned pair_capacity (ABI 4) + raw_stride, adapter_eps (ABI 6)
     assert _lib.SpfDims.pair_capacity.offset == 48 and _lib.SpfDims.bin_cap.offset == 40
     assert C.sizeof(_lib.SpfInputs) == 15 * 8          # + shs_high, raw, sh_mask (ABI 6)
-    assert C.sizeof(_lib.SpfState) == 19 * 8            # + sh_dir, verdict_host (ABI 6)
+    assert C.sizeof(_lib.SpfState) == 18 * 8            # + verdict_host (ABI 6)
     assert C.sizeof(_lib.SpfOutputs) == 3 * 8
     assert C.sizeof(_lib.SpfGrads) == 15 * 8           # + dL_dshs_high, dL_draw (ABI 6)
 
