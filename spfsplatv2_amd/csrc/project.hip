@@ -371,15 +371,10 @@ __device__ __forceinline__ void sh_contract(const float* __restrict__ sh, const 
 // itself, because it learns which channels the forward clamped only at the end of the pass; here `g` already has those
 // channels zeroed, from SpfState.sh_clamp).  Round 5: 255 -> 227 VGPRs at degree 3, 348 -> 256 at degree 4 (two waves
 // per SIMD instead of one).
-// PRE (0 or 2): coefficient groups 0 .. PRE-1 were requested by the caller long ago (`pre`: the backward kernel asks for
-// them next to its first loads -- it runs two waves per SIMD at 227 registers of 256: room for 24 more, where the forward
-// has none) and only the rest is fetched here.
-template <int NB, int NATIVE, bool ALIGNED, int PRE = 0>
+template <int NB, int NATIVE, bool ALIGNED>
 __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ sh, const float* __restrict__ hi, int K,
-                                                      const ShDir& dir, const float g[3], float dd[3], kfloat_p mk = nullptr,
-                                                      const float (*pre)[4][3] = nullptr) {
+                                                      const ShDir& dir, const float g[3], float dd[3], kfloat_p mk = nullptr) {
     constexpr int NV = NB / 4;
-    static_assert(PRE == 0 || (PRE == 2 && NV >= 2), "two prefetched groups");
     auto acc = [&](int k, const float v[3]) {
         float gx, gy, gz;
         (void)sh_term<true>(k, dir, gx, gy, gz);
@@ -390,16 +385,9 @@ __device__ __forceinline__ void sh_direction_gradient(const float* __restrict__ 
     };
     // groups of four coefficients, double-buffered by hand behind a compiler barrier (see sh_contract)
     float v[2][4][3];
-    if (PRE == 0 && NV > 0) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0], mk);
-    if (PRE == 2 && NV > 2) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 2, v[0], mk);
-    if (PRE == 2) {
+    if (NV > 0) sh_load4<NATIVE, ALIGNED>(sh, hi, K, 0, v[0], mk);
 #pragma unroll
-        for (int k4 = 0; k4 < 2; ++k4)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc(4 * k4 + i, pre[k4][i]);
-    }
-#pragma unroll
-    for (int k4 = PRE; k4 < NV; ++k4) {
+    for (int k4 = 0; k4 < NV; ++k4) {
         if (k4 + 1 < NV) sh_load4<NATIVE, ALIGNED>(sh, hi, K, k4 + 1, v[(k4 + 1) & 1], mk);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc(4 * k4 + i, v[k4 & 1][i]);
@@ -945,22 +933,6 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
     const kfloat_p mk = kRaw ? as_const(in.sh_mask) : nullptr;
     const int CR = 7 + 3 * d.K;                                       // floats of a raw row / of a dL_draw row
     float raw_dact[kRaw ? 3 : 1] = {};                                // (raw rows) d scale / d raw[0:3] without the 0.001
-    // coefficient groups 0 and 1 of the SH block, requested FIRST (degree >= 3; see sh_direction_gradient): they arrive
-    // under the chain rect / pair_off -> gradient record that the view loop has to wait for anyway
-#ifndef SPF_PBWD_PREFETCH
-#define SPF_PBWD_PREFETCH 1
-#endif
-    constexpr int kPre = (SPF_PBWD_PREFETCH && DEG >= 3) ? 2 : 0;
-    float shp[kPre ? 2 : 1][4][3];
-    if (kPre && live) {
-        const float* __restrict__ sh0 = kRaw ? raw_row + 7 : in.shs + sg * (size_t)(NATIVE == 2 ? 16 : d.K) * 3;
-        const float* __restrict__ hi0 = NATIVE == 2 ? in.shs_high + sg * 27 : nullptr;
-        if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) {
-            sh_load4<NATIVE, true>(sh0, hi0, d.K, 0, shp[0], mk); sh_load4<NATIVE, true>(sh0, hi0, d.K, 1, shp[kPre ? 1 : 0], mk);
-        } else {
-            sh_load4<NATIVE, false>(sh0, hi0, d.K, 0, shp[0], mk); sh_load4<NATIVE, false>(sh0, hi0, d.K, 1, shp[kPre ? 1 : 0], mk);
-        }
-    }
     if (live) {
         p0[0] = in.means3D[3 * sg]; p0[1] = in.means3D[3 * sg + 1]; p0[2] = in.means3D[3 * sg + 2];
         if (kRaw) {      // (the adapter's activations, as in the forward kernel)
@@ -1129,8 +1101,8 @@ __global__ __launch_bounds__(kBlock, ((DEG == 2 || DEG == 3) ? 2 : (DEG == 4 ? S
                     if (cm & 1u) gcol[0] = 0.f;
                     if (cm & 2u) gcol[1] = 0.f;
                     if (cm & 4u) gcol[2] = 0.f;
-                    if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_direction_gradient<NB, NATIVE, true, kPre>(sh, sh_hi, d.K, sd, gcol, dd, mk, shp);
-                    else sh_direction_gradient<NB, NATIVE, false, kPre>(sh, sh_hi, d.K, sd, gcol, dd, mk, shp);
+                    if (NATIVE == 2 || (!kRaw && d.K % 4 == 0)) sh_direction_gradient<NB, NATIVE, true>(sh, sh_hi, d.K, sd, gcol, dd, mk);
+                    else sh_direction_gradient<NB, NATIVE, false>(sh, sh_hi, d.K, sd, gcol, dd, mk);
                 }
                 sh_x = x; sh_y = y; sh_z = z; sh_g0 = gcol[0]; sh_g1 = gcol[1]; sh_g2 = gcol[2];
                 if (!kPark) {
