@@ -747,127 +747,6 @@ __global__ __launch_bounds__(2 * kWave) void spf_sort_tiles_pair_kernel(TileList
     else sort_tile_in_pair<8>(pairs + b, n, s_x);
 }
 
-// ---- per-tile LSD radix sort (the A/B BASELINE.json's "radix" wording and VERDICT r5 task 7 ask for) -------------------
-// One 256-thread block per tile, E keys per thread in registers (blocked: thread t holds list positions E t .. E t + E - 1).
-// The 64-bit keys are unique (depth bits << 32 | Gaussian id) and arrive in arbitrary order (the bins are filled with
-// atomics), so the order is decided by the depth bits with the id as tie-break.  Passes of 4 bits over the depth bits that
-// actually VARY inside the tile (block-wide min / max first: ~26 of the 32 for a tile that spans the scene's depth
-// range -> 7 passes), each pass: per-thread 16-bit counters per digit in LDS (own column: no atomics), a block-wide scan
-// over (digit, thread), rank = prefix + rank among the thread's own earlier keys, scatter through LDS, read back blocked.
-// Stable, so equal depths keep their arrival order: a last look at neighbours with EQUAL depth bits puts those (rare)
-// runs in id order by odd-even transposition.  Same lists as the register networks, bit for bit.
-template <int E>
-__device__ __forceinline__ void radix_sort_tile(uint64_t* __restrict__ p, uint32_t n, uint64_t* __restrict__ s_keys,
-                                                uint16_t (*s_cnt)[kBlock], uint32_t* __restrict__ s_red) {
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    uint64_t r[E];
-    uint32_t lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-        const uint32_t e = (uint32_t)(E * t + k);
-        r[k] = e < n ? p[e] : ~0ull;                       // (padding: all ones -- digit 15 in every pass, behind every key)
-        if (e < n) { const uint32_t dz = (uint32_t)(r[k] >> 32); lo = min(lo, dz); hi = max(hi, dz); }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, kWave));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, kWave));
-    }
-    if (lane == 0) { s_red[wave] = lo; s_red[4 + wave] = hi; }
-    __syncthreads();
-    lo = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-    hi = max(max(s_red[4], s_red[5]), max(s_red[6], s_red[7]));
-    const uint32_t diff = lo ^ hi;
-    const int top = diff ? 32 - __clz((int)diff) : 0;      // depth bits [0, top) vary inside this tile
-    __syncthreads();                                       // (s_red is reused by the scans)
-    for (int shift = 0; shift < top; shift += 4) {
-        // ---- count: thread t's own column of sixteen 16-bit counters ----
-#pragma unroll
-        for (int dgt = 0; dgt < 16; ++dgt) s_cnt[dgt][t] = 0;
-        uint32_t lr[E];
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int dgt = (int)((r[k] >> (32 + shift)) & 15u);
-            const uint16_t c = s_cnt[dgt][t];
-            lr[k] = c;
-            s_cnt[dgt][t] = (uint16_t)(c + 1);
-        }
-        __syncthreads();
-        // ---- scan over (digit, thread): thread T takes digit T >> 4, threads 16 (T & 15) .. + 15 ----
-        {
-            uint16_t* __restrict__ seg = &s_cnt[t >> 4][(t & 15) * 16];
-            uint32_t c[16], run = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { c[j] = seg[j]; }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { const uint32_t x = c[j]; c[j] = run; run += x; }
-            const uint32_t inc = wave_iscan_u32(run);
-            if (lane == kWave - 1) s_red[wave] = inc;
-            __syncthreads();
-            uint32_t base = inc - run;
-            for (int w = 0; w < wave; ++w) base += s_red[w];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) seg[j] = (uint16_t)(base + c[j]);
-        }
-        __syncthreads();
-        // ---- rank, scatter through LDS, read back blocked ----
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int dgt = (int)((r[k] >> (32 + shift)) & 15u);
-            s_keys[(uint32_t)s_cnt[dgt][t] + lr[k]] = r[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < E; ++k) r[k] = s_keys[E * t + k];
-        __syncthreads();
-    }
-    // ---- equal depth bits: id order (stable passes left the arrival order) ----
-#pragma unroll
-    for (int k = 0; k < E; ++k) s_keys[E * t + k] = r[k];
-    __syncthreads();
-    bool tie = false;
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-        const uint32_t e = (uint32_t)(E * t + k);
-        if (e > 0 && e < n) tie = tie || ((uint32_t)(s_keys[e - 1] >> 32) == (uint32_t)(r[k] >> 32));
-    }
-    if (__syncthreads_or(tie)) {
-        for (;;) {
-            bool swapped = false;
-            for (int phase = 0; phase < 2; ++phase) {
-                for (uint32_t i = (uint32_t)(2 * t + phase); i + 1 < n; i += 2 * kBlock) {
-                    const uint64_t a = s_keys[i], b = s_keys[i + 1];
-                    if ((uint32_t)(a >> 32) == (uint32_t)(b >> 32) && a > b) { s_keys[i] = b; s_keys[i + 1] = a; swapped = true; }
-                }
-                __syncthreads();
-            }
-            if (!__syncthreads_or(swapped)) break;
-        }
-#pragma unroll
-        for (int k = 0; k < E; ++k) r[k] = s_keys[E * t + k];
-    }
-#pragma unroll
-    for (int k = 0; k < E; ++k) {
-        const uint32_t e = (uint32_t)(E * t + k);
-        if (e < n) p[e] = r[k];
-    }
-}
-
-// lists of 513 .. 4,096 entries, one block per tile (SPF_SORT_RADIX=1: instead of the block-per-tile register networks)
-__global__ __launch_bounds__(kBlock) void spf_sort_tiles_radix_kernel(TileLists tl, const uint32_t* __restrict__ counters,
-                                                                      uint64_t* __restrict__ pairs, uint64_t capacity) {
-    __shared__ uint64_t s_keys[16 * kBlock];
-    __shared__ uint16_t s_cnt[16][kBlock];
-    __shared__ uint32_t s_red[8];
-    if (counters[0] > capacity) return;
-    uint32_t b, n;
-    tile_range(tl, blockIdx.x, b, n);
-    if (n <= 512u || n > 4096u) return;
-    if (n <= 1024u) radix_sort_tile<4>(pairs + b, n, s_keys, s_cnt, s_red);
-    else if (n <= 2048u) radix_sort_tile<8>(pairs + b, n, s_keys, s_cnt, s_red);
-    else radix_sort_tile<16>(pairs + b, n, s_keys, s_cnt, s_red);
-}
-
 // The three size classes of the "few tiles, long lists" family in ONE launch (lists of 2 .. 2048 entries): blocks
 // 0 .. RT-1 take one tile each when its list has 513 .. 2048 entries (four waves on one list: 4 or 8 keys per thread),
 // blocks RT .. RT + ceil(RT/4) - 1 take four tiles each, one per wave, when their lists have 2 .. 512 entries.  The
@@ -1072,11 +951,7 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     // 65 us with blocks)
     const char* force = getenv("SPF_SORT_BLOCKS");       // (tests: "0" / "1" pin one of the two families)
     const bool blocks = force ? force[0] == '1' : RT_call < 6144;
-    // SPF_SORT_RADIX=1 (A/B, round 6): lists of 513 .. 4,096 entries of the few-tiles family by the per-tile LDS radix sort,
-    // the shorter ones by the wave kernel as a launch of its own
-    const char* const rx = getenv("SPF_SORT_RADIX");
-    const bool radix = blocks && mx > 512 && rx && rx[0] == '1';
-    const bool mixed = blocks && mx > 512 && !radix && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
+    const bool mixed = blocks && mx > 512 && !getenv("SPF_SORT_SEPARATE");    // 2 .. 2048 in one launch (see the kernel)
     if (order && !(mx > 1))      // nothing to sort: the order on its own
         spf_tile_order_kernel<<<ob, kBlock, 0, stream>>>(tl.count, st.tile_flags, order, RT, T, tl.cap, thr, thr_f);
     // (SPF_SORT_BIG_MIXED=0: the 2,049 .. 4,096 class as a launch of its own, as before)
@@ -1103,17 +978,15 @@ hipError_t launch_tile_sort(const SpfState& st, const TileLists& tl, int RT, int
     if (mx > 1024 && !blocks)    // 1025 .. 2048 with one wave per tile (32 keys per lane)
         spf_sort_tiles_wave_kernel<32, false><<<wgrid, kBlock, 0, stream>>>(tl, st.tile_flags, st.counters, st.pairs,
                                                                             capacity, 1024, RT, thr, nullptr, 0, thr_f);
-    if (radix)
-        spf_sort_tiles_radix_kernel<<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity);
-    if (mx > 512 && blocks && !mixed && !radix)      // 513 .. 1024: one block per tile, 4 keys per thread
+    if (mx > 512 && blocks && !mixed)      // 513 .. 1024: one block per tile, 4 keys per thread
         spf_sort_tiles_block_kernel<4><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 512);
-    if (mx > 1024 && blocks && !mixed && !radix)     // 1025 .. 2048: 8 keys per thread
+    if (mx > 1024 && blocks && !mixed)     // 1025 .. 2048: 8 keys per thread
         spf_sort_tiles_block_kernel<8><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 1024);
     // 2049 .. 4096: one 256-thread block per tile, SIXTEEN keys per thread in registers (each wave sorts its 1,024 keys
     // with lane exchanges, the last two merges start with three exchanges through LDS) -- round 5: the reference's
     // 10-view shape is 768 tiles of ~2,800 entries, ALL in this class, and the all-LDS network below took 74 us for them
     // (78 barrier-separated passes of 1,024 threads); 4097 .. 8192 stay with it
-    if (mx > 2048 && !getenv("SPF_SORT_LDS_2K") && !big_mixed && !radix)
+    if (mx > 2048 && !getenv("SPF_SORT_LDS_2K") && !big_mixed)
         spf_sort_tiles_block_kernel<16><<<RT, kBlock, 0, stream>>>(tl, st.counters, st.pairs, capacity, 2048);
     if (mx > 2048 && getenv("SPF_SORT_LDS_2K"))
         spf_sort_tiles_lds_kernel<1024><<<RT, 1024, 8192 * 8, stream>>>(tl, st.counters, st.pairs, capacity, 2048, 8192);

@@ -374,30 +374,6 @@ def test_both_sort_families_give_the_same_lists(hip_lib, monkeypatch):
             assert torch.equal(a["grads"][n], b["grads"][n]), n
 
 
-def test_radix_sort_gives_the_same_lists_as_the_register_networks(hip_lib, monkeypatch):
-    """`SPF_SORT_RADIX=1` (round 6's A/B): lists of 513 .. 4,096 entries of the few-tiles family through the per-tile LDS
-    radix sort (4-bit passes over the depth bits that vary, then id order inside runs of equal depth) instead of the
-    block-per-tile register networks: unique keys, so images and gradients are bit-equal -- also when many Gaussians share
-    their depth bits exactly (duplicated centres: the tie-break pass)."""
-    outs = []
-    for fam in ("0", "1"):
-        monkeypatch.setenv("SPF_SORT_RADIX", fam)
-        per = []
-        for G, dup in ((3200, 0), (6500, 0), (12000, 0), (6500, 1500)):
-            batch = syn.make_batch("TESTBIG", 1, 1, seed=23, s_mult=1.0, G=G)
-            batch.opacities = batch.opacities * 0.03
-            if dup:
-                batch.means[:, dup:2 * dup] = batch.means[:, :dup]           # the same depth bits twice, different ids
-            p = util.run_product(batch)
-            assert p["stats"]["max_tile_list"] > 512
-            per.append(p)
-        outs.append(per)
-    for a, b in zip(*outs):
-        assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"])
-        for n in util.GRAD_NAMES:
-            assert torch.equal(a["grads"][n], b["grads"][n]), n
-
-
 def test_long_list_class_inside_the_mixed_sort_launch_gives_the_same_lists(hip_lib, monkeypatch):
     """Calls of few tiles sort lists of 2,049..4,096 entries (sixteen keys per thread) in the same launch as the shorter
     classes (`spf_sort_tiles_mixed_kernel<true>`); `SPF_SORT_BIG_MIXED=0` gives that class a launch of its own, as before.
