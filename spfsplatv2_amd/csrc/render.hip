@@ -341,10 +341,7 @@ __device__ __forceinline__ TileBox clipped_box(float gx, float gy, float r2, int
 // Measured (round 5, same box, forward stage): the reference's 10-view shape (768 tiles of ~2,800 entries) 98.9 -> 89.0 us;
 // but BASELINE config 3 (2,048 tiles) 59.8 -> 71.6, REF2V (4,096) 66.8 -> 78.9, C2 (8,192) 66.4 -> 87.6: four blocks per
 // CU instead of eight costs more than the rounds save as soon as the chip is full -- 512 only up to 768 tiles.
-// STRIPS (1, 2, 4; round 6's A/B of VERDICT r5 task 4): that many blocks per tile on the SAME list -- each stages every
-// entry of the tile but scatters and composites only its 16 x (16 / STRIPS) strip of pixels (the waves whose pixels lie
-// outside the strip are done from the start).  Pixels are independent: outputs are bit-identical.
-template <int STAGE, int STRIPS = 1>
+template <int STAGE>
 __global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_lists_kernel(   // (8 blocks per CU: <= 64 VGPRs)
     const float* __restrict__ rec, const uint64_t* __restrict__ pairs, TileLists tl,
     const uint32_t* __restrict__ tile_flags, const uint32_t* __restrict__ counters, uint64_t capacity,
@@ -363,14 +360,10 @@ __global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_l
     int vid;
     uint32_t beg, n;
     bool dense_tile;
-    int strip = 0;
-    if (!lists_tile(tl, tile_flags, dense_thr, true, RT, vid, beg, n, dense_tile, STRIPS, &strip)) return;
+    if (!lists_tile(tl, tile_flags, dense_thr, true, RT, vid, beg, n, dense_tile)) return;
     const int r = vid / T, tile = vid - r * T;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int tid = threadIdx.x;
-    if (STRIPS > 1 && dense_tile && strip != 0) return;          // (the rows form takes the whole tile: first strip's block)
-    constexpr int kStripH = kTile / STRIPS;
-    const int ys0 = STRIPS > 1 ? strip * kStripH : 0;
     if (tid == 0) s_p2z[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int X0 = tx * kTile, Y0 = ty * kTile;
     // (thread -> pixel stays row-major.  Measured: 16 consecutive lanes = one 4x4 pixel block, so that the LDS gathers of
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_l
     const int lx = tid & 15, ly = tid >> 4;
     const int pid = ly * kTile + lx;            // this thread's pixel inside the tile (row-major): its candidate column
     const int px = X0 + lx, py = Y0 + ly;
-    const bool inside = px < W && py < H && (STRIPS == 1 || (ly >= ys0 && ly < ys0 + kStripH));
+    const bool inside = px < W && py < H;
     const float* __restrict__ rec_r = rec + (size_t)r * G * kRec;
     if (dense_tile) {                                                                // (block-uniform)
         fwd_rows_tile(s_p0, s_p1, s_p2, reinterpret_cast<uint32_t (*)[16]>(&s_pm[0][0]), rec_r, pairs, beg, n, r, tx, ty,
@@ -425,11 +418,7 @@ __global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_l
                 s_p1[e] = make_float2(kLog2e * ea[q].w, eb[q].y);
                 s_p2[e] = make_float4(ec[q].x, ec[q].y, ec[q].z, eb[q].z);
             }
-            TileBox tb = clipped_box(ea[q].x, ea[q].y, eb[q].w, X0, Y0);            // (no entry: r2 = -1 -> empty box)
-            if (STRIPS > 1) {                                                        // the box's rows inside this strip
-                const int y_lo = max(tb.yl, ys0), y_hi = min(tb.yl + tb.bh, ys0 + kStripH);
-                tb.yl = y_lo; tb.bh = max(0, y_hi - y_lo);
-            }
+            const TileBox tb = clipped_box(ea[q].x, ea[q].y, eb[q].w, X0, Y0);      // (no entry: r2 = -1 -> empty box)
             scatter_box(s_pm, e, ea[q].x, ea[q].y, eb[q].w, X0, Y0, tb.xl, tb.yl, tb.bw, tb.bh);
         }
         __syncthreads();
@@ -1043,20 +1032,6 @@ hipError_t launch_render_fwd(const SpfDims& d, const SpfInputs& in, const SpfSta
     const int grid = (RT + 7) / 8 * 8;
     const char* const fe = getenv("SPF_FWD_STAGE");           // ("256" / "512" pins the instantiation: experiments, tests)
     const int stage = fe ? atoi(fe) : (RT <= kFwdLongRoundsMaxTiles ? 512 : 256);
-    // SPF_FWD_STRIPS=2 / 4 (round 6's A/B; calls without a launch order only): that many blocks per tile
-    const char* const se = getenv("SPF_FWD_STRIPS");
-    const int strips = (se && !tlo.order) ? atoi(se) : 1;
-    if (strips == 2 || strips == 4) {
-        const int sgrid = (RT * strips + 7) / 8 * 8;
-#define SPF_FWD_STRIPS_LAUNCH(ST, NS)                                                                                     \
-        spf_render_fwd_lists_kernel<ST, NS><<<sgrid, kBlock, 0, stream>>>(                                               \
-            st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth, out.alpha,       \
-            st.final_T, st.n_contrib, d.G, d.H, d.W, T, tiles_x, RT, dense_threshold_fwd())
-        if (stage == 512) { if (strips == 2) SPF_FWD_STRIPS_LAUNCH(512, 2); else SPF_FWD_STRIPS_LAUNCH(512, 4); }
-        else { if (strips == 2) SPF_FWD_STRIPS_LAUNCH(256, 2); else SPF_FWD_STRIPS_LAUNCH(256, 4); }
-#undef SPF_FWD_STRIPS_LAUNCH
-        return hipGetLastError();
-    }
     if (stage == 512)
         spf_render_fwd_lists_kernel<512><<<grid, kBlock, 0, stream>>>(
             st.rec, st.pairs, tlo, st.tile_flags, st.counters, capacity, in.bg, out.image, out.depth,

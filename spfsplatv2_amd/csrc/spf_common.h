@@ -304,13 +304,10 @@ __device__ __forceinline__ int xcd_remap(int block, int grid) {
 constexpr uint32_t kOrderTileMask = 0x3fffffffu, kOrderDenseBwd = 0x80000000u, kOrderDenseFwd = 0x40000000u;
 // The tile this block of a composite lists launch works on (false: none), where its list is and whether the tile
 // belongs to the dense (rows) kernel of this direction (`dense_thr`, `forward`): in image order, or from the launch order.
-// `strips` (forward only, round 6 A/B): that many blocks share a tile -- block slot s works on tile slot s / strips and on
-// the horizontal strip s % strips of its pixels; consecutive slots of an XCD's range are the strips of one tile (same L2).
 __device__ __forceinline__ bool lists_tile(const TileLists& tl, const uint32_t* __restrict__ tile_flags,
                                            uint32_t dense_thr, bool forward, int RT, int& vid, uint32_t& beg, uint32_t& n,
-                                           bool& dense, int strips = 1, int* strip = nullptr) {
-    int slot = xcd_remap(blockIdx.x, gridDim.x);
-    if (strips > 1) { *strip = slot % strips; slot /= strips; }
+                                           bool& dense) {
+    const int slot = xcd_remap(blockIdx.x, gridDim.x);
     if (tl.order) {
         const uint2 o = tl.order[slot];
         vid = (int)(o.x & kOrderTileMask);
