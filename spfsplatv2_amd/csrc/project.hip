@@ -507,7 +507,10 @@ __host__ __device__ inline int hist_view_group(int V, int T, bool direct = false
 // rect / depth.  tile_count ends up as the bins' fill; nothing needs a scan.
 template <int DEG, int NATIVE>
 // (raw rows at degree 3 sit five registers above the 168 of three waves per SIMD: asked for, the compiler finds them)
-__global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3) ? 3 : SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
+#ifndef SPF_PFWD_RAW_BPC
+#define SPF_PFWD_RAW_BPC 3
+#endif
+__global__ __launch_bounds__(kBlock, (NATIVE == 3 && DEG == 3) ? SPF_PFWD_RAW_BPC : SPF_PFWD_BPC) void spf_project_fwd_kernel(SpfDims d, SpfInputs in, SpfState st,
                                                                   int tiles_x, int tiles_y, int lds_hist) {
     // LDS: [VG][T] packed tile histograms of a group of views | [VG][4] per-wave pair totals | [4][64*12] record staging.
     // Nothing in the view loop waits for another wave: the histograms and the block's pair totals are flushed once per
