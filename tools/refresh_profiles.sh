@@ -37,17 +37,25 @@ if [ -z "${CONFIGS:-}" ]; then
   SPF_DIRECT_BINS=0 python bench.py --no-cpu-baseline --no-secondary > "$OUT/bench_C2_classic_bins.json" 2>> "$ERR"
   python bench.py --eval-latency > "$OUT/bench_eval_1x3.json" 2>> "$ERR"
   python bench.py --api per-view --no-cpu-baseline --steps 5 --warmup 2 --min-trials 5 --min-seconds 0 > "$OUT/bench_perview.json" 2>> "$ERR"
-  for v in "--sh-split" "--with-adapter" "--with-adapter --sh-split"; do
+  for v in "--sh-split" "--with-adapter" "--with-adapter --sh-split" "--raw-fused"; do
     n=$(echo "$v" | tr -d " -")
     SPF_SH_BAND4=0 python bench.py --config REF2V $v --no-cpu-baseline > "$OUT/bench_REF2V_$n.json" 2>> "$ERR"
   done
-  for v in "--sh-split" "--with-adapter --sh-split"; do
+  for v in "--sh-split" "--with-adapter --sh-split" "--raw-fused"; do
     n=$(echo "$v" | tr -d " -")
     SPF_SH_BAND4=0 python bench.py --config REF10V $v --no-cpu-baseline > "$OUT/bench_REF10V_$n.json" 2>> "$ERR"
   done
   python bench.py --api module --no-cpu-baseline > "$OUT/bench_C2_api_module.json" 2>> "$ERR"
   SPF_PREPARE_STEPS=0 python bench.py --api module --no-cpu-baseline > "$OUT/bench_C2_api_module_general_path.json" 2>> "$ERR"
   python bench.py --s-mult 10 --no-cpu-baseline > "$OUT/bench_C2_stress.json" 2>> "$ERR"
+  SPF_SH_BAND4=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_REF2V_rawfused" -o stats -- \
+      python bench.py --config REF2V --raw-fused --no-cpu-baseline --no-secondary > "$OUT/stats_REF2V_rawfused.log" 2>&1
+  find "$OUT/stats_REF2V_rawfused" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_REF2V_rawfused.csv" \;
+  rm -rf "$OUT/stats_REF2V_rawfused"
+  SPF_SH_BAND4=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_REF2V_split" -o stats -- \
+      python bench.py --config REF2V --sh-split --no-cpu-baseline --no-secondary > "$OUT/stats_REF2V_split.log" 2>&1
+  find "$OUT/stats_REF2V_split" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats_REF2V_split.csv" \;
+  rm -rf "$OUT/stats_REF2V_split"
   python bench.py --rope > "$OUT/rope_bench.json" 2>> "$ERR"
   tools/pmc_rope.sh > "$OUT/pmc_rope.log" 2>&1; cp gpurun_out/pmc_summary_rope.json "$OUT/pmc_summary_rope.json"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_rope" -o stats -- python bench.py --rope > "$OUT/stats_rope.log" 2>&1
