@@ -64,6 +64,8 @@ def random_case(seed: int, wide: bool = False):
     if ri(0, 3) == 0:                                    # strong view dependence: the colour clamp fires often
         batch.harmonics[..., 1:] *= 8.0
     desc = dict(S=S, V=V, K=K, G=G, hw=hw, s_mult=s_mult, si=si, band4=band4, planned=planned)
+    if K == 25 and ri(0, 1):                             # round 6: the harmonics band-split (Gaussians.harmonics_band4)
+        desc["split"] = True
     if wide:
         # a second family of draws (own generator: the plain cases keep their seeds): anisotropic, off-centre
         # intrinsics, large camera rotations, raw (non-unit) quaternions, opacities of exactly 0 and 1, zero scales
@@ -118,7 +120,7 @@ def main():
                     exact = util.run_product(batch, background=bg, scale_invariant=si, with_grads=False, band4=band4)
                     max_pairs = rasterizer.plan_pair_budget(exact["stats"], slack=1.3)
                 prod = util.run_product(batch, background=bg, scale_invariant=si, pixel_mask=ref["pixel_mask"],
-                                        band4=band4, max_pairs=max_pairs)
+                                        band4=band4, max_pairs=max_pairs, split=bool(desc.get("split")))
                 rep = util.compare(prod, ref, max_fragile_frac=0.10)
                 rep["num_pairs"] = prod["stats"].get("num_pairs")
             except Exception:                           # noqa: BLE001 -- a crash is a finding too

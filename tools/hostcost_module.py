@@ -47,7 +47,7 @@ for _ in range(n):
     step(True)
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / n
-print("train graphs:", len(d._prepared_steps), "ms/step", round(wall * 1e3, 4), {k: round(v / n * 1e6, 1) for k, v in T.items()}, "us host per phase")
+print("prepared steps:", len(d._prepared_steps), "ms/step", round(wall * 1e3, 4), {k: round(v / n * 1e6, 1) for k, v in T.items()}, "us host per phase")
 
 if os.environ.get("SPF_CPROFILE"):
     import cProfile
