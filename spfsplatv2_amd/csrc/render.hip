@@ -521,6 +521,12 @@ __global__ __launch_bounds__(kBlock, STAGE == 256 ? 8 : 4) void spf_render_fwd_l
 // each thread writes ONE 48-byte record for its entry's (Gaussian, tile) pair -- no global atomics.
 // ------------------------------------------------------------------------------------------------
 constexpr int kAcc = 10;
+#ifdef SPF_ROWS_CENSUS
+__device__ unsigned long long g_rows_census[8];
+#define SPF_CENSUS(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_rows_census[i], (unsigned long long)(v)); } while (0)
+#else
+#define SPF_CENSUS(i, v) do {} while (0)
+#endif
 
 template <bool DEPTH_GRAD>
 __device__ __forceinline__ void flush_pair(float* __restrict__ gpair, uint32_t slot, const float* acc) {
@@ -584,6 +590,7 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                                    0.f, 0.f);
     }
     if (bmax == 0) return;
+    if (wave == 0) { SPF_CENSUS(0, 1); SPF_CENSUS(1, bmax); SPF_CENSUS(7, n); }
 
     float Tr = T_final;
     float sB = -tail * T_final;          // running "behind" scalar of the replay (as in the lists form, see its phase B)
@@ -636,6 +643,7 @@ __device__ __forceinline__ void bwd_rows_tile(float4* s_p0, float2* s_p1, float4
                 const float alpha = fminf(kAlphaMax, p1.y * Gv);
                 const bool hit = act && pos < ncon && power <= 0.f && alpha >= kAlphaMin;
                 const uint64_t hb = __ballot(hit);
+                SPF_CENSUS(2, 1); SPF_CENSUS(3, __popcll(__ballot(act)) >> 4); SPF_CENSUS(4, __popcll(hb)); SPF_CENSUS(5, hb != 0);
                 if (hb == 0) continue;
                 // (the ten partial gradients are products of two per-lane scalars, w = alpha T and u = G dL/dalpha: only those
                 //  are zeroed for the lanes without a hit, the products are formed for the whole wave after the branch)
@@ -1073,3 +1081,10 @@ hipError_t launch_render_bwd(const SpfDims& d, const SpfInputs& in, const SpfSta
 }
 
 }  // namespace spf
+#ifdef SPF_ROWS_CENSUS
+extern "C" int spf_debug_rows_census(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spf::g_rows_census), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(spf::g_rows_census), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
