@@ -352,7 +352,7 @@ class _PreparedRender(torch.autograd.Function):
         step = entry.step
         if token.gen != entry.gen:
             raise RuntimeError("spfsplatv2_amd: this decoder call's saved state was overwritten by a later call of the same "
-                               "inputs (a backward through a prepared training call after a NEWER forward of the same key); "
+                               "shapes (a SECOND backward through a prepared training call after a newer forward); "
                                "set decoder.prepare_steps = False for such a loop")
         if ctx.check == "backward" and not token.consumed:
             step.raise_if_failed()                   # (one host sync, as in the eager path: a failed plan raises here)
@@ -410,6 +410,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # statistics / plan counters of THIS decoder's most recent call (two live decoders do not interleave):
         # `spfsplatv2_amd.plan_flags(decoder.last_call)`, `plan_pair_budget(decoder.last_call)`
         self.last_call = CallRecord()
+        self._last_call_borrowed = False   # last_call is the record of a prepared step / captured graph (theirs to keep)
         # Evaluation-shaped calls (no gradient will be asked for, planned pair budget): the whole call -- camera set-up,
         # projection + binning, tile sort, compositing, depth x near -- is ~9 launches of a few microseconds each, and a
         # Python thread needs longer to issue them than the GPU to run them (test_step: b = 1, v = 3,
@@ -444,14 +445,16 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self._auto_verdict = None        # the one pinned word + event all of them use
         # TRAINING calls (planned, something requires grad): what the GPU runs per call is ~9 kernels of 5 - 130 us; what the
         # host runs to launch them the general way -- validation, a dozen allocations, argument structs, autograd
-        # bookkeeping of 21 saved tensors -- approaches that on a slow host.  So, when a call's input addresses repeat (key as
-        # for evaluation calls, plus which inputs require grad), the module PREPARES the step once (rasterizer.StaticStep:
-        # the chain's state at fixed addresses, argument structs built once) and later calls are five C-ABI calls.  Outputs
-        # and gradients are fresh tensors per call -- nothing a caller holds is rewritten, leaves accumulate as ever --;
-        # results are bit-identical to the general path.  One forward may be outstanding per key: a second forward before
-        # the first one's backward takes the general path.  `prepare_steps = False` / SPF_PREPARE_STEPS=0: off.
+        # bookkeeping of 21 saved tensors -- approaches that on a slow host.  So, when a call's SHAPES repeat (all nine input
+        # shapes, which inputs require grad, image size, plan), the module PREPARES the step once (rasterizer.StaticStep:
+        # the chain's state at fixed addresses, argument structs built once) and later calls bind their inputs -- a dozen
+        # pointer fields: an encoder's fresh tensors of every step are as good as static leaves -- and are five C-ABI calls.
+        # Outputs and gradients are fresh tensors per call -- nothing a caller holds is rewritten, leaves accumulate as ever
+        # --; results are bit-identical to the general path.  A forward issued while another of the same shapes waits for
+        # its backward gets a step of its own (two per shape, three per decoder); beyond that the general path.
+        # `prepare_steps = False` / SPF_PREPARE_STEPS=0: off.
         self.prepare_steps = os.environ.get("SPF_PREPARE_STEPS", "1") != "0"
-        self._prepared_steps: dict = {}    # key -> _PreparedStep
+        self._prepared_steps: dict = {}    # key (shapes, flags, plan) -> [_PreparedStep]
         self._prepare_seen: dict = {}
         self._graphs: dict = {}          # key -> _EvalGraph (insertion-ordered: oldest first)
         self._graph_seen: dict = {}      # key -> None: keys seen once, not yet captured
@@ -485,7 +488,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         for k in self._TRANSIENT:
             if k in state:
                 state[k] = {} if isinstance(state[k], dict) else None
-        state["last_call"] = CallRecord()
+        state["last_call"], state["_last_call_borrowed"] = CallRecord(), False
         return state
 
     @property
@@ -513,15 +516,25 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self._graph_seen.clear()
         self._graph_unused = 0
 
+    def _own_record(self) -> CallRecord:
+        """The record a general-path call writes into: the decoder's own.  After a call on a prepared step or a replayed
+        graph `last_call` IS that entry's record (counters, verdict word: what its next call is checked by) -- a general
+        call that wrote into it would have the entry verify its next call against another call's buffers."""
+        if self._last_call_borrowed:
+            self.last_call, self._last_call_borrowed = CallRecord(), False
+        return self.last_call
+
     def clear_prepared_steps(self) -> None:
         self._prepared_steps.clear()
         self._prepare_seen.clear()
 
-    _PREPARED_SLOTS = 2
+    _PREPARED_SLOTS = 3          # prepared steps per decoder (each holds a whole call's state)
+    _PREPARED_PER_KEY = 2        # ... of which for the same shapes (forwards waiting for their backward at the same time)
 
     def _prepare_key(self, tensors, image_shape):
         """None unless this call may run on a prepared step: planned with a list-length class (direct bins),
-        gradients wanted, dense float32 device tensors, no capture going on, no gradient bucket waiting for the backward."""
+        gradients wanted, dense float32 device tensors, no capture going on.  The key holds SHAPES, not addresses: the
+        inputs are bound per call (StaticStep.bind), so an encoder's fresh tensors of every step find the same step."""
         plan = self.max_pairs
         if not (self.prepare_steps and isinstance(plan, PairBudget) and plan.max_tile_list > 0):
             return None
@@ -535,8 +548,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         if not any(flags) or any(flags[1:4]):           # (intrinsics / near / far are not differentiable inputs)
             return None
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
-        return (tuple(map(_data_ptr, tensors)), tuple(flags), tensors[0].shape, tensors[4].shape, tensors[5].shape,
-                tuple(image_shape), int(plan.capacity), int(plan.max_tile_list), band4, self.background_color.data_ptr(),
+        return (tuple(t.shape for t in tensors), tuple(flags), tensors[0].device.index, tuple(image_shape),
+                int(plan.capacity), int(plan.max_tile_list), band4, self.background_color.data_ptr(),
                 self.make_scale_invariant, self.enable_cov_grad, self.enable_sh_grad)
 
     def _prepare_step(self, key, gaussians, extrinsics, intrinsics, near, far, image_shape):
@@ -562,8 +575,14 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         want = dict(scales_rot=self.enable_cov_grad and (gaussians.scales.requires_grad or gaussians.rotations.requires_grad),
                     shs=self.enable_sh_grad and gaussians.harmonics.requires_grad, colors=False,
                     view=bool(extrinsics.requires_grad), means2D=False)
-        while len(self._prepared_steps) >= self._PREPARED_SLOTS:
-            self._prepared_steps.pop(next(iter(self._prepared_steps)))
+        # room: the oldest step no forward is waiting on makes way; none such -> this call the general way
+        while sum(map(len, self._prepared_steps.values())) >= self._PREPARED_SLOTS:
+            victim = next(((k, e) for k, es in self._prepared_steps.items() for e in es if not e.busy()), None)
+            if victim is None:
+                return None
+            self._prepared_steps[victim[0]].remove(victim[1])
+            if not self._prepared_steps[victim[0]]:
+                del self._prepared_steps[victim[0]]
         try:
             with torch.no_grad(), torch.cuda.device(extrinsics.device):
                 step = StaticStep(extrinsics, intrinsics, near, far, gaussians.means, gaussians.scales, gaussians.rotations,
@@ -580,16 +599,18 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             return None
         entry.record = CallRecord(counters=step.counters, plan=step.plan_info)
         entry.nbytes = step.nbytes
-        self._prepared_steps[key] = entry
+        self._prepared_steps.setdefault(key, []).append(entry)
         self._prepare_seen.pop(key, None)
         return entry
 
-    def _render_prepared(self, entry, gaussians, extrinsics, near, want_extra: bool):
+    def _render_prepared(self, entry, gaussians, extrinsics, intrinsics, near, far, want_extra: bool):
         check = self.max_pairs.check
+        entry.step.bind(extrinsics, intrinsics, near, far, gaussians.means, gaussians.scales, gaussians.rotations,
+                        gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
         color, depth, alpha, radii = _PreparedRender.apply(
             entry, check, want_extra, extrinsics, gaussians.means, gaussians.scales, gaussians.rotations,
             gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
-        self.last_call = entry.record
+        self.last_call, self._last_call_borrowed = entry.record, True
         return DecoderOutput(color, depth), alpha, radii
 
     def _render_eager(self, gaussians, extrinsics, intrinsics, near, far, image_shape, max_pairs, record):
@@ -693,23 +714,30 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
     def _render_planned(self, tensors, gaussians, extrinsics, intrinsics, near, far, image_shape, want_extra: bool):
         if getattr(gaussians, "raw", None) is not None:           # (fused adapter: the general launcher, planned or exact)
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
-                                                            self.max_pairs, self.last_call)
+                                                            self.max_pairs, self._own_record())
             return DecoderOutput(color, depth), alpha, radii
         tkey = self._prepare_key(tensors, image_shape)
         if tkey is not None:
-            entry = self._prepared_steps.get(tkey)
-            if entry is None and tkey in self._prepare_seen:
+            entries = self._prepared_steps.get(tkey)
+            entry = None
+            if entries:
+                entry = next((e for e in entries if not e.busy()), None)
+                if entry is None and len(entries) < self._PREPARED_PER_KEY:
+                    # every step of these shapes is waiting for its backward (one training step renders the target and
+                    # the context views with the same shapes, say): one more
+                    entry = self._prepare_step(tkey, gaussians, extrinsics, intrinsics, near, far, image_shape)
+            elif tkey in self._prepare_seen:
                 entry = self._prepare_step(tkey, gaussians, extrinsics, intrinsics, near, far, image_shape)
-            elif entry is None:
+            else:
                 if len(self._prepare_seen) >= 64:
                     self._prepare_seen.clear()
-                self._prepare_seen[tkey] = None            # first sight: run as usual; the second call of the key is captured
-            if entry is not None and not entry.busy():
-                return self._render_prepared(entry, gaussians, extrinsics, near, want_extra)
+                self._prepare_seen[tkey] = None            # first sight: run as usual; the second call of the shapes is prepared
+            if entry is not None:
+                return self._render_prepared(entry, gaussians, extrinsics, intrinsics, near, far, want_extra)
         key = self._eval_graph_key(tensors, image_shape)
         if key is None:
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
-                                                            self.max_pairs, self.last_call)
+                                                            self.max_pairs, self._own_record())
             return DecoderOutput(color, depth), alpha, radii
         entry = self._graphs.get(key)
         if entry is None:
@@ -721,13 +749,13 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                     self._graph_seen[key] = None
                 with torch.no_grad():
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
-                                                                    image_shape, self.max_pairs, self.last_call)
+                                                                    image_shape, self.max_pairs, self._own_record())
                 return DecoderOutput(color, depth), alpha, radii
             entry = self._capture(key, gaussians, extrinsics, intrinsics, near, far, image_shape)
             if entry is None:        # the capture failed (another thread's HIP call, out of memory ...): this call eagerly
                 with torch.no_grad():
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
-                                                                    image_shape, self.max_pairs, self.last_call)
+                                                                    image_shape, self.max_pairs, self._own_record())
                 return DecoderOutput(color, depth), alpha, radii
         else:
             self._graph_unused = 0
@@ -735,7 +763,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         if verdict is not None:
             verdict.zero_()                          # (pinned host word the graph's projection kernel stores to on failure)
         entry.graph.replay()
-        self.last_call = entry.record
+        self.last_call, self._last_call_borrowed = entry.record, True
         flat, alpha, radii = entry.outputs
         # ONE copy-out, queued right behind the replay (before any wait for the verdict): what the caller gets is the
         # caller's (the graph's own buffers are rewritten by its next replay); colour and depth were packed into one flat
@@ -753,7 +781,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             if failed:
                 # the plan did not hold for THESE inputs (the graph's outputs are NaN): this call in exact mode instead
                 # (on a record of its own: the graph's record must keep the counters its next replay is checked by)
-                self.last_call = CallRecord()
+                self.last_call, self._last_call_borrowed = CallRecord(), False
                 with torch.no_grad():
                     color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
                                                                     image_shape, None, self.last_call)

@@ -678,8 +678,10 @@ class StaticStep:
     per-pixel state, gradient records, pose partials) lives at fixed addresses, the argument structs are built once, and
     what a call costs the host is a handful of C-ABI calls -- no allocation besides its OUTPUTS, no validation, no struct
     marshalling.  Outputs (image | depth, alpha; every gradient) are fresh tensors per call: nothing a caller holds is
-    ever rewritten.  `DecoderSplattingCUDA` uses it for training calls whose input addresses repeat (decoder.py); the
-    inputs are borrowed by address, as a captured graph would borrow them.  Direct bins only.
+    ever rewritten.  `DecoderSplattingCUDA` uses it for training calls whose SHAPES repeat (decoder.py): the inputs are
+    bound per call (`bind`: a dozen pointer fields; the step holds the tensors until the next `bind`, so they outlive
+    the backward) -- an encoder that hands over fresh tensors every step runs on the same prepared state as a loop over
+    static leaves.  Direct bins only.
 
     `launch_project()` touches state only; `render()` and `backward()` write fresh outputs.  Between a
     `launch_project()` and the `backward()` that belongs to it the state must stay as it is: one step at a time.
@@ -722,26 +724,22 @@ class StaticStep:
         self.counters = self.tiles[4 * R * T + 1:4 * R * T + 5]
         self.capacity, self.bin_cap, self.RT = rec_cap, bin_cap, R * T
         self.plan_info = (int(bin_cap), int(rec_cap), lib.spf_raster_pair_shards(S, G))
-        bgx = _background(bg, S, V)
-        self.inputs = (means3D, scales, rotations, opacities, shs, None, self.view, self.proj, self.tanfov, bgx,
-                       self.vscale, self.view64)
-        self.shs_high = shs_high
+        self.bgx = _background(bg, S, V)
         self.state = (self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T, self.n_contrib)
         self.geom = (S, V, G, K, sh_degree, H, W, 1.0, 2, (0xFFFFFFFF, bin_cap, rec_cap), layout, bool(sh_band4))
-        self.near, self.scale_invariant = near, bool(scale_invariant)
-        self.cam = _lib.SpfCamera(_ptr(extrinsics), _ptr(intrinsics), _ptr(near), _ptr(far), _ptr(self.view),
-                                  _ptr(self.proj), _ptr(self.tanfov), _ptr(self.vscale), R, 1 if scale_invariant else 0,
-                                  _ptr(self.view64))
-        self.inp = _lib.SpfInputs(_ptr(means3D), _ptr(scales), _ptr(rotations), _ptr(opacities), _ptr(shs), None,
-                                  _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov), _ptr(bgx), _ptr(self.vscale),
-                                  _ptr(self.view64), _ptr(shs_high))
+        self.scale_invariant = bool(scale_invariant)
+        self.cam = _lib.SpfCamera(None, None, None, None, _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov),
+                                  _ptr(self.vscale), R, 1 if scale_invariant else 0, _ptr(self.view64))
+        self.inp = _lib.SpfInputs(None, None, None, None, None, None, _ptr(self.view), _ptr(self.proj), _ptr(self.tanfov),
+                                  _ptr(self.bgx), _ptr(self.vscale), _ptr(self.view64), None)
+        self.cam_b = _lib.SpfCamera(None, None, None, None, _ptr(self.view), None, None, None, R,
+                                    1 if scale_invariant else 0)
         self.verdict = torch.zeros(1, dtype=torch.int32, pin_memory=True)      # SpfState.verdict_host
         self.verdict_event = torch.cuda.Event()
         self.st = _state_struct(self.rec, self.radii, self.rect, self.tiles, self.pairs, self.pair_idx, self.final_T,
                                 self.n_contrib, R * T, R * G, R * nblk, verdict_host=self.verdict)
         self.out = _lib.SpfOutputs(None, None, None)
         self.max_tile = int(plan.max_tile_list)
-        self.near_b = near[:, :, None, None]                     # depth x near (decoder_splatting_cuda.py:72-76)
         # ---- backward ----
         self.want = dict(want)
         self.gpair = torch.empty((rec_cap, 10), **f32)
@@ -757,12 +755,27 @@ class StaticStep:
         self.grad_shapes = {name: tuple(t.shape) for name, t in like.items()}
         self.vpartial = torch.empty((R, nblk, 12), **f32) if want["view"] else None
         self.gr = _lib.SpfGrads(None, None, None, _ptr(self.gpair), _ptr(self.vpartial))
-        self.cam_b = _lib.SpfCamera(None, None, _ptr(near), None, _ptr(self.view), None, None, None, R,
-                                    1 if scale_invariant else 0)
         self.nblk = nblk
         self.nbytes = sum(t.numel() * t.element_size() for t in
                           (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
                            self.pairs, self.gpair))
+        self.bind(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high)
+
+    def bind(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high) -> None:
+        """This call's inputs (dense float32 device tensors of the shapes the step was prepared for -- the caller's
+        key guarantees that): a dozen pointer fields.  The step holds them until the next `bind`."""
+        cam, inp = self.cam, self.inp
+        cam.extrinsics, cam.intrinsics, cam.near, cam.far = (extrinsics.data_ptr(), intrinsics.data_ptr(), near.data_ptr(),
+                                                             far.data_ptr())
+        inp.means3D, inp.scales, inp.rotations, inp.opacities = (means3D.data_ptr(), scales.data_ptr(),
+                                                                 rotations.data_ptr(), opacities.data_ptr())
+        inp.shs, inp.shs_high = shs.data_ptr(), _ptr(shs_high)
+        self.cam_b.near = cam.near
+        self.inputs = (means3D, scales, rotations, opacities, shs, None, self.view, self.proj, self.tanfov, self.bgx,
+                       self.vscale, self.view64)
+        self.shs_high, self.near = shs_high, near
+        self.near_b = near[:, :, None, None] if self.scale_invariant else None   # depth x near (decoder_splatting_cuda.py:72-76)
+        self._held = (extrinsics, intrinsics, far)
 
     def launch_project(self) -> None:
         """Camera set-up + clearing of the tile bookkeeping, projection + binning (state only: capturable)."""

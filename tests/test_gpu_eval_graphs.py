@@ -97,6 +97,28 @@ def test_replayed_call_whose_plan_fails_is_rerun_in_exact_mode(hip_lib):
         assert torch.equal(again.color, exact.color)
 
 
+def test_a_general_call_between_replays_leaves_the_graphs_record_alone(hip_lib):
+    """`last_call` after a replay is the GRAPH's record (its counters and verdict word are what the next replay is
+    checked by).  A general-path call in between -- here an exact-mode one -- writes the decoder's own record, not that
+    one: the next replay, on inputs that outgrew the plan at the same addresses, is still caught and re-run exactly."""
+    spf, dec, b, d, g, args, exact = _setup(seed=12)
+    plan = d.max_pairs._replace(check="backward")
+    d.max_pairs = plan
+    with torch.no_grad():
+        d.forward(*args()); d.forward(*args())
+        assert len(d._graphs) == 1 and torch.equal(d.forward(*args()).color, exact.color)
+        graph_record = d.last_call
+        d.max_pairs = None
+        assert torch.equal(d.forward(*args()).color, exact.color)    # exact mode, the general launcher
+        assert d.last_call is not graph_record and graph_record.get("counters") is not None
+        d.max_pairs = plan
+        b.scales.mul_(150.0)                                         # same addresses, footprints x 150: the plan fails
+        want = util.product_decoder().forward(*args())
+        got = d.forward(*args())                                     # replayed, verified against ITS OWN record, re-run
+    assert len(d._graphs) == 1 and not bool(torch.isnan(got.color).any()) and torch.equal(got.color, want.color)
+    assert not torch.equal(got.color, exact.color)
+
+
 def _auto_decoder(slack=1.3, defer=False):
     d = util.product_decoder(auto_plan=slack)
     d.auto_plan_defer = defer
@@ -253,11 +275,11 @@ def _same(a, b):
 
 @pytest.mark.parametrize("split", [False, True], ids=["dense_sh", "split_sh"])
 def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
-    """VERDICT r5 task 5: a planned training call whose input addresses repeat runs on a PREPARED step (static state,
-    argument structs built once: five C-ABI calls) -- images, depth and every gradient bit-identical to the general path;
-    what a call returned stays the caller's; an in-place update of an input (an optimizer step) is seen; a depth gradient
-    and a retained graph's second backward give the same numbers, and a forward issued before the previous backward takes
-    the general path."""
+    """VERDICT r5 task 5: a planned training call whose shapes repeat runs on a PREPARED step (static state, argument
+    structs built once: five C-ABI calls) -- images, depth and every gradient bit-identical to the general path; what a
+    call returned stays the caller's; an in-place update of an input (an optimizer step) is seen; a depth gradient and a
+    retained graph's second backward give the same numbers, and a forward issued before the previous backward gets a
+    prepared step of its own."""
     spf, b, leaves, g, plan, step, w = _train_setup(split=split)
     eager, d = util.product_decoder(max_pairs=plan), util.product_decoder(max_pairs=plan)
     eager.prepare_steps = False
@@ -284,7 +306,7 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
         t.grad = None
     loss.backward()
     assert all(torch.equal(leaves[n].grad, g1[n]) for n in leaves)
-    # a forward before the previous one's backward: the second call is launched eagerly, both are right
+    # a forward before the previous one's backward: the second call gets a step of its own, both are right
     for t in leaves.values():
         t.grad = None
     o1 = d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
@@ -294,9 +316,53 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
     ref = step(eager)
     assert torch.equal(o1.color, o2.color) and torch.equal(o1.color, ref[0].color)
     assert all(util.rel_linf(both[n], 2 * ref[2][n]) < 1e-6 for n in leaves)
-    assert len(d._prepared_steps) == 1
+    assert len(d._prepared_steps) == 1 and [len(v) for v in d._prepared_steps.values()] == [2]
+    # ... and a third one waiting at the same time: the general path (two steps per shape), still right
+    for t in leaves.values():
+        t.grad = None
+    outs = [d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape) for _ in range(3)]
+    sum((o.color * w).sum() for o in outs).backward()
+    assert all(torch.equal(o.color, ref[0].color) for o in outs) and [len(v) for v in d._prepared_steps.values()] == [2]
+    assert all(util.rel_linf(leaves[n].grad, 3 * ref[2][n]) < 1e-6 for n in leaves)
     d.clear_prepared_steps()
     assert _same(step(d), step(eager))
+
+
+def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib):
+    """What an encoder hands the decoder: NEW tensors every step (other addresses, other values).  The prepared step is
+    keyed by shapes and binds its inputs per call, so the second call prepares it and every later one runs on it --
+    bit-identical to the general path on the same values; the tensors of a call outlive its backward (the step holds
+    them), and nothing of an older call is read."""
+    spf, b, leaves, g, plan, step, w = _train_setup(seed=37)
+    from spfsplatv2_amd import decoder as dec
+    eager, d = util.product_decoder(max_pairs=plan), util.product_decoder(max_pairs=plan)
+    eager.prepare_steps = False
+    seen = set()
+    for i in range(5):
+        fresh = {n: (t.detach() + (0.003 * i if n == "means" else 0.0)).clone().requires_grad_(True) for n, t in leaves.items()}
+        cams = [t.clone() for t in (b.intrinsics, b.near, b.far)]
+        seen.add(fresh["means"].data_ptr())
+        res = []
+        for m in (d, eager):
+            gi = dec.Gaussians(fresh["means"], None, fresh["rotations"], fresh["scales"], fresh["harmonics"], fresh["opacities"])
+            for t in fresh.values():
+                t.grad = None
+            out = m.forward(gi, fresh["extrinsics"], *cams, b.image_shape)
+            loss = (out.color * w).sum() + 0.1 * (out.depth * w[:, :, 0]).sum()
+            del gi
+            if m is d and i == 3:
+                # the caller drops everything but the loss: the inputs must still be there for the backward's kernels
+                held = {n: t for n, t in fresh.items()}
+                grads = torch.autograd.grad(loss, list(held.values()))
+                res.append((out.color.clone(), out.depth.clone(), {n: gr for n, gr in zip(held, grads)}))
+                continue
+            loss.backward()
+            res.append((out.color.clone(), out.depth.clone(), {n: t.grad.clone() for n, t in fresh.items()}))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), i
+        assert all(torch.equal(res[0][2][n], res[1][2][n]) for n in fresh), i
+    entries = [e for es in d._prepared_steps.values() for e in es]
+    assert len(entries) == 1 and entries[0].gen == 4 and len(seen) > 1      # call 0 the general way, calls 1 - 4 on ONE step
+    assert eager._prepared_steps == {}
 
 
 def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
