@@ -91,7 +91,8 @@ def build_binding(force: bool = False, verbose: bool = True) -> Path:
            "-DTORCH_EXTENSION_NAME=_spf_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", "-w",
            f"-L{tdir / 'lib'}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python",
-           f"-L{OUT_DIR}", "-lspfsplat_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tdir / 'lib'}"]
+           f"-L{OUT_DIR}", "-lspfsplat_hip", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN",
+           f"-Wl,-rpath,{tdir / 'lib'}"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

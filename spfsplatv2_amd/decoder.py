@@ -324,6 +324,17 @@ class _PreparedRender(torch.autograd.Function):
         token = _StepToken(entry.gen)
         entry.token = weakref.ref(token)
         ctx.entry, ctx.token, ctx.check = entry, token, check
+        if step.fast is not None:
+            # the compiled step (csrc/torch_binding.cpp::PreparedStep): the same chain, one C++ call
+            with rz._spf_errors():
+                color, depth, alpha, failed = step.fast.forward(check == "early")
+            radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
+            if failed:
+                token.consumed = True
+                step.raise_if_failed()
+            if want_extra:
+                ctx.mark_non_differentiable(radii)
+            return color, depth, (alpha if want_extra else None), radii
         with torch.cuda.device(step.dev):
             early = check == "early"
             if early:
@@ -359,10 +370,15 @@ class _PreparedRender(torch.autograd.Function):
         token.consumed = True                        # (a retained graph's second backward finds the same state: gen matches)
         need = ctx.needs_input_grad      # (entry, check, want_extra, extrinsics, means, scales, rotations, opacities, shs, shs_high)
         if active_bucket() is None:
+            if step.fast is not None:
+                with rz._spf_errors():
+                    d_means, d_opac, d_scales, d_rot, d_shs, d_high, d_ext = step.fast.backward(g_color, g_depth, g_alpha)
+                return (None, None, None, d_ext if need[3] else None, d_means, d_scales, d_rot, d_opac, d_shs, d_high)
             with torch.cuda.device(step.dev):
                 g = step.backward(g_color, g_depth, g_alpha)
             return (None, None, None, g.get("extrinsics") if need[3] else None, g["means"], g.get("scales"),
                     g.get("rotations"), g["opacities"], g.get("harmonics"), g.get("harmonics_band4"))
+        step.ensure_python_binding()
         # a gradient bucket supplies the output buffers (shard.GradBucket): the general launcher, same state
         if g_depth is not None:
             g_depth = g_depth[:, :, None] * step.near_b if step.scale_invariant else g_depth[:, :, None]

@@ -759,11 +759,42 @@ class StaticStep:
         self.nbytes = sum(t.numel() * t.element_size() for t in
                           (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
                            self.pairs, self.gpair))
+        # the same step driven from the compiled binding when it has been built (csrc/torch_binding.cpp::PreparedStep takes
+        # the structs over by value): bind / forward / backward are then one C++ call each
+        mod = _lib.fast()
+        self.fast = None
+        if mod is not None and hasattr(mod, "PreparedStep"):
+            with _spf_errors():
+                self.fast = mod.PreparedStep(
+                    C.addressof(self.dims), C.addressof(self.inp), C.addressof(self.st), C.addressof(self.cam),
+                    C.addressof(self.cam_b), C.addressof(self.gr), self.tiles, self.capacity, self.max_tile, nblk,
+                    self.verdict, self.view, self.vpartial, bool(want["scales_rot"]), bool(want["shs"]),
+                    "harmonics_band4" in self.grad_shapes, bool(want["view"]))
         self.bind(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high)
 
     def bind(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high) -> None:
         """This call's inputs (dense float32 device tensors of the shapes the step was prepared for -- the caller's
-        key guarantees that): a dozen pointer fields.  The step holds them until the next `bind`."""
+        key guarantees that): a dozen pointer fields.  The step holds their STORAGE until the next `bind` (detached
+        aliases: an encoder's autograd graph is not kept alive through them)."""
+        if self.fast is not None:
+            self.fast.bind(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high)
+            self._python_bound = False
+            return
+        self._bind_python(extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high)
+
+    def ensure_python_binding(self) -> None:
+        """The Python-side fields of the current binding (`inputs`, `shs_high`, `near_b`, the ctypes structs): what the
+        compiled step does not need and a gradient bucket's general backward does."""
+        if not self._python_bound:
+            self._bind_python(*self.fast.held())
+
+    def _bind_python(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high) -> None:
+        self._python_bound = True
+        (extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs) = (
+            t if t.grad_fn is None else t.detach()
+            for t in (extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs))
+        if shs_high is not None and shs_high.grad_fn is not None:
+            shs_high = shs_high.detach()
         cam, inp = self.cam, self.inp
         cam.extrinsics, cam.intrinsics, cam.near, cam.far = (extrinsics.data_ptr(), intrinsics.data_ptr(), near.data_ptr(),
                                                              far.data_ptr())

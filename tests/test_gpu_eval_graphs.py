@@ -268,13 +268,25 @@ def _train_setup(seed=31, split=False):
     return spf, b, leaves, g, plan, step, w
 
 
+@pytest.fixture(params=["compiled_step", "python_step"])
+def step_binding(request, monkeypatch):
+    """Prepared steps run from the compiled binding (csrc/torch_binding.cpp::PreparedStep) when it has been built and
+    from rasterizer.StaticStep's own ctypes calls otherwise: both under test."""
+    from spfsplatv2_amd import _lib
+    if request.param == "python_step":
+        monkeypatch.setattr(_lib, "_fast", None)
+    elif _lib.fast() is None or not hasattr(_lib.fast(), "PreparedStep"):
+        pytest.skip("the compiled binding has not been built")
+    return request.param
+
+
 def _same(a, b):
     return torch.equal(a[0].color, b[0].color) and torch.equal(a[0].depth, b[0].depth) and \
         all(torch.equal(a[2][n], b[2][n]) for n in a[2])
 
 
 @pytest.mark.parametrize("split", [False, True], ids=["dense_sh", "split_sh"])
-def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
+def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split, step_binding):
     """VERDICT r5 task 5: a planned training call whose shapes repeat runs on a PREPARED step (static state, argument
     structs built once: five C-ABI calls) -- images, depth and every gradient bit-identical to the general path; what a
     call returned stays the caller's; an in-place update of an input (an optimizer step) is seen; a depth gradient and a
@@ -291,6 +303,7 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
     held = second[0].color.clone()
     third = step(d)
     assert _same(third, want) and torch.equal(second[0].color, held) and third[0].color.data_ptr() != second[0].color.data_ptr()
+    assert all((e.step.fast is not None) == (step_binding == "compiled_step") for es in d._prepared_steps.values() for e in es)
     assert spf.plan_flags(d.last_call) == 0 and eager._prepared_steps == {}
     # an optimizer step: same addresses, new values
     with torch.no_grad():
@@ -328,7 +341,7 @@ def test_training_calls_replay_from_graphs_bit_identically(hip_lib, split):
     assert _same(step(d), step(eager))
 
 
-def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib):
+def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib, step_binding):
     """What an encoder hands the decoder: NEW tensors every step (other addresses, other values).  The prepared step is
     keyed by shapes and binds its inputs per call, so the second call prepares it and every later one runs on it --
     bit-identical to the general path on the same values; the tensors of a call outlive its backward (the step holds
@@ -344,7 +357,9 @@ def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib):
         seen.add(fresh["means"].data_ptr())
         res = []
         for m in (d, eager):
-            gi = dec.Gaussians(fresh["means"], None, fresh["rotations"], fresh["scales"], fresh["harmonics"], fresh["opacities"])
+            # (means and opacities as an encoder hands them over: non-leaf tensors with a graph behind them)
+            gi = dec.Gaussians(fresh["means"] * 1.0, None, fresh["rotations"], fresh["scales"], fresh["harmonics"],
+                               fresh["opacities"] + 0.0)
             for t in fresh.values():
                 t.grad = None
             out = m.forward(gi, fresh["extrinsics"], *cams, b.image_shape)
@@ -365,7 +380,29 @@ def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib):
     assert eager._prepared_steps == {}
 
 
-def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib):
+def test_prepared_step_backward_into_a_gradient_bucket(hip_lib, step_binding):
+    """Data-parallel ranks run the backward inside `with shard.GradBucket(...)`: the prepared step then hands the general
+    backward its state and the CURRENT binding's inputs (also when the forward ran in the compiled step) -- gradients
+    land in the bucket's views, equal to the unbucketed ones bit for bit."""
+    from spfsplatv2_amd import shard
+    spf, b, leaves, g, plan, step, w = _train_setup(seed=41)
+    d = util.product_decoder(max_pairs=plan)
+    step(d); want = step(d)                                              # second call: prepared
+    assert len(d._prepared_steps) == 1
+    for t in leaves.values():
+        t.grad = None
+    out = d.forward(g, leaves["extrinsics"], b.intrinsics, b.near, b.far, b.image_shape)
+    loss = (out.color * w).sum()
+    bucket = shard.GradBucket(*(leaves[n] for n in ("means", "scales", "rotations", "opacities", "harmonics")))
+    with bucket:
+        loss.backward()
+    lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
+    for n in ("means", "scales", "rotations", "opacities", "harmonics"):
+        assert lo <= leaves[n].grad.data_ptr() < hi and torch.equal(leaves[n].grad, want[2][n]), n
+    assert torch.equal(leaves["extrinsics"].grad, want[2]["extrinsics"]) and torch.equal(out.color, want[0].color)
+
+
+def test_training_graph_with_a_plan_that_fails_is_rerun_exactly(hip_lib, step_binding):
     """The module's own planning over prepared training calls: inputs that outgrow the plan AT THE SAME ADDRESSES (the
     prepared step exists) -> the forward's early check raises inside the module, the call is re-run in exact mode,
     re-planned and prepared again under the new plan."""
