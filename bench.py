@@ -317,10 +317,11 @@ def eval_latency(args, dev) -> dict:
     the 2-view model's 131,072 Gaussians with 25 SH coefficients, forward only, src/model/model_wrapper.py:415-454):
     wall time from the call to its result being complete, i.e. with a device synchronisation per call.  The call is the
     reference's own: `decoder.forward(gaussians, extrinsics, intrinsics, near, far, (h, w))` on the decoder MODULE
-    (`DecoderSplattingCUDA` under the registry name "splatting_cuda") -- which, for planned calls that will not be
-    differentiated, keeps its own cache of captured HIP graphs (`planned_median`: what a caller gets without doing
-    anything; `planned_no_graph_cache_median`: the same call launched kernel by kernel; `planned_graph_replay_*`: a graph
-    captured by the CALLER around the call, as round 4 measured it)."""
+    (`DecoderSplattingCUDA` under the registry name "splatting_cuda") -- which runs planned calls that will not be
+    differentiated on a forward-only PREPARED step (state at fixed addresses, structs built once, inputs bound per call;
+    `planned_median`: what a caller gets without doing anything) and, for plans that cannot be prepared, keeps a cache of
+    captured HIP graphs (`planned_graph_cache_median`: that cache alone, round 5's path; `planned_no_graph_cache_median`:
+    the general launcher, kernel by kernel; `planned_graph_replay_*`: a graph captured by the CALLER around the call)."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec, synthetic as syn
     b = syn.make_batch("REF2V", 1, 3, seed=4242).to(dev)
@@ -363,11 +364,20 @@ def eval_latency(args, dev) -> dict:
         raise RuntimeError("the unchanged-caller path does not reproduce the exact-mode image")
     decoder.auto_plan = None
     decoder.clear_eval_graphs()
+    decoder.clear_prepared_steps()
     decoder.max_pairs = plan
-    decoder.eval_graphs = False
+    decoder.eval_graphs = decoder.prepare_steps = False          # the general launcher
     for _ in range(max(args.warmup, 3)):
         call()
     nograph_med, nograph_min = latency(call, n)
+    decoder.eval_graphs = True                                   # the module's graph cache alone (round 5's path)
+    for _ in range(max(args.warmup, 3)):
+        call()
+    if not decoder._graphs:
+        raise RuntimeError("the decoder module did not capture the evaluation call")
+    cache_med, cache_min = latency(call, n)
+    decoder.clear_eval_graphs()
+    decoder.eval_graphs = False
     graph_med = graph_min = None
     try:
         g_ = torch.cuda.CUDAGraph()
@@ -379,14 +389,14 @@ def eval_latency(args, dev) -> dict:
         del g_
     except Exception as e:                                      # noqa: BLE001
         log(f"eval latency: graph capture failed ({type(e).__name__}: {e})")
-    decoder.eval_graphs = True
+    decoder.eval_graphs = decoder.prepare_steps = True          # the module as it comes
     for _ in range(max(args.warmup, 3)):
         call()
-    if not decoder._graphs:
-        raise RuntimeError("the decoder module did not capture the evaluation call")
+    if not (decoder._prepared_steps or decoder._graphs):
+        raise RuntimeError("the decoder module neither prepared nor captured the evaluation call")
     plan_med, plan_min = latency(call, n)
     if not torch.equal(call().color, reference_image):
-        raise RuntimeError("the replayed evaluation call does not reproduce the exact-mode image")
+        raise RuntimeError("the prepared evaluation call does not reproduce the exact-mode image")
     # back-to-back planned calls (no wait between them): what an evaluation loop that only reads the images later sees
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -405,10 +415,11 @@ def eval_latency(args, dev) -> dict:
             "config": {"workload": f"eval_1x3: 1 scene of {G} Gaussians, {K} SH coefficients per channel, 3 target views, "
                                    f"{h}x{w}, DecoderSplattingCUDA.forward under no_grad",
                        "launch": "one decoder.forward call, then torch.cuda.synchronize: wall time per call; planned "
-                                 "calls are replayed from the module's own HIP-graph cache"},
+                                 "calls run on the module's forward-only prepared step"},
             "latency_ms": {"exact_mode_median": round(exact_med, 4), "exact_mode_min": round(exact_min, 4),
                            "unchanged_caller_median": round(default_med, 4), "unchanged_caller_min": round(default_min, 4),
                            "planned_median": round(plan_med, 4), "planned_min": round(plan_min, 4),
+                           "planned_graph_cache_median": round(cache_med, 4), "planned_graph_cache_min": round(cache_min, 4),
                            "planned_no_graph_cache_median": round(nograph_med, 4),
                            "planned_no_graph_cache_min": round(nograph_min, 4),
                            "planned_graph_replay_median": None if graph_med is None else round(graph_med, 4),

@@ -324,33 +324,12 @@ class _PreparedRender(torch.autograd.Function):
         token = _StepToken(entry.gen)
         entry.token = weakref.ref(token)
         ctx.entry, ctx.token, ctx.check = entry, token, check
-        if step.fast is not None:
-            # the compiled step (csrc/torch_binding.cpp::PreparedStep): the same chain, one C++ call
-            with rz._spf_errors():
-                color, depth, alpha, failed = step.fast.forward(check == "early")
-            radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
-            if failed:
-                token.consumed = True
-                step.raise_if_failed()
-            if want_extra:
-                ctx.mark_non_differentiable(radii)
-            return color, depth, (alpha if want_extra else None), radii
-        with torch.cuda.device(step.dev):
-            early = check == "early"
-            if early:
-                step.verdict.zero_()                 # (host memory: the projection kernel stores here if it raises a flag)
-            step.launch_project()
-            if early:
-                # the verdict is final behind the projection kernel: an event there, waited for once sort and compositing
-                # have been queued -- the GPU works through the wait, and nothing is copied on the stream
-                step.verdict_event.record()
-            color, depth, alpha = step.render()
-            radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
-            if early:
-                step.verdict_event.synchronize()
-                if step.verdict.item() != 0:
-                    token.consumed = True
-                    step.raise_if_failed()
+        # (from the compiled step, csrc/torch_binding.cpp::PreparedStep, when it has been built: one C++ call)
+        color, depth, alpha, failed = step.forward(check == "early")
+        radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
+        if failed:
+            token.consumed = True
+            step.raise_if_failed()
         if want_extra:
             ctx.mark_non_differentiable(radii)
         return color, depth, (alpha if want_extra else None), radii
@@ -437,7 +416,9 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         # buffers, so what a call returns is the caller's (never overwritten by a later call).  A loop that hands over
         # fresh addresses every time simply never hits (after `_EVAL_GRAPH_MISSES` captures that were never replayed the
         # cache stops capturing).  `eval_graphs = False` or SPF_EVAL_GRAPHS=0 switches it off; `clear_eval_graphs()`
-        # releases the captured graphs and their buffers.
+        # releases the captured graphs and their buffers.  (Since the prepared steps below exist, evaluation calls of a
+        # plan with direct bins run on those -- faster than a replay plus its copy-out, and indifferent to where the
+        # tensors lie; this cache serves the plans that cannot be prepared and `prepare_steps = False`.)
         self.eval_graphs = True
         # `auto_plan` (slack factor, default 1.5; SPF_AUTO_PLAN=<slack>, SPF_AUTO_PLAN=0 / `auto_plan = None`: off): while the
         # caller has set no `max_pairs`, the module plans for itself -- an UNCHANGED caller does not pay exact mode's
@@ -544,24 +525,27 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self._prepared_steps.clear()
         self._prepare_seen.clear()
 
-    _PREPARED_SLOTS = 3          # prepared steps per decoder (each holds a whole call's state)
+    _PREPARED_SLOTS = 4          # prepared steps per decoder (each holds a whole call's state)
     _PREPARED_PER_KEY = 2        # ... of which for the same shapes (forwards waiting for their backward at the same time)
 
     def _prepare_key(self, tensors, image_shape):
-        """None unless this call may run on a prepared step: planned with a list-length class (direct bins),
-        gradients wanted, dense float32 device tensors, no capture going on.  The key holds SHAPES, not addresses: the
-        inputs are bound per call (StaticStep.bind), so an encoder's fresh tensors of every step find the same step."""
+        """None unless this call may run on a prepared step: planned with a list-length class (direct bins), dense
+        float32 device tensors, no capture going on.  The key holds SHAPES, not addresses: the inputs are bound per call
+        (StaticStep.bind), so an encoder's fresh tensors of every step find the same step.  Training calls (something
+        requires grad) and evaluation calls (nothing will be differentiated: forward-only steps, for the calls the graph
+        cache cannot serve because their tensors move) have keys of their own."""
         plan = self.max_pairs
         if not (self.prepare_steps and isinstance(plan, PairBudget) and plan.max_tile_list > 0):
             return None
-        if not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
             return None
+        grad = torch.is_grad_enabled()
         flags = []
         for t in tensors:
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
                 return None
-            flags.append(bool(t.requires_grad))
-        if not any(flags) or any(flags[1:4]):           # (intrinsics / near / far are not differentiable inputs)
+            flags.append(grad and bool(t.requires_grad))
+        if any(flags[1:4]):                             # (intrinsics / near / far are not differentiable inputs)
             return None
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
         return (tuple(t.shape for t in tensors), tuple(flags), tensors[0].device.index, tuple(image_shape),
@@ -588,9 +572,10 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         if high is not None:
             _f32c(high, "shs_high", (b, G, 3, 9))
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
-        want = dict(scales_rot=self.enable_cov_grad and (gaussians.scales.requires_grad or gaussians.rotations.requires_grad),
-                    shs=self.enable_sh_grad and gaussians.harmonics.requires_grad, colors=False,
-                    view=bool(extrinsics.requires_grad), means2D=False)
+        trains = any(key[1])
+        want = dict(scales_rot=trains and self.enable_cov_grad and (gaussians.scales.requires_grad or gaussians.rotations.requires_grad),
+                    shs=trains and self.enable_sh_grad and gaussians.harmonics.requires_grad, colors=False,
+                    view=trains and bool(extrinsics.requires_grad), means2D=False)
         # room: the oldest step no forward is waiting on makes way; none such -> this call the general way
         while sum(map(len, self._prepared_steps.values())) >= self._PREPARED_SLOTS:
             victim = next(((k, e) for k, es in self._prepared_steps.items() for e in es if not e.busy()), None)
@@ -603,7 +588,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             with torch.no_grad(), torch.cuda.device(extrinsics.device):
                 step = StaticStep(extrinsics, intrinsics, near, far, gaussians.means, gaussians.scales, gaussians.rotations,
                                   gaussians.opacities, gaussians.harmonics, high, self.background_color, h, w, isqrt(n) - 1,
-                                  self.make_scale_invariant, self.max_pairs, band4, want)
+                                  self.make_scale_invariant, self.max_pairs, band4, want, forward_only=not trains)
                 entry = _PreparedStep()
                 entry.step, entry.gen, entry.token = step, 0, None
         except Exception as e:                      # noqa: BLE001
@@ -619,10 +604,25 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
         self._prepare_seen.pop(key, None)
         return entry
 
-    def _render_prepared(self, entry, gaussians, extrinsics, intrinsics, near, far, want_extra: bool):
+    def _render_prepared(self, entry, gaussians, extrinsics, intrinsics, near, far, want_extra: bool, trains: bool,
+                         image_shape):
         check = self.max_pairs.check
         entry.step.bind(extrinsics, intrinsics, near, far, gaussians.means, gaussians.scales, gaussians.rotations,
                         gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
+        if not trains:
+            # an evaluation call on a forward-only step: verified like a replayed graph's (the wait is for the projection
+            # kernel only); a plan that did not hold for THESE inputs -> this call in exact mode, on a record of its own
+            step = entry.step
+            color, depth, alpha, failed = step.forward(check != "deferred")
+            if failed:
+                self.last_call, self._last_call_borrowed = CallRecord(), False
+                with torch.no_grad():
+                    color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far,
+                                                                    image_shape, None, self.last_call)
+                return DecoderOutput(color, depth), alpha, radii
+            radii = step.radii.view(alpha.shape[0], alpha.shape[1], -1).clone() if want_extra else None
+            self.last_call, self._last_call_borrowed = entry.record, True
+            return DecoderOutput(color, depth), (alpha if want_extra else None), radii
         color, depth, alpha, radii = _PreparedRender.apply(
             entry, check, want_extra, extrinsics, gaussians.means, gaussians.scales, gaussians.rotations,
             gaussians.opacities, gaussians.harmonics, getattr(gaussians, "harmonics_band4", None))
@@ -733,7 +733,14 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                                                             self.max_pairs, self._own_record())
             return DecoderOutput(color, depth), alpha, radii
         tkey = self._prepare_key(tensors, image_shape)
+        trains = tkey is not None and any(tkey[1])
+        key = None if trains else self._eval_graph_key(tensors, image_shape)
         if tkey is not None:
+            # training calls, and evaluation calls on forward-only steps: measured at the test_step shape, a prepared
+            # step's five launches into fresh outputs (0.094 ms per call and synchronisation) beat a replay of the same
+            # call's captured graph plus the copy-out of its buffers (0.108) -- and serve tensors that move every call,
+            # which a cache keyed by addresses never sees twice.  The graph cache below takes what cannot be prepared
+            # (plans without direct bins, `prepare_steps = False`).
             entries = self._prepared_steps.get(tkey)
             entry = None
             if entries:
@@ -749,8 +756,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
                     self._prepare_seen.clear()
                 self._prepare_seen[tkey] = None            # first sight: run as usual; the second call of the shapes is prepared
             if entry is not None:
-                return self._render_prepared(entry, gaussians, extrinsics, intrinsics, near, far, want_extra)
-        key = self._eval_graph_key(tensors, image_shape)
+                return self._render_prepared(entry, gaussians, extrinsics, intrinsics, near, far, want_extra, trains,
+                                             image_shape)
         if key is None:
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
                                                             self.max_pairs, self._own_record())

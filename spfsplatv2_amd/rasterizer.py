@@ -691,7 +691,7 @@ class StaticStep:
     what is prepared here.)"""
 
     def __init__(self, extrinsics, intrinsics, near, far, means3D, scales, rotations, opacities, shs, shs_high, bg,
-                 H, W, sh_degree, scale_invariant, plan: PairBudget, sh_band4, want: dict):
+                 H, W, sh_degree, scale_invariant, plan: PairBudget, sh_band4, want: dict, forward_only: bool = False):
         lib = _lib.load()
         self.lib = lib
         S, G, _ = means3D.shape
@@ -742,7 +742,7 @@ class StaticStep:
         self.max_tile = int(plan.max_tile_list)
         # ---- backward ----
         self.want = dict(want)
-        self.gpair = torch.empty((rec_cap, 10), **f32)
+        self.gpair = None if forward_only else torch.empty((rec_cap, 10), **f32)     # (evaluation calls' steps: no backward)
         like = {"means": means3D, "opacities": opacities}
         if want["scales_rot"]:
             like["scales"], like["rotations"] = scales, rotations
@@ -758,7 +758,7 @@ class StaticStep:
         self.nblk = nblk
         self.nbytes = sum(t.numel() * t.element_size() for t in
                           (self.rec, self.radii, self.rect, self.pair_idx, self.tiles, self.final_T, self.n_contrib,
-                           self.pairs, self.gpair))
+                           self.pairs, self.gpair) if t is not None)
         # the same step driven from the compiled binding when it has been built (csrc/torch_binding.cpp::PreparedStep takes
         # the structs over by value): bind / forward / backward are then one C++ call each
         mod = _lib.fast()
@@ -807,6 +807,26 @@ class StaticStep:
         self.shs_high, self.near = shs_high, near
         self.near_b = near[:, :, None, None] if self.scale_invariant else None   # depth x near (decoder_splatting_cuda.py:72-76)
         self._held = (extrinsics, intrinsics, far)
+
+    def forward(self, early: bool):
+        """The forward chain on the current binding: (colour, depth, alpha, failed).  `early`: wait for the projection
+        kernel's verdict (an event behind it, waited for once sort and compositing have been queued -- the GPU works
+        through the wait, nothing is copied on the stream); `failed` then says that the plan did not hold (outputs NaN)."""
+        if self.fast is not None:
+            with _spf_errors():
+                return self.fast.forward(bool(early))
+        with torch.cuda.device(self.dev):
+            if early:
+                self.verdict.zero_()                 # (host memory: the projection kernel stores here if it raises a flag)
+            self.launch_project()
+            if early:
+                self.verdict_event.record()
+            color, depth, alpha = self.render()
+            failed = False
+            if early:
+                self.verdict_event.synchronize()
+                failed = self.verdict.item() != 0
+        return color, depth, alpha, failed
 
     def launch_project(self) -> None:
         """Camera set-up + clearing of the tile bookkeeping, projection + binning (state only: capturable)."""

@@ -10,12 +10,14 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=9, **kw):
+def _setup(seed=9, prepare=False, **kw):
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec
     kw = {**dict(s_mult=4.0, G=3000, K=25, image_hw=(96, 80)), **kw}
     b = syn.make_batch("TEST", 1, 3, seed=seed, **kw).to("cuda")
     d = util.product_decoder()
+    d.prepare_steps = prepare         # (False: the graph cache's own tests -- with prepared steps on, evaluation calls of a
+    #                                    plan with direct bins never reach it)
     g = dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
     args = lambda gg=g, bb=b: (gg, bb.extrinsics, bb.intrinsics, bb.near, bb.far, bb.image_shape)
     with torch.no_grad():
@@ -125,10 +127,11 @@ def _auto_decoder(slack=1.3, defer=False):
     return d
 
 
-def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
+@pytest.mark.parametrize("prepare", [True, False], ids=["prepared_steps", "graph_cache"])
+def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib, prepare):
     """decoder.auto_plan (on by default): the module plans for itself.  First call of a shape: exact mode; the next ones
-    planned (and, being evaluation calls, captured); inputs that outgrow the plan are re-run in exact mode at once and
-    re-planned."""
+    planned (and, being evaluation calls, run on a forward-only prepared step -- or, with those off, captured); inputs
+    that outgrow the plan are re-run in exact mode at once and re-planned."""
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec
     small = syn.make_batch("TEST", 1, 3, seed=21, s_mult=2.0, G=3000, K=4, image_hw=(96, 80)).to("cuda")
@@ -136,6 +139,7 @@ def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
     gs = lambda b: dec.Gaussians(b.means, b.covariances, b.rotations, b.scales, b.harmonics, b.opacities)
     call = lambda d, b, g: d.forward(g, b.extrinsics, b.intrinsics, b.near, b.far, b.image_shape)
     ref, d = util.product_decoder(), _auto_decoder()
+    d.prepare_steps = prepare
     g_small, g_big = gs(small), gs(big)
     with torch.no_grad():
         want_small, want_big = call(ref, small, g_small), call(ref, big, g_big)
@@ -143,7 +147,8 @@ def test_auto_plan_evaluation_never_returns_a_failed_plan(hip_lib):
         assert isinstance(d.max_pairs, spf.PairBudget) and d.last_call.get("counters") is None       # ran exact, planned
         plan = d.max_pairs
         outs = [call(d, small, g_small) for _ in range(3)]                                           # planned; captured; replayed
-        assert d.max_pairs.capacity == plan.capacity and len(d._graphs) == 1
+        assert d.max_pairs.capacity == plan.capacity
+        assert (len(d._graphs), sum(map(len, d._prepared_steps.values()))) == ((0, 1) if prepare else (1, 0))
         for o in [first] + outs:
             assert torch.equal(o.color, want_small.color) and torch.equal(o.depth, want_small.depth)
         grown = call(d, big, g_big)                                   # same shape, many times the pairs: the plan cannot hold
@@ -378,6 +383,43 @@ def test_prepared_steps_follow_fresh_tensors_of_every_call(hip_lib, step_binding
     entries = [e for es in d._prepared_steps.values() for e in es]
     assert len(entries) == 1 and entries[0].gen == 4 and len(seen) > 1      # call 0 the general way, calls 1 - 4 on ONE step
     assert eager._prepared_steps == {}
+
+
+def test_evaluation_calls_whose_tensors_move_run_on_a_forward_only_step(hip_lib, step_binding):
+    """A validation loop hands the decoder NEW tensors every batch: the graph cache (keyed by addresses) never sees a key
+    twice.  Such calls run on a forward-only prepared step (keyed by shapes, inputs bound per call): results are exact
+    mode's bit for bit, follow the tensors of the call, and a plan that does not hold for a call's inputs is caught behind
+    the projection kernel and the call re-run exactly -- never NaN."""
+    spf, dec, b, d, g, args, exact = _setup(seed=13, prepare=True)
+    d.max_pairs = d.max_pairs._replace(check="backward")
+    ref = util.product_decoder()
+
+    def fresh(scale_opacity=1.0, scale_scales=1.0):
+        gg = dec.Gaussians(b.means.clone(), None, b.rotations.clone(), b.scales * scale_scales, b.harmonics.clone(),
+                           b.opacities * scale_opacity)
+        return gg, b.extrinsics.clone(), b.intrinsics.clone(), b.near.clone(), b.far.clone(), b.image_shape
+
+    with torch.no_grad():
+        outs = [d.forward(*fresh()) for _ in range(4)]              # general, prepared, bound, bound
+        entries = [e for es in d._prepared_steps.values() for e in es]
+        assert len(entries) == 1 and entries[0].step.gpair is None and not d._graphs
+        assert (entries[0].step.fast is not None) == (step_binding == "compiled_step")
+        assert all(torch.equal(o.color, exact.color) and torch.equal(o.depth, exact.depth) for o in outs)
+        assert len({o.color.data_ptr() for o in outs}) == 4
+        dim = fresh(scale_opacity=0.5)
+        got, want = d.render(*dim), ref.render(*dim)
+        assert torch.equal(got[0].color, want[0].color) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[2])
+        assert not torch.equal(got[0].color, exact.color) and spf.plan_flags(d.last_call) == 0
+        big = fresh(scale_scales=150.0)                              # the plan cannot hold for these
+        got, want = d.forward(*big), ref.forward(*big)
+        assert not bool(torch.isnan(got.color).any()) and torch.equal(got.color, want.color)
+        again = d.forward(*fresh())                                  # and the step is as good as before
+        assert torch.equal(again.color, exact.color)
+        # tensors that stay where they are run on the same step; the graph cache has nothing to do
+        for _ in range(3):
+            still = d.forward(*args())
+        assert not d._graphs and torch.equal(still.color, exact.color) and entries[0].gen == 0
+        assert [len(v) for v in d._prepared_steps.values()] == [1]
 
 
 def test_prepared_step_backward_into_a_gradient_bucket(hip_lib, step_binding):
