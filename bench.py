@@ -88,6 +88,10 @@ def total_bytes(S, V, G, K, P, D_total) -> float:
     return S * V * (G * (308 + 36 * K) + 60.0 * P) + 124.0 * D_total
 
 
+HOST_BINDING = None      # cpulist this process was bound to (main), or None
+WIDE_AFFINITY = None     # the affinity it started with (the CPU baseline's threads get it back)
+
+
 def log(msg: str) -> None:
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -101,6 +105,8 @@ def cpu_baseline(args, batch_cpu) -> dict:
     from spfsplatv2_amd import synthetic as syn
     host_cores = os.cpu_count() or 1
     cores = min(host_cores, 16)
+    if HOST_BINDING and WIDE_AFFINITY:
+        os.sched_setaffinity(0, WIDE_AFFINITY)      # (the oracle's thread pool is created now: on the cores the box has)
     torch.set_num_threads(cores)
     S, V = batch_cpu.extrinsics.shape[:2]
     h, w = batch_cpu.image_shape
@@ -415,7 +421,8 @@ def eval_latency(args, dev) -> dict:
             "config": {"workload": f"eval_1x3: 1 scene of {G} Gaussians, {K} SH coefficients per channel, 3 target views, "
                                    f"{h}x{w}, DecoderSplattingCUDA.forward under no_grad",
                        "launch": "one decoder.forward call, then torch.cuda.synchronize: wall time per call; planned "
-                                 "calls run on the module's forward-only prepared step"},
+                                 "calls run on the module's forward-only prepared step",
+                       "host_binding": HOST_BINDING and f"process bound to CPUs {HOST_BINDING} (one L3 group next to the GPU)"},
             "latency_ms": {"exact_mode_median": round(exact_med, 4), "exact_mode_min": round(exact_min, 4),
                            "unchanged_caller_median": round(default_med, 4), "unchanged_caller_min": round(default_min, 4),
                            "planned_median": round(plan_med, 4), "planned_min": round(plan_min, 4),
@@ -530,6 +537,8 @@ def rope_bench(args, dev) -> dict:
     from tests import util
     host_cores = os.cpu_count() or 1
     cores = min(host_cores, 16)
+    if HOST_BINDING and WIDE_AFFINITY:
+        os.sched_setaffinity(0, WIDE_AFFINITY)      # (the CPU baselines run on the cores the box has)
     torch.set_num_threads(cores)
     lib = util.rope_oracle_lib()
     cpu = []
@@ -633,6 +642,17 @@ def main():
         dist.barrier()
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
+
+    # One process per GPU, bound to one L3 group of the CPUs next to it (what `numactl --physcpubind` does from outside):
+    # the host-bound lines (`--api module`, `--eval-latency`, `--eager`) are two host threads taking turns, and the same
+    # command ran 0.358 ms per step with both in one L3 group and 0.420 with one on each socket -- per-process luck
+    # otherwise (spfsplatv2_amd/hostbind.py).  The graph-replayed headline does not care.  SPF_BIND=0: leave placement alone.
+    global HOST_BINDING, WIDE_AFFINITY
+    WIDE_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if os.environ.get("SPF_BIND", "1") != "0":
+        from spfsplatv2_amd.hostbind import bind_to_gpu_l3
+        HOST_BINDING = bind_to_gpu_l3(dev.index)
+        log(f"host threads bound to CPUs {HOST_BINDING}" if HOST_BINDING else "host threads not bound (topology not readable)")
 
     if args.eval_latency or args.rope:
         if world != 1:
@@ -994,6 +1014,7 @@ def main():
                                    + (" and through the adapter to the raw channels" if args.with_adapter else "")
                                    + ("; harmonics band-split [.,3,16] | [.,3,9] (sh_layout 2)" if args.sh_split else ""),
                        "loss": "torch.nn.functional.mse_loss" if args.torch_loss else "spfsplatv2_amd.mse_loss (fused HIP)",
+                       "host_binding": HOST_BINDING and f"process bound to CPUs {HOST_BINDING} (one L3 group next to the GPU)",
                        "scenes_per_gpu": S, "views_per_scene": V, "gaussians_per_scene": G, "image": [h, w],
                        "sh_coeffs": K, "renders_per_step": renders, "pairs_per_render": round(D_total / (S * V), 1),
                        "s_mult": args.s_mult, "pair_buffer": ("module default: planned by DecoderSplattingCUDA itself, verified per call (one host sync at the "
