@@ -293,7 +293,10 @@ def run_secondary(args) -> dict:
                *extra]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, env=dict(env0, **env_extra), capture_output=True, text=True, timeout=180)
+            # (a child starts with the affinity this process STARTED with and binds itself: its CPU baselines included)
+            widen = (lambda: os.sched_setaffinity(0, WIDE_AFFINITY)) if WIDE_AFFINITY else None
+            r = subprocess.run(cmd, env=dict(env0, **env_extra), capture_output=True, text=True, timeout=180,
+                               preexec_fn=widen)
             if r.returncode != 0:
                 raise RuntimeError(f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ''}")
             line = json.loads(r.stdout.strip().splitlines()[-1])
