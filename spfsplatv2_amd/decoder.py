@@ -541,14 +541,15 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             return None
         grad = torch.is_grad_enabled()
         flags = []
+        dev = tensors[0].device
         for t in tensors:
-            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
-                return None
+            if t.dtype != torch.float32 or t.device != dev or not t.is_cuda or not t.is_contiguous():
+                return None                              # (the general launcher names what is wrong with it)
             flags.append(grad and bool(t.requires_grad))
         if any(flags[1:4]):                             # (intrinsics / near / far are not differentiable inputs)
             return None
         band4 = sh_band4_default() if self.sh_band4 is None else bool(self.sh_band4)
-        return (tuple(t.shape for t in tensors), tuple(flags), tensors[0].device.index, tuple(image_shape),
+        return (tuple(t.shape for t in tensors), tuple(flags), dev.index, tuple(image_shape),
                 int(plan.capacity), int(plan.max_tile_list), band4, self.background_color.data_ptr(),
                 self.make_scale_invariant, self.enable_cov_grad, self.enable_sh_grad)
 
@@ -595,8 +596,8 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             import warnings
             self.prepare_steps = False
             self._prepare_seen.pop(key, None)
-            warnings.warn(f"spfsplatv2_amd: preparing the training call failed ({type(e).__name__}: {e}); this decoder "
-                          "launches its training calls the general way from now on")
+            warnings.warn(f"spfsplatv2_amd: preparing a step for this call failed ({type(e).__name__}: {e}); this decoder "
+                          "launches its calls the general way from now on")
             return None
         entry.record = CallRecord(counters=step.counters, plan=step.plan_info)
         entry.nbytes = step.nbytes

@@ -1,4 +1,4 @@
-"""development: where the host's time goes in one C2 step through the decoder MODULE (graph-replayed training call):
+"""development: where the host's time goes in one C2 step through the decoder MODULE (training call on a prepared step):
 wall time per phase with a device synchronisation only at the end of the step.   python tools/hostcost_module.py"""
 import os
 import sys
