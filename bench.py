@@ -92,6 +92,21 @@ HOST_BINDING = None      # cpulist this process was bound to (main), or None
 WIDE_AFFINITY = None     # the affinity it started with (the CPU baseline's threads get it back)
 
 
+def bind_host(dev) -> None:
+    """One process per GPU, its launching thread bound to one L3 group of the CPUs next to it (what `numactl --physcpubind`
+    does from outside): the host-bound lines (`--api module`, `--eval-latency`, `--eager`) are two host threads taking turns
+    -- the caller's and autograd's, which is created later and inherits the binding --, and the same command ran 0.358 ms
+    per step with both in one L3 group and 0.420 with one on each socket: per-process luck otherwise
+    (spfsplatv2_amd/hostbind.py).  Called AFTER the synthetic inputs have been made: torch's CPU thread pool exists by then
+    and keeps the cores the box has (created under the binding, its 100+ threads would share 16 CPUs).  The graph-replayed
+    headline does not care either way.  SPF_BIND=0: leave placement alone."""
+    global HOST_BINDING
+    if os.environ.get("SPF_BIND", "1") != "0" and HOST_BINDING is None:
+        from spfsplatv2_amd.hostbind import bind_to_gpu_l3
+        HOST_BINDING = bind_to_gpu_l3(dev.index)
+        log(f"launching thread bound to CPUs {HOST_BINDING}" if HOST_BINDING else "host threads not bound (topology not readable)")
+
+
 def log(msg: str) -> None:
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -334,6 +349,7 @@ def eval_latency(args, dev) -> dict:
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import decoder as dec, synthetic as syn
     b = syn.make_batch("REF2V", 1, 3, seed=4242).to(dev)
+    bind_host(dev)
     h, w = b.image_shape
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     decoder = dec.get_decoder(dec.DecoderSplattingCUDACfg(name="splatting_cuda", background_color=[0.0, 0.0, 0.0],
@@ -646,16 +662,8 @@ def main():
     import spfsplatv2_amd as spf
     from spfsplatv2_amd import _lib, synthetic as syn
 
-    # One process per GPU, bound to one L3 group of the CPUs next to it (what `numactl --physcpubind` does from outside):
-    # the host-bound lines (`--api module`, `--eval-latency`, `--eager`) are two host threads taking turns, and the same
-    # command ran 0.358 ms per step with both in one L3 group and 0.420 with one on each socket -- per-process luck
-    # otherwise (spfsplatv2_amd/hostbind.py).  The graph-replayed headline does not care.  SPF_BIND=0: leave placement alone.
-    global HOST_BINDING, WIDE_AFFINITY
+    global WIDE_AFFINITY
     WIDE_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
-    if os.environ.get("SPF_BIND", "1") != "0":
-        from spfsplatv2_amd.hostbind import bind_to_gpu_l3
-        HOST_BINDING = bind_to_gpu_l3(dev.index)
-        log(f"host threads bound to CPUs {HOST_BINDING}" if HOST_BINDING else "host threads not bound (topology not readable)")
 
     if args.eval_latency or args.rope:
         if world != 1:
@@ -675,6 +683,7 @@ def main():
     else:                   # independent scenes per rank (scene-first sharding of a larger batch)
         batch_cpu = syn.make_batch(args.config, S, V, seed=1000 + rank, s_mult=args.s_mult)
     b = batch_cpu.to(dev)
+    bind_host(dev)
     h, w = b.image_shape
     G, K = b.means.shape[1], b.harmonics.shape[-1]
     names = ("means", "scales", "rotations", "opacities", "harmonics", "extrinsics")

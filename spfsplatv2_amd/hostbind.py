@@ -5,9 +5,12 @@ taking turns: the caller's and autograd's device thread.  Where the kernel puts 
 two-socket EPYC host the same command ran the BASELINE config-2 step in 0.358 ms per step with both threads in one L3
 group (one CCD), 0.376 - 0.380 spread over one socket and 0.420 with one thread on each socket (round 6,
 ``tools/child_probe.sh``; the GPU's kernels take 0.354).  ``bind_to_gpu_l3`` pins the calling process to ONE L3 group
-of the NUMA node the GPU hangs off -- what ``numactl --physcpubind`` would do from outside.  Call it before the first
-backward pass (autograd's thread inherits the affinity) and widen it again (``os.sched_setaffinity(0, saved)``) around
-CPU-heavy work such as a DataLoader's workers.
+of the NUMA node the GPU hangs off -- what ``numactl --physcpubind`` would do from outside.  It binds the CALLING THREAD
+(Linux affinity is per thread) and whatever that thread creates afterwards: call it before the first backward pass
+(autograd's thread then inherits it) but AFTER torch's CPU thread pool has done its first parallel work -- a pool created
+under the binding puts its 100+ threads on one CCD (bench.py did that for one run: 15 times the wall time of its input
+generation) -- and widen it again (``os.sched_setaffinity(0, saved)``) around CPU-heavy work such as starting a
+DataLoader's workers.
 """
 from __future__ import annotations
 
@@ -77,7 +80,7 @@ def choose_group(local: list[int], allowed, k: int, n: int, sys_root: Path = _SY
 
 
 def bind_to_gpu_l3(device_index: Optional[int] = None, sys_root: Path = _SYS) -> Optional[str]:
-    """Pin this process (all of its current thread's future children included) to one L3 group of the CPUs next to HIP
+    """Pin the calling thread (and the threads it creates from now on) to one L3 group of the CPUs next to HIP
     device `device_index` (default: the current device).  Returns the cpulist it was bound to, or None when the topology
     cannot be read (no sysfs entry, a cpuset without local CPUs, no ``sched_setaffinity``) -- nothing is changed then."""
     try:
