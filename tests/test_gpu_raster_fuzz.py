@@ -98,7 +98,7 @@ def test_wide_seeds_at_the_edge_of_the_per_element_gate(hip_lib, seed):
 
 
 def test_wide_seed_with_one_pixel_on_the_alpha_threshold_of_a_far_needle(hip_lib):
-    """The one disagreement of round 6's fuzz campaigns (profiles/r06_fuzz_campaign_c.json; 22,065 cases on the final
+    """The one disagreement of round 6's fuzz campaigns (profiles/r06_fuzz_campaign_c.json; 30,096 cases on the final
     kernels): ONE pixel of a 5 x 249 image, under a needle (sigma 0.74 x 530 px) centred 1,545 px outside it whose alpha
     there is within 2e-4 of 1/255.  The exponent's three terms are 145, -269 and 133 (they sum to 8.6); the product's conic
     is good to 3 ulp of each entry, which moves ln(alpha) by up to 1.3e-4 -- more than the oracle's knife-edge window allots
