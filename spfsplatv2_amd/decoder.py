@@ -735,7 +735,6 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             return DecoderOutput(color, depth), alpha, radii
         tkey = self._prepare_key(tensors, image_shape)
         trains = tkey is not None and any(tkey[1])
-        key = None if trains else self._eval_graph_key(tensors, image_shape)
         if tkey is not None:
             # training calls, and evaluation calls on forward-only steps: measured at the test_step shape, a prepared
             # step's five launches into fresh outputs (0.094 ms per call and synchronisation) beat a replay of the same
@@ -759,6 +758,7 @@ class DecoderSplattingCUDA(Decoder[DecoderSplattingCUDACfg]):
             if entry is not None:
                 return self._render_prepared(entry, gaussians, extrinsics, intrinsics, near, far, want_extra, trains,
                                              image_shape)
+        key = None if trains else self._eval_graph_key(tensors, image_shape)
         if key is None:
             color, depth, alpha, radii = self._render_eager(gaussians, extrinsics, intrinsics, near, far, image_shape,
                                                             self.max_pairs, self._own_record())
