@@ -1,6 +1,9 @@
-"""The decoder module's cache of captured HIP graphs for evaluation-shaped calls (no gradient, planned pair budget):
+"""The decoder module's host paths for planned calls.  Evaluation-shaped calls (no gradient, planned pair budget):
 DecoderSplattingCUDA.forward at the reference's test_step shape (b = 1, v = 3, model_wrapper.py:415-454) is launch-bound
-from Python, so the second call of a key is captured and later ones are one graph launch (decoder.py)."""
+from Python; the module runs such calls on forward-only PREPARED steps (keyed by shapes, inputs bound per call) and keeps
+round 5's cache of captured HIP graphs (second call of the same addresses captured, later ones one graph launch) for plans
+that cannot be prepared -- the cache's own tests below switch the prepared steps off.  Training calls: prepared steps with
+one autograd node, from the compiled binding or from Python (decoder.py)."""
 import pytest
 import torch
 
